@@ -1,0 +1,123 @@
+/*
+ * sam3_lora_amd -- C-ABI of the MI355X (gfx950) LoRA adapter hot path.
+ *
+ * This is the drop-in boundary for the ONE path this library accelerates: the LoRA branch
+ * of an adapted nn.Linear inside the SAM3 image-model training step,
+ *
+ *     y = W x + b  +  (alpha/r) * B A drop(x)          and its backward into gx, gA, gB.
+ *
+ * The reference (Sompote/sam3_lora) is 100 % Python and has no FFI seam for this path; each
+ * entry point below names the reference code whose arithmetic it replaces (paths relative to
+ * the reference checkout).  The host-side mirrors of the reference modules
+ * (sam3_lora_amd/lora_layers.py, sam3_lora_amd/lora/) bind these with ctypes; INTEGRATION.md
+ * shows the binding a maintainer would add to the reference itself.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; matrices are row-major, leading
+ *     dimensions (ld*) are in ELEMENTS; activation base pointers and ld*sizeof(elem) must be
+ *     16-byte aligned; in_features and out_features must be multiples of 8.
+ *   - `stream` is a hipStream_t (passed as void* so that this header needs no HIP include).
+ *     Nothing here synchronises the stream or the device, allocates, or frees.
+ *   - scratch memory comes from the caller (`workspace`); size it with the *_workspace_bytes
+ *     functions.  It may be reused by the next call on the same stream.
+ *   - return value: 0 on success, a negative SAM3_LORA_E* code otherwise; the calling thread
+ *     can read a description from sam3_lora_last_error() (thread-local).  No C++ exception
+ *     crosses this boundary.  Entry points are thread-safe and keep no thread-affine state
+ *     (PyTorch runs backward, and the activation-checkpoint recompute, on other threads).
+ *   - LoRA parameters A and B are the fp32 master tensors in the layout of the reference
+ *     module they come from:
+ *         SAM3_LORA_LAYOUT_ROOT    (0): A[in, r],  B[r, out]   lora_layers.py:38-39
+ *         SAM3_LORA_LAYOUT_PACKAGE (1): A[r, in],  B[out, r]   sam3_lora/lora/lora_layer.py:47-48
+ *     1 <= r <= 32.
+ *   - activation dtype (x, y, gy, gx): SAM3_LORA_BF16 or SAM3_LORA_F32.  All contractions run
+ *     on bf16 MFMA with fp32 accumulation; gA/gB are accumulated and returned in fp32.
+ */
+#ifndef SAM3_LORA_AMD_H
+#define SAM3_LORA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAM3_LORA_ABI_VERSION 1
+
+#define SAM3_LORA_LAYOUT_ROOT 0
+#define SAM3_LORA_LAYOUT_PACKAGE 1
+
+#define SAM3_LORA_BF16 0
+#define SAM3_LORA_F32 1
+
+#define SAM3_LORA_OK 0
+#define SAM3_LORA_EINVAL (-22)     /* bad argument (shape, alignment, layout, dtype, rank) */
+#define SAM3_LORA_ENOMEM (-12)     /* workspace too small */
+#define SAM3_LORA_ENOTSUP (-95)    /* valid request this build does not implement */
+#define SAM3_LORA_ELAUNCH (-5)     /* HIP reported a launch error */
+
+/* ABI version of the loaded library (== SAM3_LORA_ABI_VERSION of the header it was built from). */
+int sam3_lora_abi_version(void);
+
+/* Thread-local description of the last error returned to the calling thread ("" if none). */
+const char* sam3_lora_last_error(void);
+
+/* Bytes of the `tT` tensor (bf16, [r_pad, M_pad]) that sam3_lora_fwd can emit for the backward. */
+size_t sam3_lora_saved_t_bytes(int64_t M, int rank);
+
+size_t sam3_lora_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype);
+size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype);
+
+/*
+ * Forward of the LoRA branch, fused with the residual add into the base output:
+ *
+ *     y_inout[M, out] += scaling * (drop(x)[M, in] @ A_c[in, r]) @ B_c[r, out]
+ *
+ * Replaces   lora_layers.py:49-55 (LoRALayer.forward) + the add in :87-91 (LoRALinear.forward)
+ * and        sam3_lora/lora/lora_layer.py:62-79 (LoRALayer.forward, which materialises B@A)
+ *            + the add in :142-158 (LinearWithLoRA.forward).
+ * On entry y_inout holds the frozen layer's output W x + b (computed by the caller, e.g.
+ * hipBLASLt through PyTorch-ROCm).  If `tT_out` is non-NULL it receives t = drop(x) @ A_c as
+ * bf16 [r_pad, M_pad] (sam3_lora_saved_t_bytes) for sam3_lora_bwd; pass NULL in inference.
+ *
+ * drop_p > 0 selects training-mode dropout on x with a counter-based generator keyed by
+ * (seed, offset, element index); the same triple must be passed to sam3_lora_bwd.
+ */
+int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, void* tT_out,
+                  int64_t M, int in_features, int out_features, int rank,
+                  int64_t ldx, int64_t ldy, int layout, float scaling,
+                  float drop_p, uint64_t seed, uint64_t offset, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Backward of the LoRA branch (the reference relies on torch.autograd for it):
+ *
+ *     g  = scaling * gy                       t  = drop(x) @ A_c   (from tT_saved, or recomputed)
+ *     gB_c += t^T @ g         [r, out]        gt = g @ B_c^T       [M, r]
+ *     gA_c += drop(x)^T @ gt  [in, r]         gx_inout += (gt @ A_c^T) * dropmask   [M, in]
+ *
+ * gx_inout holds the frozen layer's input gradient gy @ W on entry (caller-computed) and the
+ * full gradient on exit; pass NULL to skip it (input does not require grad).
+ * gA_accum / gB_accum are fp32 tensors in the caller's `layout`; accumulate != 0 adds into
+ * them (torch's `.grad +=`), accumulate == 0 overwrites.  The M-reduction is a fixed-order
+ * two-stage sum: results are bit-reproducible run to run for identical inputs.
+ */
+int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B,
+                  void* gx_inout, float* gA_accum, float* gB_accum,
+                  int64_t M, int in_features, int out_features, int rank,
+                  int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling,
+                  float drop_p, uint64_t seed, uint64_t offset, int dtype, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Merge for adapter-free inference: Wm[out, in] = W[out, in] + scaling * (A_c @ B_c)^T, fp32.
+ * Replaces sam3_lora/lora/lora_layer.py:81-88 (merge_weights) and :160-178.
+ */
+int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
+                    int in_features, int out_features, int rank, int layout, float scaling,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAM3_LORA_AMD_H */

@@ -1,0 +1,104 @@
+"""
+ctypes binding of the C-ABI in include/sam3_lora_amd.h.
+
+There is deliberately NO fallback: if the shared library is missing or does not export the
+expected symbols, importing/using the LoRA forward raises.  (The library is built in-tree by
+``__graft_entry__.build()`` / ``python -m sam3_lora_amd.build``.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+from .build import LIB_PATH
+
+LAYOUT_ROOT = 0
+LAYOUT_PACKAGE = 1
+DT_BF16 = 0
+DT_F32 = 1
+ABI_VERSION = 1
+
+EXPORTS = (
+    "sam3_lora_abi_version", "sam3_lora_last_error", "sam3_lora_saved_t_bytes",
+    "sam3_lora_fwd_workspace_bytes", "sam3_lora_bwd_workspace_bytes",
+    "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge",
+)
+
+_lib = None
+_lock = threading.Lock()
+
+
+class LoRAKernelError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    lib.sam3_lora_abi_version.restype = c_int
+    lib.sam3_lora_abi_version.argtypes = []
+    lib.sam3_lora_last_error.restype = c_char_p
+    lib.sam3_lora_last_error.argtypes = []
+    lib.sam3_lora_saved_t_bytes.restype = c_size_t
+    lib.sam3_lora_saved_t_bytes.argtypes = [c_int64, c_int]
+    for f in (lib.sam3_lora_fwd_workspace_bytes, lib.sam3_lora_bwd_workspace_bytes):
+        f.restype = c_size_t
+        f.argtypes = [c_int64, c_int, c_int, c_int, c_int]
+    lib.sam3_lora_fwd.restype = c_int
+    lib.sam3_lora_fwd.argtypes = [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,      # x, A, B, y_inout, tT_out
+        c_int64, c_int, c_int, c_int,                          # M, in, out, rank
+        c_int64, c_int64, c_int, c_float,                      # ldx, ldy, layout, scaling
+        c_float, c_uint64, c_uint64, c_int,                    # drop_p, seed, offset, dtype
+        c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
+    ]
+    lib.sam3_lora_bwd.restype = c_int
+    lib.sam3_lora_bwd.argtypes = [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,      # gy, x, tT_saved, A, B
+        c_void_p, c_void_p, c_void_p,                          # gx_inout, gA_accum, gB_accum
+        c_int64, c_int, c_int, c_int,                          # M, in, out, rank
+        c_int64, c_int64, c_int64, c_int, c_float,             # ldgy, ldx, ldgx, layout, scaling
+        c_float, c_uint64, c_uint64, c_int, c_int,             # drop_p, seed, offset, dtype, accumulate
+        c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
+    ]
+    lib.sam3_lora_merge.restype = c_int
+    lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_float, c_void_p]
+
+
+def load(path: str | None = None):
+    """Load (once) and return the ctypes handle.  Raises LoRAKernelError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        p = path or os.environ.get("SAM3_LORA_AMD_LIB") or LIB_PATH
+        if not os.path.exists(p):
+            raise LoRAKernelError(
+                f"sam3_lora_amd: HIP library not found at {p}. Build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                f"There is no CPU/PyTorch fallback for the LoRA path.")
+        try:
+            lib = ctypes.CDLL(p)
+        except OSError as e:  # missing libamdhip64 etc.
+            raise LoRAKernelError(f"sam3_lora_amd: cannot load {p}: {e}") from e
+        missing = [s for s in EXPORTS if not hasattr(lib, s)]
+        if missing:
+            raise LoRAKernelError(f"sam3_lora_amd: {p} lacks symbols {missing}")
+        _declare(lib)
+        v = lib.sam3_lora_abi_version()
+        if v != ABI_VERSION:
+            raise LoRAKernelError(f"sam3_lora_amd: ABI version {v} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return (load().sam3_lora_last_error() or b"").decode()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise LoRAKernelError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,759 @@
+// sam3_lora_amd -- hand-written CDNA4 (gfx950) kernels for the LoRA adapter hot path and the
+// C-ABI of include/sam3_lora_amd.h.  gfx950 only: 64-wide wavefronts, bf16 MFMA
+// (v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16), LDS transpose reads (ds_read_b64_tr_b16).
+//
+// The path is HBM-bound (arithmetic intensity ~9 FLOP/B against a machine balance of ~300), so
+// the design is about touching each activation byte once, in full 128-B lines:
+//
+//   T1  k_t1   T[M,r]    = X[M,K] . W1^T           row reduction  (t = x.A ; gt = gy.B^T)
+//   T2  k_t2   Y[M,N]   += s * T[M,r] . W2[r,N]    rank-r update  (y += s.t.B ; gx += s.gt.A^T)
+//   T3  k_t3   G[r,N]    = T^T[r,M] . X[M,N]       column reduction over M (gB ; gA), split over
+//                                                  row ranges, fixed-order second-stage sum
+//
+// MFMA operand roles are chosen so that no result ever needs a cross-lane shuffle:
+//   * T1 computes t^T (A-operand = LoRA weight, B-operand = activation rows): the C/D layout
+//     (lane&15 = activation row, (lane>>4)*4+reg = rank index) is exactly the B-operand layout
+//     of T2's K=r MFMA and gives 8-byte row-major stores of t.
+//   * T2 computes the update transposed (A-operand = W2^T) so every lane ends with 4 consecutive
+//     output columns of one row; the fp32 tile goes through a wave-private LDS slab once and is
+//     re-read as 16-byte row segments matching the coalesced global load/store of Y.
+//   * T3 contracts over rows, the strided dimension of a row-major activation tile: the tile is
+//     staged row-major in LDS (XOR-swizzled 16-B chunks) and the B-operand is fetched with the
+//     hardware transpose read.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "sam3_lora_amd.h"
+
+typedef unsigned short bf16_t;  // storage type of a bf16 element
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};  // RNE; lowers to v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// 8 consecutive activation elements -> packed bf16x8 (as uint4)
+__device__ __forceinline__ uint4 load8(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 load8(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    return make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+}
+__device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// ------------------------------------------------------------------------------------------
+// pack: fp32 LoRA master weights (either reference layout) -> bf16 operand images, zero padded
+//   dst[i][j] (row-major I x J) = (i < Iv && j < Jv) ? src[i*si + j*sj] : 0
+// ------------------------------------------------------------------------------------------
+struct PackJob {
+    const float* src;
+    bf16_t* dst;
+    int I, J, Iv, Jv;
+    long long si, sj;
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackJob j0, PackJob j1) {
+    const PackJob jb = blockIdx.y == 0 ? j0 : j1;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)jb.I * jb.J) return;
+    const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
+    const float v = (i < jb.Iv && j < jb.Jv) ? jb.src[i * jb.si + j * jb.sj] : 0.f;
+    bf16x2 t = {(__bf16)v, (__bf16)0.f};
+    jb.dst[idx] = (bf16_t)(__builtin_bit_cast(unsigned, t) & 0xffffu);
+}
+
+// ------------------------------------------------------------------------------------------
+// T1: T[Mp, RP] (row-major bf16) and TT[RP, Mp] (bf16) = X[M, K] . W1[RP, K]^T
+//   workgroup = 64 rows x full K, 4 waves x 16 rows; K streamed in 128-column chunks through a
+//   double-buffered, XOR-swizzled LDS tile shared by the 4 waves (W1 chunk re-used 4x).
+// ------------------------------------------------------------------------------------------
+template <typename XT, int RT>
+__global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long ldx,
+                                            const bf16_t* __restrict__ W1, bf16_t* __restrict__ T,
+                                            bf16_t* __restrict__ TT, long long M, long long Mp, int K) {
+    constexpr int RP = RT * 16, BM = 64, BK = 128, CPR = BK / 8;
+    __shared__ uint4 xs[2][BM * CPR];
+    __shared__ uint4 ws[2][RP * CPR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int nk = (K + BK - 1) / BK;
+    const int lrow = tid >> 4, lc = tid & 15;
+
+    uint4 xr[4], wr[RT];
+    auto gload = [&](int kc) {
+        const int k = kc * BK + lc * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long m = m0 + lrow + 16 * i;
+            xr[i] = (m < M && k < K) ? load8(X + m * ldx + k) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+            const int r = lrow + 16 * j;
+            wr[j] = (k < K) ? *reinterpret_cast<const uint4*>(W1 + (long long)r * K + k) : zero4();
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lrow + 16 * i;
+            xs[buf][row * CPR + (lc ^ (row & 15))] = xr[i];
+        }
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+            const int r = lrow + 16 * j;
+            ws[buf][r * CPR + (lc ^ (r & 15))] = wr[j];
+        }
+    };
+
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) gload(kc + 1);
+        const int row = wave * 16 + n;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            const int c = kk * 4 + g;
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[buf][row * CPR + (c ^ n)]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, ws[buf][(rt * 16 + n) * CPR + (c ^ n)]);
+                // D[i = rank idx][n = activation row] += sum_k W1[i][k] * X[row][k]
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[rt], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    // lane (n, g) holds t[row = m0 + wave*16 + n][rank idx = rt*16 + g*4 + j]
+    const long long m = m0 + wave * 16 + n;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const unsigned p0 = pack2(acc[rt][0], acc[rt][1]), p1 = pack2(acc[rt][2], acc[rt][3]);
+        *reinterpret_cast<uint2*>(T + m * RP + rt * 16 + g * 4) = make_uint2(p0, p1);
+        const int r = rt * 16 + g * 4;
+        TT[(long long)(r + 0) * Mp + m] = (bf16_t)(p0 & 0xffffu);
+        TT[(long long)(r + 1) * Mp + m] = (bf16_t)(p0 >> 16);
+        TT[(long long)(r + 2) * Mp + m] = (bf16_t)(p1 & 0xffffu);
+        TT[(long long)(r + 3) * Mp + m] = (bf16_t)(p1 >> 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// T2: Y[M, N] += scale * T[M, RP] . W2[RP, N]      (W2 given transposed: W2t[N, RP])
+//   one wave = 128 output columns (W2 fragments live in registers) x a strided set of 16-row
+//   tiles; no workgroup barrier anywhere -- each wave streams on its own.
+// ------------------------------------------------------------------------------------------
+template <typename YT>
+struct YTile;  // 16 rows x 128 cols, lane L owns rows p*4 + (L>>4), cols (L&15)*8 .. +8
+
+template <>
+struct YTile<bf16_t> {
+    uint4 v[4];
+    __device__ __forceinline__ void load(const bf16_t* Y, long long ldy, long long m0, int col, int lane,
+                                         long long M, int N) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long long m = m0 + p * 4 + (lane >> 4);
+            v[p] = (m < M && col < N) ? *reinterpret_cast<const uint4*>(Y + m * ldy + col) : zero4();
+        }
+    }
+    __device__ __forceinline__ void add_store(bf16_t* Y, long long ldy, long long m0, int col, int lane,
+                                              long long M, int N, const float* slab, int ldw, float scale) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int rl = p * 4 + (lane >> 4);
+            const long long m = m0 + rl;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
+            uint4 o;
+            o.x = pack2(bf_lo(v[p].x) + scale * a[0], bf_hi(v[p].x) + scale * a[1]);
+            o.y = pack2(bf_lo(v[p].y) + scale * a[2], bf_hi(v[p].y) + scale * a[3]);
+            o.z = pack2(bf_lo(v[p].z) + scale * b[0], bf_hi(v[p].z) + scale * b[1]);
+            o.w = pack2(bf_lo(v[p].w) + scale * b[2], bf_hi(v[p].w) + scale * b[3]);
+            if (m < M && col < N) *reinterpret_cast<uint4*>(Y + m * ldy + col) = o;
+        }
+    }
+};
+
+template <>
+struct YTile<float> {
+    f32x4 v[4][2];
+    __device__ __forceinline__ void load(const float* Y, long long ldy, long long m0, int col, int lane,
+                                         long long M, int N) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long long m = m0 + p * 4 + (lane >> 4);
+            const bool ok = (m < M && col < N);
+            v[p][0] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            v[p][1] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void add_store(float* Y, long long ldy, long long m0, int col, int lane,
+                                              long long M, int N, const float* slab, int ldw, float scale) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int rl = p * 4 + (lane >> 4);
+            const long long m = m0 + rl;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
+            if (m < M && col < N) {
+                *reinterpret_cast<f32x4*>(Y + m * ldy + col) = v[p][0] + scale * a;
+                *reinterpret_cast<f32x4*>(Y + m * ldy + col + 4) = v[p][1] + scale * b;
+            }
+        }
+    }
+};
+
+template <typename YT, int RT>
+__global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
+                                            const bf16_t* __restrict__ W2t, long long M, int N, float scale,
+                                            int tiles_per_wg) {
+    constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
+    __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    float* slab = slab_all[wave];
+    const int c0 = blockIdx.x * CW;
+
+    // W2^T fragments (MFMA A-operand: i = output column, k = rank index), kept for the whole kernel
+    uint2 wlo[8], whi[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const int col = c0 + ct * 16 + n;
+        const bool ok = col < N;
+        wlo[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + g * 4) : make_uint2(0u, 0u);
+        if (RT == 2)
+            whi[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + 16 + g * 4) : make_uint2(0u, 0u);
+    }
+
+    const long long ntiles = (M + 15) / 16;
+    long long t = (long long)blockIdx.y * tiles_per_wg + wave;
+    const long long t_end = min((long long)(blockIdx.y + 1) * tiles_per_wg, ntiles);
+    const int col = c0 + (lane & 15) * 8;
+
+    YTile<YT> cur, nxt;
+    if (t < t_end) nxt.load(Y, ldy, t * 16, col, lane, M, N);
+    for (; t < t_end; t += 4) {
+        const long long m0 = t * 16;
+        cur = nxt;
+        if (t + 4 < t_end) nxt.load(Y, ldy, (t + 4) * 16, col, lane, M, N);
+        // T fragment (B-operand: k = rank index, n = activation row)
+        const uint2 tlo = *reinterpret_cast<const uint2*>(T + (m0 + n) * RP + g * 4);
+        uint2 thi = make_uint2(0u, 0u);
+        if (RT == 2) thi = *reinterpret_cast<const uint2*>(T + (m0 + n) * RP + 16 + g * 4);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (RT == 1) {
+                d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wlo[ct]),
+                                                             __builtin_bit_cast(s16x4, tlo), d, 0, 0, 0);
+            } else {
+                const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
+                const uint4 tb = make_uint4(tlo.x, tlo.y, thi.x, thi.y);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa),
+                                                           __builtin_bit_cast(bf16x8, tb), d, 0, 0, 0);
+            }
+            // lane (n, g): delta[row n][cols ct*16 + g*4 .. +4]
+            *reinterpret_cast<f32x4*>(slab + n * LDW + ct * 16 + g * 4) = d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cur.add_store(Y, ldy, m0, col, lane, M, N, slab, LDW, scale);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// T3: Gpart[rs][RP][N] = sum_{m in row range rs} TT[:, m] (x) X[m, :]
+//   workgroup = 256 columns x a row range; 64-row stages, double-buffered swizzled LDS tile;
+//   wave w owns column tiles 4w..4w+3; B-operand via ds_read_b64_tr_b16.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename XT, int RT, bool GATHER>
+__global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
+                                            const bf16_t* __restrict__ TT, float* __restrict__ Gpart,
+                                            long long M, long long Mp, int N, int rows_per_wg) {
+    constexpr int RP = RT * 16, BR = 64, CW = 256, CPR = CW / 8;
+    __shared__ uint4 xs[2][BR * CPR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.x * CW;
+    const long long r_begin = (long long)blockIdx.y * rows_per_wg;
+    const long long r_end = min(r_begin + rows_per_wg, Mp);
+    const int nst = (int)((r_end - r_begin) / BR);
+    const int lrow = tid >> 5, lc = tid & 31;
+
+    uint4 xr[8];
+    auto gload = [&](int s) {
+        const int col = c0 + lc * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long m = r_begin + (long long)s * BR + lrow + 8 * i;
+            xr[i] = (m < M && col < N) ? load8(X + m * ldx + col) : zero4();
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = lrow + 8 * i;
+            xs[buf][row * CPR + (lc ^ (t3_h(row) << 1))] = xr[i];
+        }
+    };
+
+    f32x4 acc[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nst > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) gload(s + 1);
+        const long long mbase = r_begin + (long long)s * BR;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k0 = ks * 32;
+            bf16x8 tf[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                tf[rt] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const uint4*>(TT + (long long)(rt * 16 + n) * Mp + mbase + k0 + g * 8));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ct = wave * 4 + j;
+                bf16x8 xf;
+                if (!GATHER) {
+                    // 16-lane group g reads the [4 rows x 16 cols] blocks at rows k0+g*8+{0..3} and +{4..7};
+                    // lane q supplies the address of row (q>>2), cols (q&3)*4..+3 and receives column q.
+                    const int rowA = k0 + g * 8 + (n >> 2), rowB = rowA + 4;
+                    const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
+                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                    const char* base = reinterpret_cast<const char*>(&xs[buf][0]);
+                    const char* pa = base + ((rowA * CPR + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
+                    const char* pb = base + ((rowB * CPR + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    xf = __builtin_bit_cast(bf16x8, both);
+                } else {
+                    // validation path: explicit 2-byte gathers, lane (n, g) <- X[k0+g*8+jj][ct*16+n]
+                    const bf16_t* b16 = reinterpret_cast<const bf16_t*>(&xs[buf][0]);
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    s16x8 both;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int row = k0 + g * 8 + jj;
+                        const int e = ct * 16 + n, c = e >> 3;
+                        both[jj] = (short)b16[(row * CPR + (c ^ (t3_h(row) << 1))) * 8 + (e & 7)];
+                    }
+                    xf = __builtin_bit_cast(bf16x8, both);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    // D[i = rank idx][n = column] += sum_m TT[i][m] * X[m][col]
+                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[rt], xf, acc[rt][j], 0, 0, 0);
+            }
+        }
+        if (s + 1 < nst) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = Gpart + (long long)blockIdx.y * RP * N;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c0 + (wave * 4 + j) * 16 + n;
+            if (col < N) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) out[(long long)(rt * 16 + g * 4 + jj) * N + col] = acc[rt][j][jj];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// second-stage, fixed-order reduction of the T3 partials into the fp32 gradient tensors
+//   dst[r*sr + n*sn] (+)= scale * sum_rs part[rs][r][n]
+// ------------------------------------------------------------------------------------------
+struct ReduceJob {
+    const float* part;
+    float* dst;
+    int NR, RP, N, rank;
+    long long sr, sn;
+};
+
+__global__ __launch_bounds__(256) void k_reduce(ReduceJob j0, ReduceJob j1, float scale, int accumulate) {
+    const ReduceJob jb = blockIdx.y == 0 ? j0 : j1;
+    if (jb.dst == nullptr) return;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)jb.rank * jb.N) return;
+    const int r = (int)(idx / jb.N), n = (int)(idx % jb.N);
+    float s = 0.f;
+    for (int rs = 0; rs < jb.NR; ++rs) s += jb.part[((long long)rs * jb.RP + r) * jb.N + n];
+    s *= scale;
+    float* d = jb.dst + r * jb.sr + n * jb.sn;
+    *d = accumulate ? (*d + s) : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// merge: Wm[o][i] = W[o][i] + scaling * sum_r A_c[i][r] * B_c[r][o]     (fp32, one-off)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge(const float* __restrict__ W, const float* __restrict__ A,
+                                               const float* __restrict__ B, float* __restrict__ Wm, int in_f,
+                                               int out_f, int rank, long long a_si, long long a_sr,
+                                               long long b_sr, long long b_so, float scaling) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)in_f * out_f) return;
+    const int o = (int)(idx / in_f), i = (int)(idx % in_f);
+    float s = 0.f;
+    for (int r = 0; r < rank; ++r) s += A[i * a_si + r * a_sr] * B[r * b_sr + o * b_so];
+    Wm[idx] = W[idx] + scaling * s;
+}
+
+// ==========================================================================================
+// host side: C-ABI
+// ==========================================================================================
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline long long round_up(long long a, long long b) { return (a + b - 1) / b * b; }
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int rpad(int rank) { return rank <= 16 ? 16 : 32; }
+inline size_t esize(int dtype) { return dtype == SAM3_LORA_F32 ? 4 : 2; }
+
+struct T3Plan {
+    int nchunks, NR, rows_per_wg;
+};
+T3Plan plan_t3(long long Mp, int N) {
+    T3Plan p;
+    p.nchunks = (N + 255) / 256;
+    const long long stages = Mp / 64;
+    long long nr = (768 + p.nchunks - 1) / p.nchunks;
+    if (nr > stages) nr = stages;
+    if (nr < 1) nr = 1;
+    const long long st_per = (stages + nr - 1) / nr;
+    p.rows_per_wg = (int)(st_per * 64);
+    p.NR = (int)((stages + st_per - 1) / st_per);
+    return p;
+}
+
+int check_common(long long M, int in_f, int out_f, int rank, int layout, int dtype) {
+    if (M <= 0) return fail(SAM3_LORA_EINVAL, "M must be positive (got %lld)", M);
+    if (in_f <= 0 || out_f <= 0 || (in_f % 8) || (out_f % 8))
+        return fail(SAM3_LORA_EINVAL, "in_features/out_features must be positive multiples of 8 (got %d, %d)", in_f, out_f);
+    if (rank < 1 || rank > 32) return fail(SAM3_LORA_EINVAL, "rank must be in [1, 32] (got %d)", rank);
+    if (layout != SAM3_LORA_LAYOUT_ROOT && layout != SAM3_LORA_LAYOUT_PACKAGE)
+        return fail(SAM3_LORA_EINVAL, "unknown layout %d", layout);
+    if (dtype != SAM3_LORA_BF16 && dtype != SAM3_LORA_F32) return fail(SAM3_LORA_EINVAL, "unknown dtype %d", dtype);
+    return 0;
+}
+
+int check_act(const void* p, long long ld, int width, int dtype, const char* what) {
+    if (!p) return fail(SAM3_LORA_EINVAL, "%s is NULL", what);
+    if (ld < width) return fail(SAM3_LORA_EINVAL, "ld of %s (%lld) < row width (%d)", what, ld, width);
+    if (((uintptr_t)p & 15) || ((ld * (long long)esize(dtype)) & 15))
+        return fail(SAM3_LORA_EINVAL, "%s: base pointer and row pitch must be 16-byte aligned", what);
+    return 0;
+}
+
+int launch_ok(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SAM3_LORA_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+bool env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+
+// strides of the canonical views A_c[in, r], B_c[r, out] inside the caller's tensors
+struct Strides {
+    long long a_si, a_sr, b_sr, b_so;
+};
+Strides strides_of(int layout, int in_f, int out_f, int rank) {
+    Strides s;
+    if (layout == SAM3_LORA_LAYOUT_ROOT) {  // A[in, r], B[r, out]
+        s.a_si = rank; s.a_sr = 1; s.b_sr = out_f; s.b_so = 1;
+    } else {  // A[r, in], B[out, r]
+        s.a_si = 1; s.a_sr = in_f; s.b_sr = 1; s.b_so = rank;
+    }
+    return s;
+}
+
+void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
+    const long long na = (long long)a.I * a.J, nb = (long long)b.I * b.J;
+    const long long nmax = na > nb ? na : nb;
+    dim3 grid((unsigned)((nmax + 255) / 256), 2);
+    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, a, b);
+}
+
+template <typename XT>
+void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t* TT, long long M, long long Mp, int K,
+               int RT, hipStream_t st) {
+    dim3 grid((unsigned)(Mp / 64));
+    if (RT == 1)
+        hipLaunchKernelGGL((k_t1<XT, 1>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K);
+    else
+        hipLaunchKernelGGL((k_t1<XT, 2>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K);
+}
+
+template <typename YT>
+void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT,
+               hipStream_t st) {
+    const long long ntiles = (M + 15) / 16;
+    const int nchunks = (N + 127) / 128;
+    long long want = (3072 + nchunks - 1) / nchunks;  // ~3k workgroups of 4 waves
+    long long tiles_per_wg = (ntiles + want - 1) / want;
+    if (tiles_per_wg < 4) tiles_per_wg = 4;
+    tiles_per_wg = round_up(tiles_per_wg, 4);
+    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
+    if (RT == 1)
+        hipLaunchKernelGGL((k_t2<YT, 1>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg);
+    else
+        hipLaunchKernelGGL((k_t2<YT, 2>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg);
+}
+
+template <typename XT>
+void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N,
+               const T3Plan& p, int RT, hipStream_t st) {
+    dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
+    const bool gather = env_flag("SAM3_LORA_T3_GATHER");
+#define T3_LAUNCH(RTV, GV) \
+    hipLaunchKernelGGL((k_t3<XT, RTV, GV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg)
+    if (RT == 1) {
+        if (gather) T3_LAUNCH(1, true); else T3_LAUNCH(1, false);
+    } else {
+        if (gather) T3_LAUNCH(2, true); else T3_LAUNCH(2, false);
+    }
+#undef T3_LAUNCH
+}
+
+struct FwdWs {
+    size_t w1, w2t, t, tt, total;
+};
+FwdWs fwd_ws(long long M, int in_f, int out_f, int rank) {
+    const int RP = rpad(rank);
+    const long long Mp = round_up(M, 64);
+    FwdWs w;
+    size_t off = 0;
+    w.w1 = off; off += al256((size_t)RP * in_f * 2);
+    w.w2t = off; off += al256((size_t)out_f * RP * 2);
+    w.t = off; off += al256((size_t)Mp * RP * 2);
+    w.tt = off; off += al256((size_t)RP * Mp * 2);
+    w.total = off;
+    return w;
+}
+
+struct BwdWs {
+    size_t w1b, w2tb, w1a, gt, gtt, t, tt, pb, pa, total;
+    T3Plan pB, pA;
+};
+BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
+    const int RP = rpad(rank);
+    const long long Mp = round_up(M, 64);
+    BwdWs w;
+    w.pB = plan_t3(Mp, out_f);
+    w.pA = plan_t3(Mp, in_f);
+    size_t off = 0;
+    w.w1b = off; off += al256((size_t)RP * out_f * 2);
+    w.w2tb = off; off += al256((size_t)in_f * RP * 2);
+    w.w1a = off; off += al256((size_t)RP * in_f * 2);
+    w.gt = off; off += al256((size_t)Mp * RP * 2);
+    w.gtt = off; off += al256((size_t)RP * Mp * 2);
+    w.t = off; off += al256((size_t)Mp * RP * 2);
+    w.tt = off; off += al256((size_t)RP * Mp * 2);
+    w.pb = off; off += al256((size_t)w.pB.NR * RP * out_f * 4);
+    w.pa = off; off += al256((size_t)w.pA.NR * RP * in_f * 4);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sam3_lora_abi_version(void) { return SAM3_LORA_ABI_VERSION; }
+
+const char* sam3_lora_last_error(void) { return g_err; }
+
+size_t sam3_lora_saved_t_bytes(int64_t M, int rank) {
+    if (M <= 0 || rank < 1 || rank > 32) return 0;
+    return (size_t)rpad(rank) * (size_t)round_up(M, 64) * 2;
+}
+
+size_t sam3_lora_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
+    if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
+    return fwd_ws(M, in_features, out_features, rank).total;
+}
+
+size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
+    if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
+    return bwd_ws(M, in_features, out_features, rank).total;
+}
+
+int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
+                  int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
+                  float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    (void)seed; (void)offset;
+    g_err[0] = 0;
+    int rc;
+    if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
+    if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
+    if ((rc = check_act(y_inout, ldy, out_features, dtype, "y_inout"))) return rc;
+    if (!A || !B) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
+    if (drop_p != 0.f) return fail(SAM3_LORA_ENOTSUP, "in-kernel dropout (drop_p=%g) is not implemented in this build", drop_p);
+    const FwdWs w = fwd_ws(M, in_features, out_features, rank);
+    if (!workspace || workspace_bytes < w.total)
+        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
+    if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
+    if (tT_out && ((uintptr_t)tT_out & 15)) return fail(SAM3_LORA_EINVAL, "tT_out must be 16-byte aligned");
+
+    hipStream_t st = (hipStream_t)stream;
+    const int RP = rpad(rank), RT = RP / 16;
+    const long long Mp = round_up(M, 64);
+    char* ws = (char*)workspace;
+    bf16_t* W1 = (bf16_t*)(ws + w.w1);
+    bf16_t* W2t = (bf16_t*)(ws + w.w2t);
+    bf16_t* T = (bf16_t*)(ws + w.t);
+    bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+
+    // W1[RP][in] = A_c^T ; W2t[out][RP] = B_c^T
+    PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si};
+    PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr};
+    launch_pack(ja, jb, st);
+    if (dtype == SAM3_LORA_BF16) {
+        launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
+        launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
+    } else {
+        launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
+        launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
+    }
+    return launch_ok("sam3_lora_fwd");
+}
+
+int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
+                  float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
+                  int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
+                  uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)seed; (void)offset;
+    g_err[0] = 0;
+    int rc;
+    if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
+    if ((rc = check_act(gy, ldgy, out_features, dtype, "gy"))) return rc;
+    if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
+    if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
+    if (!A || !B) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
+    if (drop_p != 0.f) return fail(SAM3_LORA_ENOTSUP, "in-kernel dropout (drop_p=%g) is not implemented in this build", drop_p);
+    if (tT_saved && ((uintptr_t)tT_saved & 15)) return fail(SAM3_LORA_EINVAL, "tT_saved must be 16-byte aligned");
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank);
+    if (!workspace || workspace_bytes < w.total)
+        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
+    if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
+
+    hipStream_t st = (hipStream_t)stream;
+    const int RP = rpad(rank), RT = RP / 16;
+    const long long Mp = round_up(M, 64);
+    char* ws = (char*)workspace;
+    bf16_t* W1b = (bf16_t*)(ws + w.w1b);
+    bf16_t* W2tb = (bf16_t*)(ws + w.w2tb);
+    bf16_t* W1a = (bf16_t*)(ws + w.w1a);
+    bf16_t* GT = (bf16_t*)(ws + w.gt);
+    bf16_t* GTT = (bf16_t*)(ws + w.gtt);
+    bf16_t* Tscr = (bf16_t*)(ws + w.t);
+    const bf16_t* TT = (const bf16_t*)tT_saved;
+    float* PB = (float*)(ws + w.pb);
+    float* PA = (float*)(ws + w.pa);
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+
+    // W1b[RP][out] = B_c ; W2tb[in][RP] = A_c
+    PackJob jb{(const float*)B, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so};
+    PackJob ja{(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr};
+    launch_pack(jb, ja, st);
+    const bool bf = dtype == SAM3_LORA_BF16;
+    if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
+        PackJob j1{(const float*)A, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si};
+        PackJob j2{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+        launch_pack(j1, j2, st);
+        bf16_t* TTs = (bf16_t*)(ws + w.tt);
+        if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st);
+        else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st);
+        TT = TTs;
+    }
+    if (bf) {
+        launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
+        if (gB_accum) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);   // gB = t^T . gy
+        if (gA_accum) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);     // gA^T = gt^T . x
+        if (gx_inout) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
+    } else {
+        launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);
+        if (gB_accum) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);
+        if (gA_accum) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);
+        if (gx_inout) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
+    }
+    if (gA_accum || gB_accum) {
+        // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
+        ReduceJob rb{PB, gB_accum, w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
+        ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
+        const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
+        dim3 grid((unsigned)(((nb > na ? nb : na) + 255) / 256), 2);
+        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling, accumulate);
+    }
+    return launch_ok("sam3_lora_bwd");
+}
+
+int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm, int in_features, int out_features,
+                    int rank, int layout, float scaling, void* stream) {
+    g_err[0] = 0;
+    int rc;
+    if ((rc = check_common(1, 8, 8, rank, layout, SAM3_LORA_F32))) return rc;
+    if (in_features <= 0 || out_features <= 0) return fail(SAM3_LORA_EINVAL, "bad shape");
+    if (!W || !A || !B || !Wm) return fail(SAM3_LORA_EINVAL, "NULL pointer");
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+    const long long nel = (long long)in_features * out_features;
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, A, B, Wm,
+                       in_features, out_features, rank, s.a_si, s.a_sr, s.b_sr, s.b_so, scaling);
+    return launch_ok("sam3_lora_merge");
+}
+
+}  // extern "C"

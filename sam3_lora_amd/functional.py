@@ -1,0 +1,227 @@
+"""
+Host-side glue between torch tensors and the C-ABI (include/sam3_lora_amd.h).
+
+``lora_linear`` is the single differentiable entry point both reference-compatible module
+families use (``sam3_lora_amd.lora_layers.LoRALinear`` <- lora_layers.py:58-91 and
+``sam3_lora_amd.lora.LinearWithLoRA`` <- sam3_lora/lora/lora_layer.py:91-158):
+
+    y = F.linear(x, W, b)  +  scaling * (drop(x) @ A_c) @ B_c
+
+The frozen GEMMs (F.linear forward, ``gy @ W`` backward) run on PyTorch-ROCm (hipBLASLt);
+everything involving A and B runs in the hand-written HIP kernels, in place on the GEMM
+outputs.  torch is plumbing here: device memory, the current HIP stream, autograd wiring.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _ffi
+from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, LoRAKernelError
+
+__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
+
+_ws_lock = threading.Lock()
+_workspaces = {}  # (device index, stream handle) -> uint8 tensor
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Scratch buffer reused by consecutive calls on one stream (stream order makes that safe)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    with _ws_lock:
+        buf = _workspaces.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            _workspaces[key] = buf
+    return buf
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float32:
+        return DT_F32
+    raise LoRAKernelError(f"sam3_lora_amd: activations must be bfloat16 or float32, got {t.dtype}")
+
+
+def _require_cuda(*ts: torch.Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise LoRAKernelError(
+                "sam3_lora_amd: the LoRA path runs only on an AMD GPU through the HIP kernels "
+                f"(got a {t.device} tensor); there is no CPU fallback.")
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """[..., C] -> [M, C] with unit column stride and 16-byte aligned rows (copies only if needed)."""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1 or (t2.stride(0) * t2.element_size()) % 16 or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+    return t2
+
+
+def _master(p: torch.Tensor) -> torch.Tensor:
+    p = p.detach()
+    if p.dtype != torch.float32 or not p.is_contiguous():
+        p = p.float().contiguous()
+    return p
+
+
+def _rank_of(A: torch.Tensor, layout: int) -> int:
+    return A.shape[1] if layout == LAYOUT_ROOT else A.shape[0]
+
+
+def saved_t_like(M: int, rank: int, device) -> torch.Tensor:
+    n = _ffi.load().sam3_lora_saved_t_bytes(M, rank)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tensor, scaling: float, layout: int,
+              save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0) -> Optional[torch.Tensor]:
+    """In place: y2[M,out] += scaling * (x2[M,in] @ A_c) @ B_c.  Returns the saved-t blob if asked."""
+    lib = _ffi.load()
+    _require_cuda(x2, A, B, y2)
+    M, fin = x2.shape
+    fout = y2.shape[1]
+    rank = _rank_of(A, layout)
+    dt = _dtype_code(x2)
+    if y2.dtype != x2.dtype:
+        raise LoRAKernelError("sam3_lora_amd: x and y must share a dtype")
+    nws = lib.sam3_lora_fwd_workspace_bytes(M, fin, fout, rank, dt)
+    if nws == 0:
+        raise LoRAKernelError(f"sam3_lora_fwd_workspace_bytes: {_ffi.last_error()}")
+    ws = _workspace(x2.device, nws)
+    tT = saved_t_like(M, rank, x2.device) if save_t else None
+    rc = lib.sam3_lora_fwd(
+        x2.data_ptr(), A.data_ptr(), B.data_ptr(), y2.data_ptr(), tT.data_ptr() if tT is not None else None,
+        M, fin, fout, rank, x2.stride(0), y2.stride(0), layout, float(scaling),
+        float(drop_p), int(seed), int(offset), dt, ws.data_ptr(), ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
+    _ffi.check(rc, "sam3_lora_fwd")
+    return tT
+
+
+def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor,
+              gx2: Optional[torch.Tensor], gA: Optional[torch.Tensor], gB: Optional[torch.Tensor], scaling: float,
+              layout: int, accumulate: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0) -> None:
+    """In place: gx2 += lora input-grad; gA/gB (fp32, caller layout) = or += the LoRA weight grads."""
+    lib = _ffi.load()
+    _require_cuda(gy2, x2, A, B, gx2, gA, gB)
+    M, fin = x2.shape
+    fout = gy2.shape[1]
+    rank = _rank_of(A, layout)
+    dt = _dtype_code(x2)
+    if gy2.dtype != x2.dtype or (gx2 is not None and gx2.dtype != x2.dtype):
+        raise LoRAKernelError("sam3_lora_amd: gy, x and gx must share a dtype")
+    for g in (gA, gB):
+        if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+            raise LoRAKernelError("sam3_lora_amd: gA/gB must be contiguous float32")
+    nws = lib.sam3_lora_bwd_workspace_bytes(M, fin, fout, rank, dt)
+    if nws == 0:
+        raise LoRAKernelError(f"sam3_lora_bwd_workspace_bytes: {_ffi.last_error()}")
+    ws = _workspace(x2.device, nws)
+    rc = lib.sam3_lora_bwd(
+        gy2.data_ptr(), x2.data_ptr(), tT.data_ptr() if tT is not None else None, A.data_ptr(), B.data_ptr(),
+        gx2.data_ptr() if gx2 is not None else None,
+        gA.data_ptr() if gA is not None else None, gB.data_ptr() if gB is not None else None,
+        M, fin, fout, rank, gy2.stride(0), x2.stride(0), gx2.stride(0) if gx2 is not None else fin,
+        layout, float(scaling), float(drop_p), int(seed), int(offset), dt, 1 if accumulate else 0,
+        ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
+    _ffi.check(rc, "sam3_lora_bwd")
+
+
+def merge_weight(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float, layout: int) -> torch.Tensor:
+    """W + scaling * (A_c @ B_c)^T in fp32 on the GPU (lora_layer.py:81-88)."""
+    lib = _ffi.load()
+    _require_cuda(W, A, B)
+    Wf, Af, Bf = W.detach().float().contiguous(), _master(A), _master(B)
+    out = torch.empty_like(Wf)
+    rc = lib.sam3_lora_merge(Wf.data_ptr(), Af.data_ptr(), Bf.data_ptr(), out.data_ptr(), Wf.shape[1], Wf.shape[0],
+                             _rank_of(Af, layout), layout, float(scaling),
+                             ctypes.c_void_p(torch.cuda.current_stream(W.device).cuda_stream))
+    _ffi.check(rc, "sam3_lora_merge")
+    return out
+
+
+class _LoRALinearFn(torch.autograd.Function):
+    """Frozen linear + LoRA branch as one autograd node (saved tensors: x, t^T -- never y or delta)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_mask):
+        _require_cuda(x, weight, A, B)
+        ref = weight if weight is not None else x        # weight None: bare LoRA branch (zero base)
+        cdt = ref.dtype if ref.dtype in (torch.bfloat16, torch.float32) else torch.float32
+        if torch.is_autocast_enabled("cuda"):
+            cdt = torch.get_autocast_dtype("cuda")
+            if cdt not in (torch.bfloat16, torch.float32):
+                raise LoRAKernelError(f"sam3_lora_amd: autocast dtype {cdt} unsupported (use bfloat16)")
+        x2 = _rows(x if x.dtype == cdt else x.to(cdt))
+        w = weight if (weight is None or weight.dtype == cdt) else weight.to(cdt)
+        b = bias if (bias is None or bias.dtype == cdt) else bias.to(cdt)
+        if w is None:
+            fout = B.shape[1] if layout == LAYOUT_ROOT else B.shape[0]
+            y2 = x2.new_zeros(x2.shape[0], fout)
+        else:
+            with torch.autocast("cuda", enabled=False):
+                y2 = F.linear(x2, w, b)                  # frozen GEMM: PyTorch-ROCm / hipBLASLt
+        Am, Bm = _master(A), _master(B)
+        xl = x2 if drop_mask is None else x2 * drop_mask.reshape(x2.shape).to(cdt)
+        need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        tT = lora_fwd_(xl, Am, Bm, y2, scaling, layout, save_t=need_w)
+        ctx.scaling, ctx.layout = scaling, layout
+        ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
+        ctx.has_mask = drop_mask is not None
+        ctx.save_for_backward(xl, w, A, B, tT, drop_mask)
+        return y2.view(*x.shape[:-1], y2.shape[-1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        xl, w, A, B, tT, drop_mask = ctx.saved_tensors
+        gy2 = _rows(gy if gy.dtype == xl.dtype else gy.to(xl.dtype))
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        Am, Bm = _master(A), _master(B)
+        gx2 = None
+        if need_x:
+            if w is None:
+                gx2 = torch.zeros_like(xl)
+            else:
+                with torch.autocast("cuda", enabled=False):
+                    gx2 = gy2 @ w                        # frozen GEMM
+        gA = torch.empty_like(Am) if need_w else None
+        gB = torch.empty_like(Bm) if need_w else None
+        if ctx.has_mask and need_x:
+            # dropout on the LoRA input only: the branch's input-grad is masked before it joins gx
+            gxl = torch.zeros_like(gx2)
+            lora_bwd_(gy2, xl, tT, Am, Bm, gxl, gA, gB, ctx.scaling, ctx.layout)
+            gx2 = gx2 + gxl * drop_mask.reshape(gxl.shape).to(gxl.dtype)
+        else:
+            lora_bwd_(gy2, xl, tT, Am, Bm, gx2, gA, gB, ctx.scaling, ctx.layout)
+        gx = gx2.view(ctx.x_shape).to(ctx.x_dtype) if need_x else None
+        if need_w:
+            gA = gA.to(A.dtype) if ctx.needs_input_grad[3] else None
+            gB = gB.to(B.dtype) if ctx.needs_input_grad[4] else None
+        return gx, None, None, gA, gB, None, None, None
+
+
+def lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], A: torch.Tensor,
+                B: torch.Tensor, scaling: float, layout: int, dropout_p: float = 0.0,
+                training: bool = False) -> torch.Tensor:
+    """``F.linear(x, weight, bias) + scaling * (dropout(x) @ A_c) @ B_c`` on the HIP path.
+
+    ``layout`` selects how A/B are stored (LAYOUT_ROOT: A[in,r], B[r,out]; LAYOUT_PACKAGE:
+    A[r,in], B[out,r]).  Dropout follows nn.Dropout semantics on the branch input only
+    (lora_layers.py:54, lora_layer.py:73).
+    """
+    mask = None
+    if training and dropout_p > 0.0:
+        if dropout_p >= 1.0:
+            mask = torch.zeros_like(x)
+        else:
+            keep = torch.rand(x.shape, device=x.device, dtype=torch.float32) >= dropout_p
+            mask = keep.to(x.dtype) * (1.0 / (1.0 - dropout_p))
+    return _LoRALinearFn.apply(x, weight, bias, A, B, float(scaling), int(layout), mask)

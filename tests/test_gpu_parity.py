@@ -1,0 +1,278 @@
+"""
+GPU parity (run with ``-m gpu`` on an MI355X): the HIP path, called through the C-ABI, against
+  * the golden vectors produced by the reference itself (tests/golden/*.npz),
+  * the numpy oracle (oracle/lora_oracle.py) on seeded inputs,
+  * at BASELINE.json's full size, a plain torch fp32 evaluation of the same expressions on the
+    GPU plus size-independent properties (linearity, bitwise run-to-run determinism).
+
+Tolerances (floating point; stated per check):
+  the kernels contract bf16 operands with fp32 accumulation and round the rank-r intermediate
+  (t, gt) to bf16 once.  Against a model of exactly those roundings
+  (``adapter_delta_bf16_model``) outputs agree to 2e-3 of the tensor's max magnitude; against
+  the fp32 reference to 1e-2 of it (bf16 has 8 mantissa bits: 2^-9 = 2e-3 relative per rounding).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import lora_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from sam3_lora_amd import functional as Fn
+    from sam3_lora_amd import lora_layers as root_api
+    from sam3_lora_amd import lora as pkg_api
+
+DEV = "cuda:0"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def _relmax(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"adapter_{name}.npz"))
+
+
+def test_library_is_the_hip_one():
+    from sam3_lora_amd import _ffi
+    lib = _ffi.load()
+    assert lib.sam3_lora_abi_version() == 1
+    assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_kernels_vs_oracle_and_reference(golden_dir, name, dtype):
+    """lora_fwd_/lora_bwd_ (C-ABI) on the golden inputs: delta, gx_lora, gA, gB."""
+    c = cases.make_case(name)
+    g = _golden(golden_dir, name)
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    lay, s = c["layout"], c["scaling"]
+    x = _t(c["x"], td).reshape(-1, c["x"].shape[-1])
+    gy = _t(c["gy"], td).reshape(-1, c["gy"].shape[-1])
+    A, B = _t(c["A"]), _t(c["B"])
+    M = x.shape[0]
+    # forward on a zero base -> pure delta
+    y = torch.zeros(M, gy.shape[1], device=DEV, dtype=td)
+    tT = Fn.lora_fwd_(x, A, B, y, s, lay, save_t=True)
+    d_model = O.adapter_delta_bf16_model(c["x"], c["A"], c["B"], s, lay).reshape(M, -1)
+    d_ref = O.adapter_delta(c["x"], c["A"], c["B"], s, lay, acc_dtype=np.float64).reshape(M, -1)
+    tol_model = 2e-3 if dtype == "f32" else 6e-3      # bf16 output adds one more 2^-9 rounding
+    assert _relmax(y.float().cpu().numpy(), d_model) < tol_model
+    assert _relmax(y.float().cpu().numpy(), d_ref) < 1e-2
+    # backward, overwrite mode
+    gx = torch.zeros(M, x.shape[1], device=DEV, dtype=td)
+    gA, gB = torch.full_like(A, 7.0), torch.full_like(B, 7.0)
+    Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, s, lay, accumulate=False)
+    gx_r, gA_r, gB_r = O.adapter_backward(c["gy"], c["x"], c["A"], c["B"], s, lay, acc_dtype=np.float64)
+    assert _relmax(gx.float().cpu().numpy(), gx_r.reshape(M, -1)) < 1e-2
+    assert _relmax(gA.cpu().numpy(), gA_r) < 1e-2
+    assert _relmax(gB.cpu().numpy(), gB_r) < 1e-2
+    # golden cross-check: reference's autograd grads of A and B are exactly the adapter grads
+    assert _relmax(gA.cpu().numpy(), g["gA"]) < 1e-2
+    assert _relmax(gB.cpu().numpy(), g["gB"]) < 1e-2
+    # accumulate mode adds on top; recompute-t mode (tT=None) agrees with saved-t mode
+    gA2, gB2 = gA.clone(), gB.clone()
+    Fn.lora_bwd_(gy, x, None, A, B, None, gA2, gB2, s, lay, accumulate=True)
+    assert _relmax(gA2.cpu().numpy(), 2 * gA.cpu().numpy()) < 1e-6
+    assert _relmax(gB2.cpu().numpy(), 2 * gB.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_module_forward_backward_vs_reference_golden(golden_dir, name, dtype):
+    """The drop-in modules (base GEMM on PyTorch-ROCm + HIP adapter) against the reference's outputs."""
+    c = cases.make_case(name)
+    g = _golden(golden_dir, name)
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    fin, fout = c["W"].shape[1], c["W"].shape[0]
+    lin = torch.nn.Linear(fin, fout, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(c["W"]))
+        lin.bias.copy_(torch.from_numpy(c["b"]))
+    if c["layout"] == cases.LAYOUT_ROOT:
+        mod = root_api.LoRALinear(lin, rank=c["rank"], alpha=c["alpha"], dropout=0.0)
+    else:
+        mod = pkg_api.LinearWithLoRA(lin, rank=c["rank"], alpha=c["alpha"], dropout=0.0)
+    with torch.no_grad():
+        mod.lora.lora_A.copy_(torch.from_numpy(c["A"]))
+        mod.lora.lora_B.copy_(torch.from_numpy(c["B"]))
+    mod.to(DEV)
+    if dtype == "bf16":  # frozen base in bf16, fp32 LoRA masters (the MI355X training layout)
+        (mod.original_layer if hasattr(mod, "original_layer") else mod.linear).to(torch.bfloat16)
+    x = _t(c["x"], td).requires_grad_(True)
+    y = mod(x)
+    y.backward(_t(c["gy"], td))
+    tol = 5e-3 if dtype == "f32" else 2e-2
+    assert y.shape == g["y"].shape and y.dtype == td
+    assert _relmax(y.detach().float().cpu().numpy(), g["y"]) < tol
+    assert _relmax(x.grad.float().cpu().numpy(), g["gx"]) < tol
+    assert mod.lora.lora_A.grad.dtype == torch.float32
+    assert _relmax(mod.lora.lora_A.grad.cpu().numpy(), g["gA"]) < 1e-2
+    assert _relmax(mod.lora.lora_B.grad.cpu().numpy(), g["gB"]) < 1e-2
+    base = mod.original_layer if hasattr(mod, "original_layer") else mod.linear
+    assert base.weight.grad is None and base.bias.grad is None
+
+
+@pytest.mark.parametrize("gather", ["0", "1"])
+def test_t3_transpose_read_equals_gather(gather, monkeypatch):
+    """ds_read_b64_tr_b16 operand fetch == explicit 2-byte gathers (bitwise)."""
+    c = cases.make_case("root_ffn_r8")
+    x, gy, A, B = _t(c["x"], torch.bfloat16), _t(c["gy"], torch.bfloat16), _t(c["A"]), _t(c["B"])
+    outs = []
+    for flag in ("0", gather):
+        monkeypatch.setenv("SAM3_LORA_T3_GATHER", flag)
+        gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+        Fn.lora_bwd_(gy, x, None, A, B, None, gA, gB, c["scaling"], c["layout"])
+        outs.append((gA.clone(), gB.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 63, 64, 65, 127, 1000])
+def test_ragged_row_counts(M):
+    rng = np.random.default_rng(M)
+    fin, fout, r = 256, 384, 16
+    x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    gy = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    A = O.bf16_round(rng.uniform(-.25, .25, (fin, r)).astype(np.float32))
+    B = O.bf16_round((rng.standard_normal((r, fout)) * .05).astype(np.float32))
+    base = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    y = _t(base, torch.bfloat16)
+    tT = Fn.lora_fwd_(_t(x, torch.bfloat16), _t(A), _t(B), y, 2.0, 0, save_t=True)
+    want = base + O.adapter_delta_bf16_model(x, A, B, 2.0, 0)
+    assert _relmax(y.float().cpu().numpy(), want) < 6e-3
+    gx = torch.zeros(M, fin, device=DEV, dtype=torch.bfloat16)
+    gA, gB = torch.zeros_like(_t(A)), torch.zeros_like(_t(B))
+    Fn.lora_bwd_(_t(gy, torch.bfloat16), _t(x, torch.bfloat16), tT, _t(A), _t(B), gx, gA, gB, 2.0, 0)
+    gx_r, gA_r, gB_r = O.adapter_backward(gy, x, A, B, 2.0, 0, acc_dtype=np.float64)
+    assert _relmax(gx.float().cpu().numpy(), gx_r) < 1.5e-2
+    assert _relmax(gA.cpu().numpy(), gA_r) < 1.5e-2
+    assert _relmax(gB.cpu().numpy(), gB_r) < 1.5e-2
+
+
+def test_strided_rows_and_untouched_padding():
+    """ld > width: x, y are column slices of wider buffers; bytes outside the slice stay intact."""
+    rng = np.random.default_rng(5)
+    M, fin, fout, r = 70, 128, 256, 8
+    xw = torch.from_numpy(O.bf16_round(rng.standard_normal((M, fin + 64)).astype(np.float32))).to(DEV).bfloat16()
+    yw = torch.from_numpy(O.bf16_round(rng.standard_normal((M, fout + 32)).astype(np.float32))).to(DEV).bfloat16()
+    y0 = yw.clone()
+    A = _t(O.bf16_round(rng.uniform(-.3, .3, (r, fin)).astype(np.float32)))
+    B = _t(O.bf16_round((rng.standard_normal((fout, r)) * .05).astype(np.float32)))
+    xs, ys = xw[:, :fin], yw[:, :fout]
+    Fn.lora_fwd_(xs, A, B, ys, 0.5, 1)
+    want = y0[:, :fout].float().cpu().numpy() + O.adapter_delta_bf16_model(
+        xs.float().cpu().numpy(), A.cpu().numpy(), B.cpu().numpy(), 0.5, 1)
+    assert _relmax(ys.float().cpu().numpy(), want) < 6e-3
+    assert torch.equal(yw[:, fout:], y0[:, fout:])
+
+
+def test_bitwise_determinism_and_full_size_properties():
+    """BASELINE config-2 size (B=8 images -> M=41472 rows, fc1 1024->4736, r=16, bf16)."""
+    torch.manual_seed(0)
+    M, fin, fout, r, s = 41472, 1024, 4736, 16, 2.0
+    x = torch.randn(M, fin, device=DEV).bfloat16()
+    gy = torch.randn(M, fout, device=DEV).bfloat16()
+    A = (torch.rand(fin, r, device=DEV) - .5).bfloat16().float()
+    B = (torch.randn(r, fout, device=DEV) * .05).bfloat16().float()
+    y1 = torch.zeros(M, fout, device=DEV, dtype=torch.bfloat16)
+    tT = Fn.lora_fwd_(x, A, B, y1, s, 0, save_t=True)
+    # torch fp32 evaluation of the same expression with the same intermediate rounding
+    t = (x.float() @ A).bfloat16().float()
+    want = s * (t @ B)
+    err = (y1.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 6e-3, err
+    # linearity in B: delta(2B) == 2*delta(B) bitwise (powers of two commute with rounding)
+    y2 = torch.zeros_like(y1)
+    Fn.lora_fwd_(x, A, 2 * B, y2, s, 0)
+    assert torch.equal(y2.float(), 2 * y1.float())
+    # backward: fixed-order reductions -> bitwise identical across runs
+    res = []
+    for _ in range(2):
+        gx = torch.zeros(M, fin, device=DEV, dtype=torch.bfloat16)
+        gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+        Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, s, 0)
+        res.append((gx, gA, gB))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    gx, gA, gB = res[0]
+    g = s * gy.float()
+    gB_w = t.t() @ g
+    gt = (gy.float() @ B.t()).bfloat16().float()
+    gA_w = x.float().t() @ (s * gt)
+    gx_w = s * (gt @ A.t())
+    assert ((gB - gB_w).abs().max() / gB_w.abs().max()).item() < 5e-3
+    assert ((gA - gA_w).abs().max() / gA_w.abs().max()).item() < 5e-3
+    assert ((gx.float() - gx_w).abs().max() / gx_w.abs().max()).item() < 6e-3
+
+
+def test_dropout_branch_masks_input_and_grad():
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(256, 512)
+    mod = root_api.LoRALinear(lin, rank=16, alpha=32, dropout=0.5).to(DEV)
+    with torch.no_grad():
+        mod.lora.lora_B.normal_(0, 0.05)
+    mod.train()
+    x = torch.randn(64, 256, device=DEV, requires_grad=True)
+    y = mod(x)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    mod.eval()
+    y_eval = mod(x.detach())
+    t = x.detach() @ mod.lora.lora_A
+    want = lin.to(DEV)(x.detach()) + 2.0 * (t @ mod.lora.lora_B)
+    assert ((y_eval - want).abs().max() / want.abs().max()).item() < 5e-3
+
+
+def test_merge_weights_matches_oracle(golden_dir):
+    c = cases.make_case("pkg_1row_r16")
+    g = _golden(golden_dir, "pkg_1row_r16")
+    lin = torch.nn.Linear(c["W"].shape[1], c["W"].shape[0])
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(c["W"]))
+        lin.bias.copy_(torch.from_numpy(c["b"]))
+    mod = pkg_api.LinearWithLoRA(lin, rank=c["rank"], alpha=c["alpha"]).to(DEV)
+    with torch.no_grad():
+        mod.lora.lora_A.copy_(_t(c["A"]))
+        mod.lora.lora_B.copy_(_t(c["B"]))
+    merged = mod.merge_weights()
+    assert isinstance(merged, torch.nn.Linear)
+    np.testing.assert_allclose(merged.weight.detach().cpu().numpy(), g["merged_weight"], atol=2e-6, rtol=0)
+
+
+def test_activation_checkpoint_roundtrip():
+    """The adapter inside torch.utils.checkpoint (the ViT recomputes every block, vitdet.py:837)."""
+    from torch.utils.checkpoint import checkpoint
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(256, 256)
+    mod = root_api.LoRALinear(lin, rank=8, alpha=16).to(DEV)
+    with torch.no_grad():
+        mod.lora.lora_B.normal_(0, 0.05)
+    x = torch.randn(100, 256, device=DEV, requires_grad=True)
+    y = checkpoint(mod, x, use_reentrant=False)
+    y.square().sum().backward()
+    gA1, gx1 = mod.lora.lora_A.grad.clone(), x.grad.clone()
+    mod.zero_grad()
+    x.grad = None
+    mod(x).square().sum().backward()
+    assert torch.equal(gA1, mod.lora.lora_A.grad) and torch.equal(gx1, x.grad)
+
+
+def test_errors_are_loud():
+    x = torch.zeros(4, 12, device=DEV)
+    with pytest.raises(Fn.LoRAKernelError):
+        Fn.lora_fwd_(x, torch.zeros(12, 4, device=DEV), torch.zeros(4, 16, device=DEV),
+                     torch.zeros(4, 16, device=DEV), 1.0, 0)   # in_features not a multiple of 8
+    with pytest.raises(Fn.LoRAKernelError):
+        root_api.LoRALinear(torch.nn.Linear(16, 16))(torch.zeros(2, 16))  # CPU tensor: no fallback
