@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""
+bench.py -- throughput of the LoRA adapter hot path on MI355X, at BASELINE.json's config.
+
+One STEP = one pass of the hot path over one batch of synthetic input, i.e. everything the
+LoRA adapters of the SAM3 ViT trunk do in one training step of `full_lora_config.yaml` at r=16
+(configs[1]: batch 8 @ 1024^2 source -> 1008^2 model input -> 72x72 = 5184 tokens/image,
+M = 41472 rows; 32 blocks x {fc1 1024->4736, fc2 4736->1024} = 64 adapted Linears, bf16):
+
+    forward            64 x sam3_lora_fwd                      (no-grad pass of activation checkpointing)
+    recompute+backward 64 x sam3_lora_fwd (saving t) + 64 x sam3_lora_bwd, block 31 -> 0
+                       (the reference ViT recomputes every block in backward, vitdet.py:837-838)
+    gradient exchange  all-reduce of the flat fp32 A/B-grad buffer (N > 1 only), bucketed on a side stream
+
+The frozen GEMMs / attention / DETR / loss are PyTorch-ROCm plumbing outside this path and are NOT in
+the timed region (and not claimed): `value` is images/s THROUGH THE ADAPTER PATH, the quantity
+the hand-written kernels determine.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed),
+"kernels"/"ops" (every kernel and every C-ABI op at this config), "cpu_baseline" (numpy oracle).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+D_MODEL, D_HID, TOKENS, N_BLOCKS = 1024, 4736, 5184, 32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (weak scaling)")
+    ap.add_argument("--blocks", type=int, default=N_BLOCKS)
+    ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class Workload:
+    """Synthetic, HBM-resident state of the adapter path of one ViT trunk."""
+
+    def __init__(self, dev, batch, rank, blocks, seed):
+        from sam3_lora_amd.ddp import LoRAGradReducer
+        self.dev, self.rank, self.blocks = dev, rank, blocks
+        self.M = batch * TOKENS
+        self.scaling = 2.0  # alpha = 2*rank in every shipped config
+        g = torch.Generator(device=dev).manual_seed(seed)
+        M = self.M
+
+        def act(cols):
+            return torch.randn(M, cols, device=dev, generator=g, dtype=torch.float32).bfloat16()
+
+        # two rotating activation sets so consecutive blocks never reuse the same lines
+        self.x1 = [act(D_MODEL) for _ in range(2)]
+        self.h = [act(D_HID) for _ in range(2)]
+        self.y2 = [act(D_MODEL) for _ in range(2)]
+        self.g2 = [act(D_MODEL) for _ in range(2)]
+        self.gh = [act(D_HID) for _ in range(2)]
+        self.g1 = [act(D_MODEL) for _ in range(2)]
+        P = torch.nn.Parameter
+        self.A1 = [P((torch.rand(D_MODEL, rank, device=dev, generator=g) - .5) * (2 / rank ** .5)) for _ in range(blocks)]
+        self.B1 = [P(torch.randn(rank, D_HID, device=dev, generator=g) * 2e-3) for _ in range(blocks)]
+        self.A2 = [P((torch.rand(D_HID, rank, device=dev, generator=g) - .5) * (2 / rank ** .5)) for _ in range(blocks)]
+        self.B2 = [P(torch.randn(rank, D_MODEL, device=dev, generator=g) * 2e-3) for _ in range(blocks)]
+        params = []
+        for b in range(blocks):
+            params += [self.A1[b], self.B1[b], self.A2[b], self.B2[b]]
+        self.reducer = LoRAGradReducer(params, bucket_bytes=8 << 20)
+        self.params = params
+        self.tT1 = [None] * blocks
+        self.tT2 = [None] * blocks
+
+    def step(self):
+        from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
+        s, L = self.scaling, 0
+        self.reducer.zero_grad()
+        with torch.no_grad():
+            for b in range(self.blocks):                       # forward
+                k = b & 1
+                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L)
+                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L)
+            for b in reversed(range(self.blocks)):             # per-block recompute, then backward
+                k = b & 1
+                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True)
+                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True)
+                lora_bwd_(self.g2[k], self.h[k], t2, self.A2[b], self.B2[b], self.gh[k],
+                          self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True)
+                lora_bwd_(self.gh[k], self.x1[k], t1, self.A1[b], self.B1[b], self.g1[k],
+                          self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True)
+                for p in (self.A1[b], self.B1[b], self.A2[b], self.B2[b]):
+                    self.reducer.notify(p)
+        self.reducer.finish()
+
+
+def time_events(fn, iters, warm=3):
+    """Average per-call GPU time (us) of fn() measured with HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+
+
+def kernel_table(w, iters):
+    """Per-kernel and per-op timings at this config (rank-0 diagnostic + roofline source)."""
+    from sam3_lora_amd import _ffi
+    from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
+    lib = _ffi.load()
+    M, r, s = w.M, w.rank, w.scaling
+    RP = 16 if r <= 16 else 32
+    e = 2
+    x1, h, y2, g2, gh, g1 = w.x1[0], w.h[0], w.y2[0], w.g2[0], w.gh[0], w.g1[0]
+    A1, B1, A2, B2 = w.A1[0], w.B1[0], w.A2[0], w.B2[0]
+    gA1, gB1, gA2, gB2 = (torch.zeros_like(p) for p in (A1, B1, A2, B2))
+    t1 = lora_fwd_(x1, A1, B1, h, s, 0, save_t=True)
+    t2 = lora_fwd_(h, A2, B2, y2, s, 0, save_t=True)
+    fwd1 = lambda: lora_fwd_(x1, A1, B1, h, s, 0)
+    fwd2 = lambda: lora_fwd_(h, A2, B2, y2, s, 0)
+    bwd2 = lambda: lora_bwd_(g2, h, t2, A2, B2, gh, gA2, gB2, s, 0, accumulate=True)
+    bwd1 = lambda: lora_bwd_(gh, x1, t1, A1, B1, g1, gA1, gB1, s, 0, accumulate=True)
+    for f in (fwd1, fwd2, bwd2, bwd1):   # populate workspaces
+        f()
+    rows = []
+
+    def one(name, shape, mask, fn, nbytes):
+        lib.sam3_lora_debug_set_stages(mask)
+        try:
+            avg, med, mn = time_events(fn, iters)
+        finally:
+            lib.sam3_lora_debug_set_stages(_ffi.STAGE_ALL)
+        rows.append(dict(kernel=name, shape=shape, algorithmic_bytes=nbytes, avg_us=round(avg, 2),
+                         median_us=round(med, 2), min_us=round(mn, 2), GBps=round(nbytes / avg / 1e3, 1)))
+
+    D, H = D_MODEL, D_HID
+    # T2: read+write Y[M,N] + read T[M,RP] + W2t[N,RP]
+    one("k_t2", f"M={M},N={H} (fc1 fwd y / fc2 bwd gx)", _ffi.STAGE_T2, fwd1, 2 * e * M * H + e * M * RP + e * H * RP)
+    one("k_t2", f"M={M},N={D} (fc2 fwd y / fc1 bwd gx)", _ffi.STAGE_T2, fwd2, 2 * e * M * D + e * M * RP + e * D * RP)
+    # T1: read X[M,K] + W1[RP,K], write T and TT
+    one("k_t1", f"M={M},K={D} (fc1 fwd t / fc2 bwd gt)", _ffi.STAGE_T1, fwd1, e * M * D + e * RP * D + 2 * e * M * RP)
+    one("k_t1", f"M={M},K={H} (fc2 fwd t / fc1 bwd gt)", _ffi.STAGE_T1, fwd2, e * M * H + e * RP * H + 2 * e * M * RP)
+    # T3: read X[M,N] + TT[RP,M]; partial writes are overhead, not algorithmic
+    one("k_t3", f"M={M},N={H} (fc1 gB / fc2 gA)", _ffi.STAGE_T3_GB, bwd1, e * M * H + e * RP * M)
+    one("k_t3", f"M={M},N={D} (fc1 gA / fc2 gB)", _ffi.STAGE_T3_GA, bwd1, e * M * D + e * RP * M)
+    one("k_reduce", "fc1 (gA,gB)", _ffi.STAGE_REDUCE, bwd1, 2 * 4 * r * (D + H))
+    one("k_pack", "fc1", _ffi.STAGE_PACK, fwd1, (4 + 2) * r * (D + H))
+    ops = []
+
+    def op(name, fn, nbytes):
+        avg, med, mn = time_events(fn, iters)
+        ops.append(dict(op=name, algorithmic_bytes=nbytes, avg_us=round(avg, 2), GBps=round(nbytes / avg / 1e3, 1),
+                        frac_of_peak=round(nbytes / avg / 1e3 / HBM_PEAK_GBPS, 4)))
+
+    # SURVEY section 8(d) per-unit figures (standalone fused adapter)
+    fwd_b = lambda i, o: e * M * (i + 2 * o) + e * r * (i + o)
+    bwd_b = lambda i, o: e * M * (o + i + 2 * i) + 4 * r * (i + o) * 2
+    op("sam3_lora_fwd fc1 (1024->4736)", fwd1, fwd_b(D, H))
+    op("sam3_lora_fwd fc2 (4736->1024)", fwd2, fwd_b(H, D))
+    op("sam3_lora_bwd fc1 (1024->4736)", bwd1, bwd_b(D, H))
+    op("sam3_lora_bwd fc2 (4736->1024)", bwd2, bwd_b(H, D))
+    return rows, ops
+
+
+def cpu_baseline(rank, seconds_budget=25.0):
+    """numpy oracle (kind 'port') on a bounded sample: 1 image through the same 64-Linear
+    fwd + recompute + bwd schedule, fp32 (the reference CLI's dtype)."""
+    import numpy as np
+    from oracle import lora_oracle as O
+    M, r, s = TOKENS, rank, 2.0
+    rng = np.random.default_rng(0)
+    x1 = rng.standard_normal((M, D_MODEL), dtype=np.float32)
+    h = rng.standard_normal((M, D_HID), dtype=np.float32)
+    y2 = rng.standard_normal((M, D_MODEL), dtype=np.float32)
+    g2 = rng.standard_normal((M, D_MODEL), dtype=np.float32)
+    gh = rng.standard_normal((M, D_HID), dtype=np.float32)
+    g1 = rng.standard_normal((M, D_MODEL), dtype=np.float32)
+    A1 = rng.uniform(-.25, .25, (D_MODEL, r)).astype(np.float32)
+    B1 = (rng.standard_normal((r, D_HID)) * 2e-3).astype(np.float32)
+    A2 = rng.uniform(-.25, .25, (D_HID, r)).astype(np.float32)
+    B2 = (rng.standard_normal((r, D_MODEL)) * 2e-3).astype(np.float32)
+
+    def block():
+        nonlocal h, y2, gh, g1
+        for _ in range(2):  # forward + recompute
+            h += O.adapter_delta(x1, A1, B1, s, 0)
+            y2 += O.adapter_delta(h, A2, B2, s, 0)
+        gx, gA, gB = O.adapter_backward(g2, h, A2, B2, s, 0)
+        gh += gx
+        gx, gA, gB = O.adapter_backward(gh, x1, A1, B1, s, 0)
+        g1 += gx
+
+    block()  # warm
+    t0 = time.perf_counter()
+    n = 0
+    while n < N_BLOCKS and time.perf_counter() - t0 < seconds_budget:
+        block()
+        n += 1
+    dt = time.perf_counter() - t0
+    per_img_s = dt / n * N_BLOCKS
+    try:
+        import threadpoolctl
+        threads = max((p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()), default=os.cpu_count())
+    except Exception:
+        threads = os.cpu_count()
+    return dict(value=round(1.0 / per_img_s, 4), unit="images/s", cores=int(threads), kind="port",
+                sample=f"numpy fp32 oracle, 1 image (M={M}), {n}/{N_BLOCKS} ViT blocks timed "
+                       f"(fc1+fc2 adapter fwd, recompute fwd, bwd), extrapolated to 32 blocks; {dt:.1f}s of CPU work")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs an AMD GPU (the LoRA path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        w.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    finite = all(torch.isfinite(p.grad).all().item() for p in w.params[:8]) and torch.isfinite(w.h[0].float()).all().item()
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "training images/sec at 1024^2 (adapter path: 64 LoRA'd ViT-MLP Linears fwd + recompute + bwd), SAM3-base r=%d" % args.rank,
+            "value": round(world * args.batch / (dt / args.steps), 2),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "full_lora_config.yaml @ r=%d alpha=%d (configs[1]): batch %d/GPU @ 1024^2 -> 1008^2 "
+                                   "(M=%d rows), %d ViT blocks x {fc1 1024->4736, fc2 4736->1024}, bf16 activations, "
+                                   "fp32 A/B + fp32 grad accumulation; frozen GEMMs/attention/DETR/loss excluded"
+                                   % (args.rank, 2 * args.rank, args.batch, w.M, args.blocks),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "grad_allreduce_bytes": w.reducer.nbytes, "finite": bool(finite)},
+        }
+    if rank == 0 and not args.no_roofline:
+        rows, ops = kernel_table(w, args.kernel_iters)
+        dom = max(rows[:6], key=lambda r_: r_["avg_us"] * {"k_t2": 3, "k_t1": 3, "k_t3": 1}[r_["kernel"]])
+        out["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} [{dom['shape']}]",
+                           "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(dom["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_us": dom["avg_us"]}
+        out["kernels"] = rows
+        out["ops"] = ops
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.rank)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,21 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
                     int in_features, int out_features, int rank, int layout, float scaling,
                     void* stream);
 
+/*
+ * Profiling aid, not part of the training path: restrict which internal stages the NEXT calls of
+ * sam3_lora_fwd / sam3_lora_bwd launch (process-wide; returns the previous mask; default all).
+ * bench.py uses it to time one kernel at a time with HIP events on the caller's stream.  With a
+ * partial mask the outputs of the call are meaningless.
+ */
+#define SAM3_LORA_STAGE_PACK 1u     /* k_pack   : fp32 A/B -> bf16 operand images              */
+#define SAM3_LORA_STAGE_T1 2u       /* k_t1     : t = x.A_c (fwd) / gt = gy.B_c^T (bwd)         */
+#define SAM3_LORA_STAGE_T2 4u       /* k_t2     : y += s.t.B_c (fwd) / gx += s.gt.A_c^T (bwd)   */
+#define SAM3_LORA_STAGE_T3_GB 8u    /* k_t3     : gB partials = t^T.gy                          */
+#define SAM3_LORA_STAGE_T3_GA 16u   /* k_t3     : gA partials = gt^T.x                          */
+#define SAM3_LORA_STAGE_REDUCE 32u  /* k_reduce : fixed-order sum of the partials into gA/gB    */
+#define SAM3_LORA_STAGE_ALL 0xffffffffu
+unsigned sam3_lora_debug_set_stages(unsigned mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,8 +23,9 @@ ABI_VERSION = 1
 EXPORTS = (
     "sam3_lora_abi_version", "sam3_lora_last_error", "sam3_lora_saved_t_bytes",
     "sam3_lora_fwd_workspace_bytes", "sam3_lora_bwd_workspace_bytes",
-    "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge",
+    "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages",
 )
+STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
 _lib = None
 _lock = threading.Lock()
@@ -61,6 +62,8 @@ def _declare(lib):
         c_float, c_uint64, c_uint64, c_int, c_int,             # drop_p, seed, offset, dtype, accumulate
         c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
     ]
+    lib.sam3_lora_debug_set_stages.restype = ctypes.c_uint
+    lib.sam3_lora_debug_set_stages.argtypes = [ctypes.c_uint]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]

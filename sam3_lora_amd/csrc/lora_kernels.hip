@@ -446,6 +446,10 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// profiling aid (sam3_lora_debug_set_stages): which stages fwd/bwd launch.  Default: all.
+unsigned g_stages = 0xffffffffu;
+inline bool stage_on(unsigned bit) { return (g_stages & bit) != 0; }
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -613,6 +617,12 @@ extern "C" {
 
 int sam3_lora_abi_version(void) { return SAM3_LORA_ABI_VERSION; }
 
+unsigned sam3_lora_debug_set_stages(unsigned mask) {
+    const unsigned old = g_stages;
+    g_stages = mask;
+    return old;
+}
+
 const char* sam3_lora_last_error(void) { return g_err; }
 
 size_t sam3_lora_saved_t_bytes(int64_t M, int rank) {
@@ -661,13 +671,13 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
     // W1[RP][in] = A_c^T ; W2t[out][RP] = B_c^T
     PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si};
     PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr};
-    launch_pack(ja, jb, st);
+    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(ja, jb, st);
     if (dtype == SAM3_LORA_BF16) {
-        launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
-        launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
     } else {
-        launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
-        launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
     }
     return launch_ok("sam3_lora_fwd");
 }
@@ -709,7 +719,7 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     // W1b[RP][out] = B_c ; W2tb[in][RP] = A_c
     PackJob jb{(const float*)B, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so};
     PackJob ja{(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr};
-    launch_pack(jb, ja, st);
+    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(jb, ja, st);
     const bool bf = dtype == SAM3_LORA_BF16;
     if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
         PackJob j1{(const float*)A, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si};
@@ -720,18 +730,20 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
         else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st);
         TT = TTs;
     }
+    const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
+    const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
     if (bf) {
-        launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
-        if (gB_accum) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);   // gB = t^T . gy
-        if (gA_accum) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);     // gA^T = gt^T . x
-        if (gx_inout) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
+        if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
+        if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);   // gB = t^T . gy
+        if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);     // gA^T = gt^T . x
+        if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
     } else {
-        launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);
-        if (gB_accum) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);
-        if (gA_accum) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);
-        if (gx_inout) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
+        if (s1) launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);
+        if (gB_accum && s3b) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);
+        if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);
+        if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
     }
-    if (gA_accum || gB_accum) {
+    if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
         // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
         ReduceJob rb{PB, gB_accum, w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
         ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};

@@ -1,0 +1,157 @@
+"""
+Data-parallel reduction of the LoRA gradients -- the only cross-GPU exchange of the path.
+
+The reference's DDP variant wraps the whole model in ``torch.nn.parallel.DistributedDataParallel``
+(sam3_lora/train/native_trainer.py:319-340) and lets it bucket every ``requires_grad`` gradient,
+which for a LoRA run is just A and B (23.6 MB fp32 at r=16).  Here the exchange is
+explicit and sized for xGMI (point-to-point links, ring collectives are per-link bound, so few
+large messages beat many small ones):
+
+  * all A/B gradients live in ONE flat fp32 buffer; every ``param.grad`` is a view into it, so the
+    HIP backward accumulates straight into the buffer and no gather/scatter copy ever runs;
+  * the buffer is cut into a few contiguous buckets in reverse registration order (gradients
+    complete from the last ViT block to the first); when the last gradient of a bucket has been
+    accumulated, that bucket is all-reduced (SUM) on a side HIP stream while backward continues;
+  * ``finish()`` makes the compute stream wait for the side stream and scales by 1/world_size
+    (mean, as DDP does).  Parameters that never receive a gradient in a step (the reference's
+    ``find_unused_parameters`` case) are reduced as zeros, never skipped.
+
+Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU (tests).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class LoRAGradReducer:
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
+                 bucket_bytes: int = 16 << 20, average: bool = True, overlap: bool = True):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("LoRAGradReducer: no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev for p in self.params):
+            raise ValueError("LoRAGradReducer: parameters must share a device")
+        self.device = dev
+        self.group = process_group
+        self.average = average
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap and dev.type == "cuda"
+        # flat buffer, 64-element aligned slots, params in registration order
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._offs = offs
+        for p, o in zip(self.params, offs):
+            if p.dtype != torch.float32:
+                raise ValueError("LoRAGradReducer: LoRA master parameters must be float32")
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        # buckets: contiguous ranges of the flat buffer, built from the END (last params finish first)
+        self.buckets = []          # (start, end, first_param_idx, last_param_idx)
+        per = max(1, bucket_bytes // 4)
+        hi = len(self.params)
+        while hi > 0:
+            lo = hi - 1
+            end = offs[hi - 1] + (self.params[hi - 1].numel() + 63) // 64 * 64
+            while lo > 0 and end - offs[lo - 1] <= per:
+                lo -= 1
+            self.buckets.append((offs[lo], end, lo, hi))
+            hi = lo
+        self._bucket_of = {}
+        for b, (_, _, lo, hi_) in enumerate(self.buckets):
+            for i in range(lo, hi_):
+                self._bucket_of[i] = b
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._armed = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    # ------------------------------------------------------------------ step protocol ----
+    def zero_grad(self):
+        """Zero the flat buffer (keeps every ``param.grad`` a view of it) and arm the hooks."""
+        self.flat.zero_()
+        for p, o in zip(self.params, self._offs):
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self.arm()
+
+    def arm(self):
+        """Call before the backward of the LAST micro-batch (no_sync semantics for earlier ones)."""
+        for b, (_, _, lo, hi) in enumerate(self.buckets):
+            self._pending[b] = hi - lo
+            self._launched[b] = False
+        self._works = []
+        self._armed = True
+
+    def notify(self, param: torch.nn.Parameter):
+        """Manual form of the autograd hook, for callers that accumulate into ``param.grad`` through
+        the C-ABI directly (bench.py): declares this parameter's gradient final for the step."""
+        if not hasattr(self, "_index"):
+            self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._make_hook(self._index[id(param)])(param)
+
+    def _make_hook(self, idx: int):
+        def hook(param):
+            if not self._armed:
+                return
+            o = self._offs[idx]
+            if param.grad is not None and param.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                # someone replaced .grad (e.g. zero_grad(set_to_none=True)): fold it back into the buffer
+                self.flat[o:o + param.numel()].view_as(param).add_(param.grad)
+                param.grad = self.flat[o:o + param.numel()].view_as(param)
+            b = self._bucket_of[idx]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: int):
+        if self._launched[b] or self.world_size == 1:
+            self._launched[b] = True
+            return
+        self._launched[b] = True
+        s, e, _, _ = self.buckets[b]
+        chunk = self.flat[s:e]
+        if self.overlap:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """After backward: reduce whatever has not been launched (unused params), wait, average."""
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        if self.overlap:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        if self.average and self.world_size > 1:
+            self.flat.mul_(1.0 / self.world_size)
+        self._works = []
+        self._armed = False
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+
+def allreduce_scalar_sum(value: torch.Tensor, process_group=None) -> torch.Tensor:
+    """``num_boxes`` style scalar exchange (sam3/train/loss/sam3_loss.py:74-76)."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(value, op=dist.ReduceOp.SUM, group=process_group)
+    return value
