@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 (ROCm 7.2, rocpd sqlite output) results into small text summaries that can
+be committed under profiles/.
+
+    python tools/rocpd_summary.py stats  <bench_results.db>  > profiles/rNN_kernel_stats.txt
+    python tools/rocpd_summary.py pmc    <bench_results.db>  > profiles/rNN_pmc_<counter>.txt
+
+`stats`: per kernel (== rocprofv3 --stats 'top_kernels') and per (kernel, grid) shape.
+`pmc`  : per (kernel, grid, counter): number of dispatches, mean/min/max counter value.
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str, n: int = 70) -> str:
+    name = re.sub(r"^void\s+", "", name)
+    name = name.split("(")[0]
+    name = name.replace("unsigned short", "bf16").replace("long long", "i64")
+    return name if len(name) <= n else name[: n - 3] + "..."
+
+
+def stats(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, grid_x, grid_y, workgroup_x, duration, vgpr_count, lds_size from kernels").fetchall()
+    tot = sum(r[4] for r in rows)
+    by_k, by_s = {}, {}
+    for name, gx, gy, wx, dur, vg, lds in rows:
+        k = short(name)
+        by_k.setdefault(k, []).append(dur)
+        by_s.setdefault((k, gx // max(wx, 1), gy, vg, lds), []).append(dur)
+    print("# rocprofv3 --kernel-trace --stats (rocpd) -- durations in microseconds")
+    print(f"# total kernel time {tot / 1e3:.1f} us over {len(rows)} dispatches\n")
+    print(f"{'kernel':72s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    for k, d in sorted(by_k.items(), key=lambda kv: -sum(kv[1]))[:25]:
+        print(f"{k:72s} {len(d):6d} {sum(d) / 1e3:12.1f} {sum(d) / len(d) / 1e3:10.2f} {min(d) / 1e3:10.2f} {max(d) / 1e3:10.2f} {100 * sum(d) / tot:6.2f}")
+    print("\n# per (kernel, workgroups_x, grid_y) shape")
+    print(f"{'kernel':60s} {'wg_x':>6s} {'grid_y':>6s} {'vgpr':>5s} {'lds':>6s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
+    for (k, gx, gy, vg, lds), d in sorted(by_s.items(), key=lambda kv: -sum(kv[1]))[:40]:
+        if not k.startswith("k_"):
+            continue
+        print(f"{k:60s} {gx:6d} {gy:6d} {vg:5d} {lds:6d} {len(d):6d} {sum(d) / len(d) / 1e3:10.2f} {min(d) / 1e3:10.2f} {max(d) / 1e3:10.2f}")
+
+
+def pmc(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, grid_size_x, grid_size_y, workgroup_size_x, counter_name, value "
+                       "from counters_collection").fetchall()
+    agg = {}
+    for name, gx, gy, wx, cn, v in rows:
+        k = short(name)
+        if not k.startswith("k_"):
+            continue
+        agg.setdefault((k, gx // max(wx, 1), gy, cn), []).append(v)
+    print("# rocprofv3 --pmc (rocpd) -- per (kernel, workgroups_x, grid_y, counter); values as reported")
+    print("# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x")
+    print("# (MI355X_MICROARCH.md, HBM section) -- bench.py doubles it before comparing with byte counts.\n")
+    print(f"{'kernel':60s} {'wg_x':>6s} {'grid_y':>6s} {'counter':>14s} {'n':>5s} {'mean':>14s} {'min':>14s} {'max':>14s}")
+    for (k, gx, gy, cn), v in sorted(agg.items()):
+        print(f"{k:60s} {gx:6d} {gy:6d} {cn:>14s} {len(v):5d} {sum(v) / len(v):14.1f} {min(v):14.1f} {max(v):14.1f}")
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
