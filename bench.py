@@ -105,18 +105,39 @@ class Workload:
         self.reducer.finish()
 
 
-def time_events(fn, iters, warm=3):
-    """Average per-call GPU time (us) of fn() measured with HIP events on the current stream."""
+def time_events(fn, iters, warm=3, reps=5):
+    """Average GPU time (us) of one fn() call: HIP events on the current stream bracket a batch of
+    `iters` back-to-back calls (the queue stays full, so host launch latency is not in the number);
+    repeated `reps` times -> (mean, median, min) of the per-call averages."""
     for _ in range(warm):
         fn()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in evs:
+    per = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(iters):
+            fn()
         b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-    return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+        b.synchronize()
+        per.append(a.elapsed_time(b) * 1e3 / iters)
+    per.sort()
+    return sum(per) / len(per), per[len(per) // 2], per[0]
+
+
+def committed_traffic(kernel, wg_x):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*traffic.json,
+    produced by tools/rocpd_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs
+    of this bench; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            for row in json.load(open(path)):
+                if row["kernel"].startswith(kernel) and row["wg_x"] == wg_x:
+                    best = dict(row, source=os.path.relpath(path, ROOT))
+        except Exception:
+            pass
+    return best
 
 
 def kernel_table(w, iters):
@@ -278,9 +299,11 @@ def main():
     if rank == 0 and not args.no_roofline:
         rows, ops = kernel_table(w, args.kernel_iters)
         dom = max(rows[:6], key=lambda r_: r_["avg_us"] * {"k_t2": 3, "k_t1": 3, "k_t3": 1}[r_["kernel"]])
+        tr = committed_traffic(dom["kernel"], (D_HID + 127) // 128 if "N=%d" % D_HID in dom["shape"] else -1)
         out["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} [{dom['shape']}]",
                            "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(dom["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                           "frac": round(dom["GBps"] / HBM_PEAK_GBPS, 4),
+                           "traffic": tr["hbm_bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_us": dom["avg_us"]}
         out["kernels"] = rows
         out["ops"] = ops

@@ -61,6 +61,54 @@ def bf16_round(a: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# dropout keep-mask of the HIP kernels (integer arithmetic -> bit-exact target).
+# The reference uses torch's nn.Dropout stream (lora_layers.py:42,54), which cannot be matched
+# across devices; the kernels therefore define their own counter-based stream and
+# THIS function is its specification.  What is pinned to the reference is the SEMANTICS
+# (mask applied to x before A only, kept values scaled by 1/(1-p), gradient masked the same way):
+# see adapter_delta/adapter_backward with drop_scale_mask and tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------------------
+def _fmix32(h: np.ndarray) -> np.ndarray:
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    h = (h.astype(np.uint64) * np.uint64(0x85EBCA6B)).astype(np.uint32)
+    h ^= h >> np.uint32(13)
+    h = (h.astype(np.uint64) * np.uint64(0xC2B2AE35)).astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def dropout_threshold(p: float) -> int:
+    """thr = round-half-even(p * 65536) clamped to [1, 65536]; an element is kept iff u16 >= thr."""
+    return int(min(max(int(np.rint(np.float32(p) * np.float32(65536.0))), 1), 65536))
+
+
+def dropout_keep(M: int, width: int, p: float, seed: int, offset: int = 0) -> np.ndarray:
+    """bool[M, width]: keep mask of element e = row*width + col.
+
+    counter c = e >> 1 (two 16-bit draws per 32-bit hash);  h = fmix32(lo32(c) ^ k0 ^ hi32(c)*0x85EBCA6B)
+    with k0 = lo32(seed ^ seed>>32) ^ lo32(offset)*0x9E3779B9 ^ hi32(offset); even e takes the low
+    half of h, odd e the high half.
+    """
+    seed, offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1)
+    k0 = ((seed ^ (seed >> 32)) & 0xFFFFFFFF) ^ (((offset & 0xFFFFFFFF) * 0x9E3779B9) & 0xFFFFFFFF) ^ (offset >> 32)
+    e = np.arange(M * width, dtype=np.uint64)
+    c = e >> np.uint64(1)
+    lo = (c & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = ((c >> np.uint64(32)).astype(np.uint64) * np.uint64(0x85EBCA6B)).astype(np.uint32)
+    h = _fmix32(lo ^ np.uint32(k0) ^ hi)
+    u16 = np.where((e & np.uint64(1)) == 0, h & np.uint32(0xFFFF), h >> np.uint32(16))
+    return (u16 >= np.uint32(dropout_threshold(p))).reshape(M, width)
+
+
+def dropout_scale_mask(M: int, width: int, p: float, seed: int, offset: int = 0) -> np.ndarray:
+    """The multiplier nn.Dropout(p) applies in training: 0 or 1/(1-p) (0 everywhere for p == 1)."""
+    keep = dropout_keep(M, width, p, seed, offset)
+    inv = np.float32(1.0 / (1.0 - p)) if p < 1.0 else np.float32(0.0)
+    return keep.astype(np.float32) * inv
+
+
+# --------------------------------------------------------------------------------------
 # canonical views: every formula below works on A_c[in, r], B_c[r, out]
 # --------------------------------------------------------------------------------------
 def _canon(A: np.ndarray, B: np.ndarray, layout: int) -> Tuple[np.ndarray, np.ndarray]:

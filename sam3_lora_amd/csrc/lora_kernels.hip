@@ -54,6 +54,43 @@ __device__ __forceinline__ uint4 load8(const float* p) {
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 
 // ------------------------------------------------------------------------------------------
+// dropout on the branch input x (nn.Dropout semantics, lora_layers.py:54): counter-based, so the
+// forward, the checkpoint recompute and the three backward consumers regenerate the same mask.
+//   element e = row*width + col ; 4 x murmur3-fmix32 per aligned group of 8 elements, 16 bits each;
+//   keep  <=>  u16 >= thr  (thr = round(p * 65536)).  Restated in oracle/lora_oracle.py:dropout_keep.
+// ------------------------------------------------------------------------------------------
+struct DropKey {
+    unsigned k0;   // seed/offset mix
+    unsigned thr;  // 0 => dropout off
+    int width;     // logical row width of x (in_features)
+};
+
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+// keep-bits (bit j <=> element e8 + j is kept) of the aligned 8-element group starting at e8
+__device__ __forceinline__ unsigned keep8(unsigned long long e8, const DropKey& dk) {
+    const unsigned long long c0 = e8 >> 1;
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long c = c0 + j;
+        const unsigned h = fmix32((unsigned)c ^ dk.k0 ^ ((unsigned)(c >> 32) * 0x85ebca6bu));
+        bits |= ((h & 0xffffu) >= dk.thr ? 1u : 0u) << (2 * j);
+        bits |= ((h >> 16) >= dk.thr ? 1u : 0u) << (2 * j + 1);
+    }
+    return bits;
+}
+
+__device__ __forceinline__ uint4 drop8(uint4 v, unsigned long long e8, const DropKey& dk) {
+    const unsigned b = keep8(e8, dk);
+    auto m = [&](int j) { return ((b >> (2 * j)) & 1u ? 0xffffu : 0u) | ((b >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u); };
+    return make_uint4(v.x & m(0), v.y & m(1), v.z & m(2), v.w & m(3));
+}
+
+// ------------------------------------------------------------------------------------------
 // pack: fp32 LoRA master weights (either reference layout) -> bf16 operand images, zero padded
 //   dst[i][j] (row-major I x J) = (i < Iv && j < Jv) ? src[i*si + j*sj] : 0
 // ------------------------------------------------------------------------------------------
@@ -82,7 +119,8 @@ __global__ __launch_bounds__(256) void k_pack(PackJob j0, PackJob j1) {
 template <typename XT, int RT>
 __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ W1, bf16_t* __restrict__ T,
-                                            bf16_t* __restrict__ TT, long long M, long long Mp, int K) {
+                                            bf16_t* __restrict__ TT, long long M, long long Mp, int K,
+                                            DropKey dk) {
     constexpr int RP = RT * 16, BM = 64, BK = 128, CPR = BK / 8;
     __shared__ uint4 xs[2][BM * CPR];
     __shared__ uint4 ws[2][RP * CPR];
@@ -99,6 +137,7 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
         for (int i = 0; i < 4; ++i) {
             const long long m = m0 + lrow + 16 * i;
             xr[i] = (m < M && k < K) ? load8(X + m * ldx + k) : zero4();
+            if (dk.thr) xr[i] = drop8(xr[i], (unsigned long long)m * dk.width + k, dk);
         }
 #pragma unroll
         for (int j = 0; j < RT; ++j) {
@@ -163,6 +202,14 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
 //   one wave = 128 output columns (W2 fragments live in registers) x a strided set of 16-row
 //   tiles; no workgroup barrier anywhere -- each wave streams on its own.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mask8(f32x4& a, f32x4& b, unsigned keep) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!((keep >> j) & 1u)) a[j] = 0.f;
+        if (!((keep >> (4 + j)) & 1u)) b[j] = 0.f;
+    }
+}
+
 template <typename YT>
 struct YTile;  // 16 rows x 128 cols, lane L owns rows p*4 + (L>>4), cols (L&15)*8 .. +8
 
@@ -178,13 +225,15 @@ struct YTile<bf16_t> {
         }
     }
     __device__ __forceinline__ void add_store(bf16_t* Y, long long ldy, long long m0, int col, int lane,
-                                              long long M, int N, const float* slab, int ldw, float scale) {
+                                              long long M, int N, const float* slab, int ldw, float scale,
+                                              const DropKey& dk) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
             const long long m = m0 + rl;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
+            f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
+            f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
+            if (dk.thr) mask8(a, b, keep8((unsigned long long)m * dk.width + col, dk));
             uint4 o;
             o.x = pack2(bf_lo(v[p].x) + scale * a[0], bf_hi(v[p].x) + scale * a[1]);
             o.y = pack2(bf_lo(v[p].y) + scale * a[2], bf_hi(v[p].y) + scale * a[3]);
@@ -209,13 +258,15 @@ struct YTile<float> {
         }
     }
     __device__ __forceinline__ void add_store(float* Y, long long ldy, long long m0, int col, int lane,
-                                              long long M, int N, const float* slab, int ldw, float scale) {
+                                              long long M, int N, const float* slab, int ldw, float scale,
+                                              const DropKey& dk) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
             const long long m = m0 + rl;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
+            f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
+            f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
+            if (dk.thr) mask8(a, b, keep8((unsigned long long)m * dk.width + col, dk));
             if (m < M && col < N) {
                 *reinterpret_cast<f32x4*>(Y + m * ldy + col) = v[p][0] + scale * a;
                 *reinterpret_cast<f32x4*>(Y + m * ldy + col + 4) = v[p][1] + scale * b;
@@ -227,7 +278,7 @@ struct YTile<float> {
 template <typename YT, int RT>
 __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
-                                            int tiles_per_wg) {
+                                            int tiles_per_wg, DropKey dk) {
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
     __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,7 +330,7 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        cur.add_store(Y, ldy, m0, col, lane, M, N, slab, LDW, scale);
+        cur.add_store(Y, ldy, m0, col, lane, M, N, slab, LDW, scale, dk);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -296,7 +347,7 @@ __device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) &
 template <typename XT, int RT, bool GATHER>
 __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TT, float* __restrict__ Gpart,
-                                            long long M, long long Mp, int N, int rows_per_wg) {
+                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk) {
     constexpr int RP = RT * 16, BR = 64, CW = 256, CPR = CW / 8;
     __shared__ uint4 xs[2][BR * CPR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -314,6 +365,7 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
         for (int i = 0; i < 8; ++i) {
             const long long m = r_begin + (long long)s * BR + lrow + 8 * i;
             xr[i] = (m < M && col < N) ? load8(X + m * ldx + col) : zero4();
+            if (dk.thr) xr[i] = drop8(xr[i], (unsigned long long)m * dk.width + col, dk);
         }
     };
     auto sstore = [&](int buf) {
@@ -411,17 +463,36 @@ struct ReduceJob {
     long long sr, sn;
 };
 
+// block = 64 consecutive (r, n) elements; wave w sums partials w, w+4, w+8, ... (independent loads in
+// flight), then the four wave sums are combined in the fixed order 0,1,2,3 -> bit-reproducible.
 __global__ __launch_bounds__(256) void k_reduce(ReduceJob j0, ReduceJob j1, float scale, int accumulate) {
     const ReduceJob jb = blockIdx.y == 0 ? j0 : j1;
-    if (jb.dst == nullptr) return;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)jb.rank * jb.N) return;
-    const int r = (int)(idx / jb.N), n = (int)(idx % jb.N);
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + lane;
+    const bool ok = jb.dst != nullptr && idx < (long long)jb.rank * jb.N;
+    int r = 0, n = 0;
     float s = 0.f;
-    for (int rs = 0; rs < jb.NR; ++rs) s += jb.part[((long long)rs * jb.RP + r) * jb.N + n];
-    s *= scale;
-    float* d = jb.dst + r * jb.sr + n * jb.sn;
-    *d = accumulate ? (*d + s) : s;
+    if (ok) {
+        r = (int)(idx / jb.N);
+        n = (int)(idx % jb.N);
+        const long long stride = (long long)jb.RP * jb.N;
+        const float* p = jb.part + (long long)r * jb.N + n;
+        int rs = wave;
+        for (; rs + 12 < jb.NR; rs += 16) {
+            const float a0 = p[rs * stride], a1 = p[(rs + 4) * stride], a2 = p[(rs + 8) * stride],
+                        a3 = p[(rs + 12) * stride];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; rs < jb.NR; rs += 4) s += p[rs * stride];
+    }
+    sm[wave][lane] = s;
+    __syncthreads();
+    if (ok && wave == 0) {
+        const float tot = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+        float* d = jb.dst + r * jb.sr + n * jb.sn;
+        *d = accumulate ? (*d + scale * tot) : scale * tot;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -504,6 +575,21 @@ int launch_ok(const char* what) {
     return 0;
 }
 
+// dropout request -> kernel key (thr == 0 means off) and the 1/(1-p) factor folded into the fp32 scales
+DropKey make_dropkey(float p, uint64_t seed, uint64_t offset, int width, float* inv_keep) {
+    DropKey dk{0u, 0u, width};
+    *inv_keep = 1.f;
+    if (p > 0.f) {
+        long thr = lrintf(p * 65536.f);
+        if (thr < 1) thr = 1;
+        if (thr > 65536) thr = 65536;
+        dk.thr = (unsigned)thr;
+        dk.k0 = (unsigned)(seed ^ (seed >> 32)) ^ ((unsigned)offset * 0x9e3779b9u) ^ (unsigned)(offset >> 32);
+        *inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    }
+    return dk;
+}
+
 bool env_flag(const char* name) {
     const char* v = getenv(name);
     return v && v[0] && v[0] != '0';
@@ -532,17 +618,17 @@ void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
 
 template <typename XT>
 void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t* TT, long long M, long long Mp, int K,
-               int RT, hipStream_t st) {
+               int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)(Mp / 64));
     if (RT == 1)
-        hipLaunchKernelGGL((k_t1<XT, 1>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K);
+        hipLaunchKernelGGL((k_t1<XT, 1>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
     else
-        hipLaunchKernelGGL((k_t1<XT, 2>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K);
+        hipLaunchKernelGGL((k_t1<XT, 2>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
 }
 
 template <typename YT>
 void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT,
-               hipStream_t st) {
+               hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
     long long want = (3072 + nchunks - 1) / nchunks;  // ~3k workgroups of 4 waves
@@ -551,18 +637,18 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     tiles_per_wg = round_up(tiles_per_wg, 4);
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
     if (RT == 1)
-        hipLaunchKernelGGL((k_t2<YT, 1>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg);
+        hipLaunchKernelGGL((k_t2<YT, 1>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk);
     else
-        hipLaunchKernelGGL((k_t2<YT, 2>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg);
+        hipLaunchKernelGGL((k_t2<YT, 2>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk);
 }
 
 template <typename XT>
 void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N,
-               const T3Plan& p, int RT, hipStream_t st) {
+               const T3Plan& p, int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
     const bool gather = env_flag("SAM3_LORA_T3_GATHER");
 #define T3_LAUNCH(RTV, GV) \
-    hipLaunchKernelGGL((k_t3<XT, RTV, GV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg)
+    hipLaunchKernelGGL((k_t3<XT, RTV, GV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk)
     if (RT == 1) {
         if (gather) T3_LAUNCH(1, true); else T3_LAUNCH(1, false);
     } else {
@@ -644,14 +730,14 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
                   int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
                   float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
                   void* stream) {
-    (void)seed; (void)offset;
+    if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if ((rc = check_act(y_inout, ldy, out_features, dtype, "y_inout"))) return rc;
     if (!A || !B) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
-    if (drop_p != 0.f) return fail(SAM3_LORA_ENOTSUP, "in-kernel dropout (drop_p=%g) is not implemented in this build", drop_p);
+    float inv_keep; const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
     const FwdWs w = fwd_ws(M, in_features, out_features, rank);
     if (!workspace || workspace_bytes < w.total)
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
@@ -673,11 +759,11 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
     PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr};
     if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(ja, jb, st);
     if (dtype == SAM3_LORA_BF16) {
-        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
-        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
+        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st);
     } else {
-        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st);
-        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
+        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st);
     }
     return launch_ok("sam3_lora_fwd");
 }
@@ -686,7 +772,7 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
                   float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
                   int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
                   uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    (void)seed; (void)offset;
+    if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
@@ -694,7 +780,7 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
     if (!A || !B) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
-    if (drop_p != 0.f) return fail(SAM3_LORA_ENOTSUP, "in-kernel dropout (drop_p=%g) is not implemented in this build", drop_p);
+    float inv_keep; const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
     if (tT_saved && ((uintptr_t)tT_saved & 15)) return fail(SAM3_LORA_EINVAL, "tT_saved must be 16-byte aligned");
     const BwdWs w = bwd_ws(M, in_features, out_features, rank);
     if (!workspace || workspace_bytes < w.total)
@@ -726,8 +812,8 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
         PackJob j2{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
         launch_pack(j1, j2, st);
         bf16_t* TTs = (bf16_t*)(ws + w.tt);
-        if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st);
-        else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st);
+        if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk);
+        else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk);
         TT = TTs;
     }
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
@@ -735,21 +821,21 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     if (bf) {
         if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
         if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);   // gB = t^T . gy
-        if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);     // gA^T = gt^T . x
-        if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
+        if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st, dk);     // gA^T = gt^T . x
+        if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
     } else {
         if (s1) launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);
         if (gB_accum && s3b) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);
-        if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st);
-        if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
+        if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st, dk);
+        if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
     }
     if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
         // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
         ReduceJob rb{PB, gB_accum, w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
         ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
-        dim3 grid((unsigned)(((nb > na ? nb : na) + 255) / 256), 2);
-        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling, accumulate);
+        dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);
+        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling * inv_keep, accumulate);
     }
     return launch_ok("sam3_lora_bwd");
 }

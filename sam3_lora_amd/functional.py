@@ -151,7 +151,7 @@ class _LoRALinearFn(torch.autograd.Function):
     """Frozen linear + LoRA branch as one autograd node (saved tensors: x, t^T -- never y or delta)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_mask):
+    def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_p, seed):
         _require_cuda(x, weight, A, B)
         ref = weight if weight is not None else x        # weight None: bare LoRA branch (zero base)
         cdt = ref.dtype if ref.dtype in (torch.bfloat16, torch.float32) else torch.float32
@@ -169,59 +169,52 @@ class _LoRALinearFn(torch.autograd.Function):
             with torch.autocast("cuda", enabled=False):
                 y2 = F.linear(x2, w, b)                  # frozen GEMM: PyTorch-ROCm / hipBLASLt
         Am, Bm = _master(A), _master(B)
-        xl = x2 if drop_mask is None else x2 * drop_mask.reshape(x2.shape).to(cdt)
         need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        tT = lora_fwd_(xl, Am, Bm, y2, scaling, layout, save_t=need_w)
-        ctx.scaling, ctx.layout = scaling, layout
+        tT = lora_fwd_(x2, Am, Bm, y2, scaling, layout, save_t=need_w, drop_p=drop_p, seed=seed)
+        ctx.scaling, ctx.layout, ctx.drop_p, ctx.seed = scaling, layout, drop_p, seed
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
-        ctx.has_mask = drop_mask is not None
-        ctx.save_for_backward(xl, w, A, B, tT, drop_mask)
+        ctx.save_for_backward(x2, w, A, B, tT)
         return y2.view(*x.shape[:-1], y2.shape[-1])
 
     @staticmethod
     def backward(ctx, gy):
-        xl, w, A, B, tT, drop_mask = ctx.saved_tensors
-        gy2 = _rows(gy if gy.dtype == xl.dtype else gy.to(xl.dtype))
+        x2, w, A, B, tT = ctx.saved_tensors
+        gy2 = _rows(gy if gy.dtype == x2.dtype else gy.to(x2.dtype))
         need_x = ctx.needs_input_grad[0]
         need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         Am, Bm = _master(A), _master(B)
         gx2 = None
         if need_x:
             if w is None:
-                gx2 = torch.zeros_like(xl)
+                gx2 = torch.zeros_like(x2)
             else:
                 with torch.autocast("cuda", enabled=False):
                     gx2 = gy2 @ w                        # frozen GEMM
         gA = torch.empty_like(Am) if need_w else None
         gB = torch.empty_like(Bm) if need_w else None
-        if ctx.has_mask and need_x:
-            # dropout on the LoRA input only: the branch's input-grad is masked before it joins gx
-            gxl = torch.zeros_like(gx2)
-            lora_bwd_(gy2, xl, tT, Am, Bm, gxl, gA, gB, ctx.scaling, ctx.layout)
-            gx2 = gx2 + gxl * drop_mask.reshape(gxl.shape).to(gxl.dtype)
-        else:
-            lora_bwd_(gy2, xl, tT, Am, Bm, gx2, gA, gB, ctx.scaling, ctx.layout)
+        if need_x or need_w:
+            lora_bwd_(gy2, x2, tT, Am, Bm, gx2, gA, gB, ctx.scaling, ctx.layout,
+                      drop_p=ctx.drop_p, seed=ctx.seed)
         gx = gx2.view(ctx.x_shape).to(ctx.x_dtype) if need_x else None
         if need_w:
             gA = gA.to(A.dtype) if ctx.needs_input_grad[3] else None
             gB = gB.to(B.dtype) if ctx.needs_input_grad[4] else None
-        return gx, None, None, gA, gB, None, None, None
+        return gx, None, None, gA, gB, None, None, None, None
 
 
-def lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], A: torch.Tensor,
+def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], A: torch.Tensor,
                 B: torch.Tensor, scaling: float, layout: int, dropout_p: float = 0.0,
                 training: bool = False) -> torch.Tensor:
     """``F.linear(x, weight, bias) + scaling * (dropout(x) @ A_c) @ B_c`` on the HIP path.
 
     ``layout`` selects how A/B are stored (LAYOUT_ROOT: A[in,r], B[r,out]; LAYOUT_PACKAGE:
     A[r,in], B[out,r]).  Dropout follows nn.Dropout semantics on the branch input only
-    (lora_layers.py:54, lora_layer.py:73).
+    (lora_layers.py:54, lora_layer.py:73) and is generated inside the kernels from a counter-based
+    hash; the seed is drawn from torch's CPU generator, so ``torch.manual_seed`` controls it and
+    ``torch.utils.checkpoint`` (which restores the RNG state for its recompute) replays the mask.
     """
-    mask = None
+    p, seed = 0.0, 0
     if training and dropout_p > 0.0:
-        if dropout_p >= 1.0:
-            mask = torch.zeros_like(x)
-        else:
-            keep = torch.rand(x.shape, device=x.device, dtype=torch.float32) >= dropout_p
-            mask = keep.to(x.dtype) * (1.0 / (1.0 - dropout_p))
-    return _LoRALinearFn.apply(x, weight, bias, A, B, float(scaling), int(layout), mask)
+        p = float(dropout_p)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _LoRALinearFn.apply(x, weight, bias, A, B, float(scaling), int(layout), p, seed)

@@ -217,22 +217,67 @@ def test_bitwise_determinism_and_full_size_properties():
     assert ((gx.float() - gx_w).abs().max() / gx_w.abs().max()).item() < 6e-3
 
 
-def test_dropout_branch_masks_input_and_grad():
+@pytest.mark.parametrize("layout,p,dtype", [(0, 0.1, "bf16"), (1, 0.5, "bf16"), (0, 0.3, "f32"), (1, 1.0, "bf16")])
+def test_in_kernel_dropout_matches_oracle_mask(layout, p, dtype):
+    """The kernels' counter-based dropout stream == oracle.dropout_keep, bit for bit (a single flipped
+    mask bit moves the result by far more than the tolerance), in forward, gx, gA and gB."""
+    rng = np.random.default_rng(11)
+    M, fin, fout, r, s, seed = 150, 256, 384, 16, 2.0, 0x1234_5678_9ABC_DEF
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    gy = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    A = O.bf16_round(rng.uniform(-.25, .25, (fin, r) if layout == 0 else (r, fin)).astype(np.float32))
+    B = O.bf16_round((rng.standard_normal((r, fout) if layout == 0 else (fout, r)) * .05).astype(np.float32))
+    mask = O.dropout_scale_mask(M, fin, p, seed, 7)
+    assert abs((mask > 0).mean() - (1 - p)) < 0.02
+    y = torch.zeros(M, fout, device=DEV, dtype=td)
+    tT = Fn.lora_fwd_(_t(x, td), _t(A), _t(B), y, s, layout, save_t=True, drop_p=p, seed=seed, offset=7)
+    want = O.adapter_delta(x, A, B, s, layout, mask, acc_dtype=np.float64)
+    scale = max(np.abs(want).max(), 1e-6)
+    assert np.abs(y.float().cpu().numpy() - want).max() < 1.2e-2 * scale
+    gx = torch.zeros(M, fin, device=DEV, dtype=td)
+    gA, gB = torch.zeros_like(_t(A)), torch.zeros_like(_t(B))
+    Fn.lora_bwd_(_t(gy, td), _t(x, td), tT, _t(A), _t(B), gx, gA, gB, s, layout, drop_p=p, seed=seed, offset=7)
+    gx_r, gA_r, gB_r = O.adapter_backward(gy, x, A, B, s, layout, mask, acc_dtype=np.float64)
+    for got, ref in ((gx.float().cpu().numpy(), gx_r), (gA.cpu().numpy(), gA_r), (gB.cpu().numpy(), gB_r)):
+        assert np.abs(got - ref).max() < 1.2e-2 * max(np.abs(ref).max(), 1e-6)
+    if p < 1.0:
+        assert np.all(gx.float().cpu().numpy()[mask == 0] == 0)       # dropped inputs get no branch gradient
+    # a different offset is a different stream
+    y2 = torch.zeros_like(y)
+    Fn.lora_fwd_(_t(x, td), _t(A), _t(B), y2, s, layout, drop_p=p, seed=seed, offset=8)
+    assert p == 1.0 or not torch.equal(y, y2)
+
+
+def test_module_dropout_train_eval_and_checkpoint_replay():
+    from torch.utils.checkpoint import checkpoint
     torch.manual_seed(1)
     lin = torch.nn.Linear(256, 512)
     mod = root_api.LoRALinear(lin, rank=16, alpha=32, dropout=0.5).to(DEV)
     with torch.no_grad():
         mod.lora.lora_B.normal_(0, 0.05)
-    mod.train()
     x = torch.randn(64, 256, device=DEV, requires_grad=True)
-    y = mod(x)
-    y.sum().backward()
-    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
     mod.eval()
     y_eval = mod(x.detach())
-    t = x.detach() @ mod.lora.lora_A
-    want = lin.to(DEV)(x.detach()) + 2.0 * (t @ mod.lora.lora_B)
+    want = lin.to(DEV)(x.detach()) + 2.0 * ((x.detach() @ mod.lora.lora_A) @ mod.lora.lora_B)
     assert ((y_eval - want).abs().max() / want.abs().max()).item() < 5e-3
+    mod.train()
+    torch.manual_seed(5)
+    y1 = mod(x)
+    torch.manual_seed(5)
+    y2 = mod(x)
+    y3 = mod(x)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)          # seeded by torch's generator
+    assert not torch.equal(y1, y_eval)
+    # checkpoint recompute replays the same mask: grads equal the non-checkpointed run
+    torch.manual_seed(9)
+    checkpoint(mod, x, use_reentrant=False).square().sum().backward()
+    gA1, gx1 = mod.lora.lora_A.grad.clone(), x.grad.clone()
+    mod.zero_grad()
+    x.grad = None
+    torch.manual_seed(9)
+    mod(x).square().sum().backward()
+    assert torch.equal(gA1, mod.lora.lora_A.grad) and torch.equal(gx1, x.grad)
 
 
 def test_merge_weights_matches_oracle(golden_dir):
