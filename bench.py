@@ -140,14 +140,58 @@ def committed_traffic(kernel, wg_x):
     return best
 
 
-def kernel_table(w, iters):
-    """Per-kernel and per-op timings at this config (rank-0 diagnostic + roofline source)."""
+def insitu_kernels(w, steps=2):
+    """Per-kernel durations measured INSIDE the step sequence: the library brackets every launch with a
+    pair of HIP events on the stream it launches on (sam3_lora_prof_start/stop), for `steps` extra steps
+    after the timed region.  Grouped by (kernel, streamed dimension)."""
+    import ctypes
     from sam3_lora_amd import _ffi
-    from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
     lib = _ffi.load()
-    M, r, s = w.M, w.rank, w.scaling
-    RP = 16 if r <= 16 else 32
-    e = 2
+    cap = 16384
+    _ffi.check(lib.sam3_lora_prof_start(_ffi.STAGE_ALL, cap), "prof_start")
+    for _ in range(steps):
+        w.step()
+    us = (ctypes.c_float * cap)()
+    st = (ctypes.c_int * cap)()
+    dm = (ctypes.c_int * cap)()
+    n = lib.sam3_lora_prof_stop(us, st, dm, cap)
+    if n < 0:
+        raise RuntimeError(_ffi.last_error())
+    M, r = w.M, w.rank
+    RP, e = (16 if r <= 16 else 32), 2
+    names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2", _ffi.STAGE_T3_GB: "k_t3",
+             _ffi.STAGE_T3_GA: "k_t3", _ffi.STAGE_REDUCE: "k_reduce"}
+
+    def alg_bytes(kernel, dim):
+        if kernel == "k_t2":      # read + write Y[M,N]; read T[M,RP], W2t[N,RP]
+            return 2 * e * M * dim + e * M * RP + e * dim * RP
+        if kernel == "k_t1":      # read X[M,K], W1[RP,K]; write T and TT
+            return e * M * dim + e * RP * dim + 2 * e * M * RP
+        if kernel == "k_t3":      # read X[M,N], TT[RP,M] (partials are overhead, not algorithmic)
+            return e * M * dim + e * RP * M
+        if kernel == "k_reduce":  # read-modify-write fp32 gA, gB
+            return 2 * 4 * r * dim
+        return (4 + 2) * r * dim  # k_pack: read fp32, write bf16
+
+    groups = {}
+    for i in range(n):
+        groups.setdefault((names[st[i]], dm[i]), []).append(us[i])
+    rows = []
+    for (k, dim), v in groups.items():
+        v.sort()
+        avg = sum(v) / len(v)
+        nb = alg_bytes(k, dim)
+        rows.append(dict(kernel=k, dim=dim, launches=len(v), algorithmic_bytes=nb, avg_us=round(avg, 2),
+                         median_us=round(v[len(v) // 2], 2), min_us=round(v[0], 2), total_us=round(sum(v), 1),
+                         GBps=round(nb / avg / 1e3, 1)))
+    rows.sort(key=lambda r_: -r_["total_us"])
+    return rows
+
+
+def op_table(w, iters):
+    """Whole C-ABI calls (all their kernels) against SURVEY section 8(d)'s per-unit algorithmic bytes."""
+    from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
+    M, r, s, e = w.M, w.rank, w.scaling, 2
     x1, h, y2, g2, gh, g1 = w.x1[0], w.h[0], w.y2[0], w.g2[0], w.gh[0], w.g1[0]
     A1, B1, A2, B2 = w.A1[0], w.B1[0], w.A2[0], w.B2[0]
     gA1, gB1, gA2, gB2 = (torch.zeros_like(p) for p in (A1, B1, A2, B2))
@@ -157,46 +201,22 @@ def kernel_table(w, iters):
     fwd2 = lambda: lora_fwd_(h, A2, B2, y2, s, 0)
     bwd2 = lambda: lora_bwd_(g2, h, t2, A2, B2, gh, gA2, gB2, s, 0, accumulate=True)
     bwd1 = lambda: lora_bwd_(gh, x1, t1, A1, B1, g1, gA1, gB1, s, 0, accumulate=True)
-    for f in (fwd1, fwd2, bwd2, bwd1):   # populate workspaces
-        f()
-    rows = []
-
-    def one(name, shape, mask, fn, nbytes):
-        lib.sam3_lora_debug_set_stages(mask)
-        try:
-            avg, med, mn = time_events(fn, iters)
-        finally:
-            lib.sam3_lora_debug_set_stages(_ffi.STAGE_ALL)
-        rows.append(dict(kernel=name, shape=shape, algorithmic_bytes=nbytes, avg_us=round(avg, 2),
-                         median_us=round(med, 2), min_us=round(mn, 2), GBps=round(nbytes / avg / 1e3, 1)))
-
     D, H = D_MODEL, D_HID
-    # T2: read+write Y[M,N] + read T[M,RP] + W2t[N,RP]
-    one("k_t2", f"M={M},N={H} (fc1 fwd y / fc2 bwd gx)", _ffi.STAGE_T2, fwd1, 2 * e * M * H + e * M * RP + e * H * RP)
-    one("k_t2", f"M={M},N={D} (fc2 fwd y / fc1 bwd gx)", _ffi.STAGE_T2, fwd2, 2 * e * M * D + e * M * RP + e * D * RP)
-    # T1: read X[M,K] + W1[RP,K], write T and TT
-    one("k_t1", f"M={M},K={D} (fc1 fwd t / fc2 bwd gt)", _ffi.STAGE_T1, fwd1, e * M * D + e * RP * D + 2 * e * M * RP)
-    one("k_t1", f"M={M},K={H} (fc2 fwd t / fc1 bwd gt)", _ffi.STAGE_T1, fwd2, e * M * H + e * RP * H + 2 * e * M * RP)
-    # T3: read X[M,N] + TT[RP,M]; partial writes are overhead, not algorithmic
-    one("k_t3", f"M={M},N={H} (fc1 gB / fc2 gA)", _ffi.STAGE_T3_GB, bwd1, e * M * H + e * RP * M)
-    one("k_t3", f"M={M},N={D} (fc1 gA / fc2 gB)", _ffi.STAGE_T3_GA, bwd1, e * M * D + e * RP * M)
-    one("k_reduce", "fc1 (gA,gB)", _ffi.STAGE_REDUCE, bwd1, 2 * 4 * r * (D + H))
-    one("k_pack", "fc1", _ffi.STAGE_PACK, fwd1, (4 + 2) * r * (D + H))
-    ops = []
-
-    def op(name, fn, nbytes):
-        avg, med, mn = time_events(fn, iters)
-        ops.append(dict(op=name, algorithmic_bytes=nbytes, avg_us=round(avg, 2), GBps=round(nbytes / avg / 1e3, 1),
-                        frac_of_peak=round(nbytes / avg / 1e3 / HBM_PEAK_GBPS, 4)))
-
-    # SURVEY section 8(d) per-unit figures (standalone fused adapter)
     fwd_b = lambda i, o: e * M * (i + 2 * o) + e * r * (i + o)
     bwd_b = lambda i, o: e * M * (o + i + 2 * i) + 4 * r * (i + o) * 2
-    op("sam3_lora_fwd fc1 (1024->4736)", fwd1, fwd_b(D, H))
-    op("sam3_lora_fwd fc2 (4736->1024)", fwd2, fwd_b(H, D))
-    op("sam3_lora_bwd fc1 (1024->4736)", bwd1, bwd_b(D, H))
-    op("sam3_lora_bwd fc2 (4736->1024)", bwd2, bwd_b(H, D))
-    return rows, ops
+    ops = []
+    for name, fn, nb in (("sam3_lora_fwd fc1 (1024->4736)", fwd1, fwd_b(D, H)),
+                         ("sam3_lora_fwd fc2 (4736->1024)", fwd2, fwd_b(H, D)),
+                         ("sam3_lora_bwd fc1 (1024->4736)", bwd1, bwd_b(D, H)),
+                         ("sam3_lora_bwd fc2 (4736->1024)", bwd2, bwd_b(H, D))):
+        avg, med, mn = time_events(fn, iters)
+        ops.append(dict(op=name, algorithmic_bytes=nb, avg_us=round(avg, 2), GBps=round(nb / avg / 1e3, 1),
+                        frac_of_peak=round(nb / avg / 1e3 / HBM_PEAK_GBPS, 4)))
+    tot_b = sum(o["algorithmic_bytes"] for o in ops)
+    tot_t = sum(o["avg_us"] for o in ops)
+    ops.append(dict(op="fwd+bwd of one block (fc1+fc2)", algorithmic_bytes=tot_b, avg_us=round(tot_t, 2),
+                    GBps=round(tot_b / tot_t / 1e3, 1), frac_of_peak=round(tot_b / tot_t / 1e3 / HBM_PEAK_GBPS, 4)))
+    return ops
 
 
 def cpu_baseline(rank, seconds_budget=25.0):
@@ -297,10 +317,13 @@ def main():
                        "grad_allreduce_bytes": w.reducer.nbytes, "finite": bool(finite)},
         }
     if rank == 0 and not args.no_roofline:
-        rows, ops = kernel_table(w, args.kernel_iters)
-        dom = max(rows[:6], key=lambda r_: r_["avg_us"] * {"k_t2": 3, "k_t1": 3, "k_t3": 1}[r_["kernel"]])
-        tr = committed_traffic(dom["kernel"], (D_HID + 127) // 128 if "N=%d" % D_HID in dom["shape"] else -1)
-        out["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} [{dom['shape']}]",
+        rows = insitu_kernels(w)
+        ops = op_table(w, args.kernel_iters)
+        dom = rows[0]             # largest share of the step's kernel time
+        dimname = {"k_t1": "K", "k_t2": "N", "k_t3": "N"}.get(dom["kernel"], "dim")
+        tr = committed_traffic(dom["kernel"], (dom["dim"] + 127) // 128 if dom["kernel"] == "k_t2" else -1)
+        out["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} [M={w.M},{dimname}={dom['dim']}]",
+                           "launches_timed": dom["launches"],
                            "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(dom["GBps"] / HBM_PEAK_GBPS, 4),
                            "traffic": tr["hbm_bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,

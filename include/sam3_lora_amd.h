@@ -132,6 +132,16 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
 #define SAM3_LORA_STAGE_ALL 0xffffffffu
 unsigned sam3_lora_debug_set_stages(unsigned mask);
 
+/*
+ * In-situ kernel timer (profiling aid): between prof_start and prof_stop every launch of a stage in
+ * `stage_mask` is bracketed by a pair of HIP events recorded on the caller's stream, inside the real
+ * fwd/bwd call sequence (up to `capacity` launches).  prof_stop synchronises those events, writes per
+ * launch the elapsed microseconds, the stage bit and the streamed dimension (K for T1, N for T2/T3) and
+ * returns the number of samples (or a negative error).  Not thread-safe; one profiler at a time.
+ */
+int sam3_lora_prof_start(unsigned stage_mask, int capacity);
+int sam3_lora_prof_stop(float* us_out, int* stage_out, int* dim_out, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ EXPORTS = (
     "sam3_lora_abi_version", "sam3_lora_last_error", "sam3_lora_saved_t_bytes",
     "sam3_lora_fwd_workspace_bytes", "sam3_lora_bwd_workspace_bytes",
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages",
+    "sam3_lora_prof_start", "sam3_lora_prof_stop",
 )
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
@@ -64,6 +65,10 @@ def _declare(lib):
     ]
     lib.sam3_lora_debug_set_stages.restype = ctypes.c_uint
     lib.sam3_lora_debug_set_stages.argtypes = [ctypes.c_uint]
+    lib.sam3_lora_prof_start.restype = c_int
+    lib.sam3_lora_prof_start.argtypes = [ctypes.c_uint, c_int]
+    lib.sam3_lora_prof_stop.restype = c_int
+    lib.sam3_lora_prof_stop.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]

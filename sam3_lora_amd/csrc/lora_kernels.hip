@@ -116,44 +116,47 @@ __global__ __launch_bounds__(256) void k_pack(PackJob j0, PackJob j1) {
 //   workgroup = 64 rows x full K, 4 waves x 16 rows; K streamed in 128-column chunks through a
 //   double-buffered, XOR-swizzled LDS tile shared by the 4 waves (W1 chunk re-used 4x).
 // ------------------------------------------------------------------------------------------
-template <typename XT, int RT>
+template <typename XT, int RT, int BK>
 __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ W1, bf16_t* __restrict__ T,
                                             bf16_t* __restrict__ TT, long long M, long long Mp, int K,
                                             DropKey dk) {
-    constexpr int RP = RT * 16, BM = 64, BK = 128, CPR = BK / 8;
+    constexpr int RP = RT * 16, BM = 64, CPR = BK / 8;          // CPR 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;                               // tile rows covered per pass of 256 threads
+    constexpr int XP = BM / RPP, WP = RP / RPP;                  // passes for the x tile / the W1 tile
+    static_assert(RP % RPP == 0, "tile geometry");
     __shared__ uint4 xs[2][BM * CPR];
     __shared__ uint4 ws[2][RP * CPR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const long long m0 = (long long)blockIdx.x * BM;
     const int nk = (K + BK - 1) / BK;
-    const int lrow = tid >> 4, lc = tid & 15;
+    const int lrow = tid / CPR, lc = tid % CPR;
 
-    uint4 xr[4], wr[RT];
+    uint4 xr[XP], wr[WP];
     auto gload = [&](int kc) {
         const int k = kc * BK + lc * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long m = m0 + lrow + 16 * i;
+        for (int i = 0; i < XP; ++i) {
+            const long long m = m0 + lrow + RPP * i;
             xr[i] = (m < M && k < K) ? load8(X + m * ldx + k) : zero4();
             if (dk.thr) xr[i] = drop8(xr[i], (unsigned long long)m * dk.width + k, dk);
         }
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-            const int r = lrow + 16 * j;
+        for (int j = 0; j < WP; ++j) {
+            const int r = lrow + RPP * j;
             wr[j] = (k < K) ? *reinterpret_cast<const uint4*>(W1 + (long long)r * K + k) : zero4();
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = lrow + 16 * i;
+        for (int i = 0; i < XP; ++i) {
+            const int row = lrow + RPP * i;
             xs[buf][row * CPR + (lc ^ (row & 15))] = xr[i];
         }
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-            const int r = lrow + 16 * j;
+        for (int j = 0; j < WP; ++j) {
+            const int r = lrow + RPP * j;
             ws[buf][r * CPR + (lc ^ (r & 15))] = wr[j];
         }
     };
@@ -541,7 +544,8 @@ T3Plan plan_t3(long long Mp, int N) {
     T3Plan p;
     p.nchunks = (N + 255) / 256;
     const long long stages = Mp / 64;
-    long long nr = (768 + p.nchunks - 1) / p.nchunks;
+    long long nr = 512 / p.nchunks;  // 64 KB LDS -> 2 workgroups per CU: keep every workgroup co-resident (one round)
+    if (nr < 1) nr = 1;
     if (nr > stages) nr = stages;
     if (nr < 1) nr = 1;
     const long long st_per = (stages + nr - 1) / nr;
@@ -609,10 +613,37 @@ Strides strides_of(int layout, int in_f, int out_f, int rank) {
     return s;
 }
 
+// ---- in-situ kernel timer (sam3_lora_prof_start/stop): HIP events recorded on the caller's stream
+// immediately before and after each launch of the selected stages, inside the real call sequence.
+struct ProfState {
+    unsigned mask = 0;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;  // 2*cap events
+    int* stage = nullptr;
+    int* dim = nullptr;
+} g_prof;
+
+struct ProfScope {
+    int slot = -1;
+    hipStream_t st;
+    ProfScope(unsigned stage_bit, int dim, hipStream_t s) : st(s) {
+        if ((g_prof.mask & stage_bit) && g_prof.n < g_prof.cap) {
+            slot = g_prof.n++;
+            g_prof.stage[slot] = (int)stage_bit;
+            g_prof.dim[slot] = dim;
+            hipEventRecord(g_prof.ev[2 * slot], st);
+        }
+    }
+    ~ProfScope() {
+        if (slot >= 0) hipEventRecord(g_prof.ev[2 * slot + 1], st);
+    }
+};
+
 void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
     const long long na = (long long)a.I * a.J, nb = (long long)b.I * b.J;
     const long long nmax = na > nb ? na : nb;
     dim3 grid((unsigned)((nmax + 255) / 256), 2);
+    ProfScope ps(SAM3_LORA_STAGE_PACK, a.J > b.J ? a.J : b.J, st);
     hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, a, b);
 }
 
@@ -620,10 +651,17 @@ template <typename XT>
 void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t* TT, long long M, long long Mp, int K,
                int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)(Mp / 64));
-    if (RT == 1)
-        hipLaunchKernelGGL((k_t1<XT, 1>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
-    else
-        hipLaunchKernelGGL((k_t1<XT, 2>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+    ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
+    // wide K: 256-column chunks (2 x 40 KB in flight per workgroup); narrow K: 128-column chunks
+    const bool wide = K >= 2048 && !env_flag("SAM3_LORA_T1_BK128");
+#define T1_LAUNCH(RTV, BKV) \
+    hipLaunchKernelGGL((k_t1<XT, RTV, BKV>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk)
+    if (RT == 1) {
+        if (wide) T1_LAUNCH(1, 256); else T1_LAUNCH(1, 128);
+    } else {
+        if (wide) T1_LAUNCH(2, 256); else T1_LAUNCH(2, 128);
+    }
+#undef T1_LAUNCH
 }
 
 template <typename YT>
@@ -633,9 +671,10 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     const int nchunks = (N + 127) / 128;
     long long want = (3072 + nchunks - 1) / nchunks;  // ~3k workgroups of 4 waves
     long long tiles_per_wg = (ntiles + want - 1) / want;
-    if (tiles_per_wg < 4) tiles_per_wg = 4;
+    if (tiles_per_wg < 16) tiles_per_wg = 16;
     tiles_per_wg = round_up(tiles_per_wg, 4);
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
+    ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
     if (RT == 1)
         hipLaunchKernelGGL((k_t2<YT, 1>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk);
     else
@@ -644,9 +683,10 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
 
 template <typename XT>
 void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N,
-               const T3Plan& p, int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
+               const T3Plan& p, int RT, unsigned stage_bit, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
     const bool gather = env_flag("SAM3_LORA_T3_GATHER");
+    ProfScope ps(stage_bit, N, st);
 #define T3_LAUNCH(RTV, GV) \
     hipLaunchKernelGGL((k_t3<XT, RTV, GV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk)
     if (RT == 1) {
@@ -707,6 +747,41 @@ unsigned sam3_lora_debug_set_stages(unsigned mask) {
     const unsigned old = g_stages;
     g_stages = mask;
     return old;
+}
+
+int sam3_lora_prof_start(unsigned stage_mask, int capacity) {
+    g_err[0] = 0;
+    if (g_prof.ev) return fail(SAM3_LORA_EINVAL, "profiler already started");
+    if (capacity <= 0 || capacity > (1 << 20)) return fail(SAM3_LORA_EINVAL, "bad capacity %d", capacity);
+    g_prof.ev = new hipEvent_t[2 * (size_t)capacity];
+    g_prof.stage = new int[capacity];
+    g_prof.dim = new int[capacity];
+    for (int i = 0; i < 2 * capacity; ++i)
+        if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return fail(SAM3_LORA_ELAUNCH, "hipEventCreate failed");
+    g_prof.cap = capacity;
+    g_prof.n = 0;
+    g_prof.mask = stage_mask;
+    return 0;
+}
+
+int sam3_lora_prof_stop(float* us_out, int* stage_out, int* dim_out, int capacity) {
+    g_err[0] = 0;
+    if (!g_prof.ev) return fail(SAM3_LORA_EINVAL, "profiler not started");
+    g_prof.mask = 0;
+    const int n = g_prof.n < capacity ? g_prof.n : capacity;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        us_out[i] = ms * 1e3f;
+        stage_out[i] = g_prof.stage[i];
+        dim_out[i] = g_prof.dim[i];
+    }
+    for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev; delete[] g_prof.stage; delete[] g_prof.dim;
+    g_prof.ev = nullptr; g_prof.stage = nullptr; g_prof.dim = nullptr;
+    g_prof.cap = 0; g_prof.n = 0;
+    return n;
 }
 
 const char* sam3_lora_last_error(void) { return g_err; }
@@ -820,13 +895,13 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
     if (bf) {
         if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
-        if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);   // gB = t^T . gy
-        if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st, dk);     // gA^T = gt^T . x
+        if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
+        if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);     // gA^T = gt^T . x
         if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
     } else {
         if (s1) launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);
-        if (gB_accum && s3b) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, st);
-        if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, st, dk);
+        if (gB_accum && s3b) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);
+        if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
         if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
     }
     if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
@@ -835,6 +910,7 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
         ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
         dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);
+        ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
         hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling * inv_keep, accumulate);
     }
     return launch_ok("sam3_lora_bwd");
