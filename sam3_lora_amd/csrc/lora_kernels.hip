@@ -129,7 +129,12 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
     __shared__ uint4 ws[2][RP * CPR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const long long m0 = (long long)blockIdx.x * BM;
+    // Traversal order is part of the design: workgroups are dispatched in blockIdx order, and T1 walks
+    // the activation from its LAST rows to its first.  T2 (which writes y / gx front to back) is always
+    // followed by a T1 over that same tensor (fc1's y is fc2's x; fc2's gx is fc1's gy), so T1 starts on
+    // the ~256 MB the Infinity Cache still holds; the T3 that follows T1 walks front to back for the
+    // same reason.
+    const long long m0 = (long long)(gridDim.x - 1 - blockIdx.x) * BM;
     const int nk = (K + BK - 1) / BK;
     const int lrow = tid / CPR, lc = tid % CPR;
 
@@ -356,13 +361,17 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.x * CW;
-    const long long r_begin = (long long)blockIdx.y * rows_per_wg;
+    // T3 walks the tensor front to back; T1 walks it back to front (see k_t1), so a T3 that follows a
+    // T1 over the same activation starts on the rows T1 streamed last (still in the Infinity Cache).
+    const int rs = (int)blockIdx.y;
+    const long long r_begin = (long long)rs * rows_per_wg;
     const long long r_end = min(r_begin + rows_per_wg, Mp);
     const int nst = (int)((r_end - r_begin) / BR);
     const int lrow = tid >> 5, lc = tid & 31;
 
     uint4 xr[8];
-    auto gload = [&](int s) {
+    auto gload = [&](int sidx) {
+        const int s = sidx;
         const int col = c0 + lc * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
         if (s + 1 < nst) sstore(buf ^ 1);
         __syncthreads();
     }
-    float* out = Gpart + (long long)blockIdx.y * RP * N;
+    float* out = Gpart + (long long)rs * RP * N;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -652,8 +661,9 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
                int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)(Mp / 64));
     ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
-    // wide K: 256-column chunks (2 x 40 KB in flight per workgroup); narrow K: 128-column chunks
-    const bool wide = K >= 2048 && !env_flag("SAM3_LORA_T1_BK128");
+    // 128-column chunks measured faster than 256 at K=4736 on MI355X (76.6 vs 99.0 us, profiles/r01b):
+    // the 80 KB-LDS variant halves co-residency.  Kept selectable for re-tuning.
+    const bool wide = env_flag("SAM3_LORA_T1_BK256");
 #define T1_LAUNCH(RTV, BKV) \
     hipLaunchKernelGGL((k_t1<XT, RTV, BKV>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk)
     if (RT == 1) {
@@ -671,7 +681,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     const int nchunks = (N + 127) / 128;
     long long want = (3072 + nchunks - 1) / nchunks;  // ~3k workgroups of 4 waves
     long long tiles_per_wg = (ntiles + want - 1) / want;
-    if (tiles_per_wg < 16) tiles_per_wg = 16;
+    if (tiles_per_wg < 4) tiles_per_wg = 4;
     tiles_per_wg = round_up(tiles_per_wg, 4);
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
