@@ -97,29 +97,86 @@ __device__ __forceinline__ uint4 drop8(uint4 v, unsigned long long e8, const Dro
 struct PackJob {
     const float* src;
     bf16_t* dst;
-    int I, J, Iv, Jv;
+    int I, J, Iv, Jv;     // dst is I x J (J already padded), valid region Iv x Jv
     long long si, sj;
+    int frag;             // 1: dst is the fragment-major W1f image (see k_t1), I = RP, J = K padded to 128
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackJob j0, PackJob j1) {
     const PackJob jb = blockIdx.y == 0 ? j0 : j1;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)jb.I * jb.J) return;
-    const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
+    int i, j;
+    if (jb.frag) {   // idx = ((kstep*RT + rt)*64 + g*16 + n)*8 + e  ->  i = rt*16 + n, j = kstep*32 + g*8 + e
+        const int RT = jb.I / 16, e = (int)(idx & 7), nn = (int)(idx >> 3) & 15, gg = (int)(idx >> 7) & 3;
+        const int blk = (int)(idx >> 9);
+        i = (blk % RT) * 16 + nn;
+        j = (blk / RT) * 32 + gg * 8 + e;
+    } else {
+        i = (int)(idx / jb.J);
+        j = (int)(idx % jb.J);
+    }
     const float v = (i < jb.Iv && j < jb.Jv) ? jb.src[i * jb.si + j * jb.sj] : 0.f;
     bf16x2 t = {(__bf16)v, (__bf16)0.f};
     jb.dst[idx] = (bf16_t)(__builtin_bit_cast(unsigned, t) & 0xffffu);
 }
 
 // ------------------------------------------------------------------------------------------
-// T1: T[Mp, RP] (row-major bf16) and TT[RP, Mp] (bf16) = X[M, K] . W1[RP, K]^T
+// Streaming discipline shared by T1 / T2 / T3 (measured on MI355X, profiles/r01c notes):
+//   * every global load in a main loop is UNCONDITIONAL.  Tails are handled by clamping the address
+//     into the tensor and zeroing the value with a bit mask when it is consumed.  A predicated load
+//     becomes an exec-masked branch, and hipcc then falls back to `s_waitcnt vmcnt(0)` at the first
+//     consumer -- which silently drains the prefetch and leaves the kernel latency-bound (~5.0 TB/s).
+//   * a load whose value is needed "now" (LoRA fragments, t fragments) is issued one stage EARLY,
+//     in front of the big prefetch: vmcnt is an in-order counter, so waiting for the newest load
+//     would wait for everything older too.
+//   * the software pipeline is written straight-line (two named register sets, loop unrolled by 2,
+//     iteration count padded to even with zero-masked stages) so the waits are counted, not zero.
+//   * no workgroup barrier inside a streaming loop: each wave streams its own rows through its own LDS
+//     slab (a wave's LDS operations execute in order, so only the compiler needs pinning).
+// ------------------------------------------------------------------------------------------
+template <typename XT>
+struct Raw8;  // 8 consecutive activation elements exactly as loaded (conversion happens at use)
+template <>
+struct Raw8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ uint4 packed() const { return v; }
+};
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ uint4 packed() const {
+        return make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+    }
+};
+__device__ __forceinline__ uint4 and4(uint4 v, unsigned m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); }
+
+// ------------------------------------------------------------------------------------------
+// T1: T[Mp, RP] (row-major bf16) and TTf (fragment-major bf16) = X[M, K] . W1[RP, K]^T
 //   workgroup = 64 rows x full K, 4 waves x 16 rows; K streamed in 128-column chunks through a
 //   double-buffered, XOR-swizzled LDS tile shared by the 4 waves (W1 chunk re-used 4x).
+//   This plain structure measured FASTEST of four variants on MI355X at K=4736, M=41472 (same box A/B or
+//   back-to-back runs, profiles/r01c_t1_variants.txt): 77 us (this) | 91 us (same tile, branch-free
+//   counted-vmcnt distance-2 prefetch) | 99 us (256-column chunks) | 103 us (wave-private slabs with the
+//   LoRA operand read fragment-major from L2 -- operand traffic = activation traffic).
+//   TTf  fragment-major image of T^T:  block (m/32, rt) = 64 lanes x 8 elements, lane = g*16 + n holds
+//        T[(m/32)*32 + g*8 .. +8][rt*16 + n]   -- exactly the A-operand T3 needs, 1 KB per load
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {   // LDS ops of one wave execute in order; this pins the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename XT, int RT, int BK>
 __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ W1, bf16_t* __restrict__ T,
-                                            bf16_t* __restrict__ TT, long long M, long long Mp, int K,
+                                            bf16_t* __restrict__ TTf, long long M, long long Mp, int K,
                                             DropKey dk) {
     constexpr int RP = RT * 16, BM = 64, CPR = BK / 8;          // CPR 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;                               // tile rows covered per pass of 256 threads
@@ -129,12 +186,7 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
     __shared__ uint4 ws[2][RP * CPR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    // Traversal order is part of the design: workgroups are dispatched in blockIdx order, and T1 walks
-    // the activation from its LAST rows to its first.  T2 (which writes y / gx front to back) is always
-    // followed by a T1 over that same tensor (fc1's y is fc2's x; fc2's gx is fc1's gy), so T1 starts on
-    // the ~256 MB the Infinity Cache still holds; the T3 that follows T1 walks front to back for the
-    // same reason.
-    const long long m0 = (long long)(gridDim.x - 1 - blockIdx.x) * BM;
+    const long long m0 = (long long)blockIdx.x * BM;
     const int nk = (K + BK - 1) / BK;
     const int lrow = tid / CPR, lc = tid % CPR;
 
@@ -193,22 +245,24 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
     }
     // lane (n, g) holds t[row = m0 + wave*16 + n][rank idx = rt*16 + g*4 + j]
     const long long m = m0 + wave * 16 + n;
+    const long long blk = m >> 5;
+    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const unsigned p0 = pack2(acc[rt][0], acc[rt][1]), p1 = pack2(acc[rt][2], acc[rt][3]);
         *reinterpret_cast<uint2*>(T + m * RP + rt * 16 + g * 4) = make_uint2(p0, p1);
-        const int r = rt * 16 + g * 4;
-        TT[(long long)(r + 0) * Mp + m] = (bf16_t)(p0 & 0xffffu);
-        TT[(long long)(r + 1) * Mp + m] = (bf16_t)(p0 >> 16);
-        TT[(long long)(r + 2) * Mp + m] = (bf16_t)(p1 & 0xffffu);
-        TT[(long long)(r + 3) * Mp + m] = (bf16_t)(p1 >> 16);
+        bf16_t* tb = TTf + (((blk * RT + rt) * 4 + gq) * 16 + g * 4) * 8 + jq;   // [blk][rt][gq][n'=g*4+j][jq]
+        tb[0] = (bf16_t)(p0 & 0xffffu);
+        tb[8] = (bf16_t)(p0 >> 16);
+        tb[16] = (bf16_t)(p1 & 0xffffu);
+        tb[24] = (bf16_t)(p1 >> 16);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // T2: Y[M, N] += scale * T[M, RP] . W2[RP, N]      (W2 given transposed: W2t[N, RP])
 //   one wave = 128 output columns (W2 fragments live in registers) x a strided set of 16-row
-//   tiles; no workgroup barrier anywhere -- each wave streams on its own.
+//   tiles; no workgroup barrier anywhere -- each wave streams on its own, one tile ahead.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void mask8(f32x4& a, f32x4& b, unsigned keep) {
 #pragma unroll
@@ -224,14 +278,17 @@ struct YTile;  // 16 rows x 128 cols, lane L owns rows p*4 + (L>>4), cols (L&15)
 template <>
 struct YTile<bf16_t> {
     uint4 v[4];
+    template <bool FAST>
     __device__ __forceinline__ void load(const bf16_t* Y, long long ldy, long long m0, int col, int lane,
                                          long long M, int N) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const long long m = m0 + p * 4 + (lane >> 4);
-            v[p] = (m < M && col < N) ? *reinterpret_cast<const uint4*>(Y + m * ldy + col) : zero4();
+            if (FAST) v[p] = *reinterpret_cast<const uint4*>(Y + m * ldy + col);
+            else v[p] = (m < M && col < N) ? *reinterpret_cast<const uint4*>(Y + m * ldy + col) : zero4();
         }
     }
+    template <bool FAST, bool DROP>
     __device__ __forceinline__ void add_store(bf16_t* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
                                               const DropKey& dk) {
@@ -241,13 +298,13 @@ struct YTile<bf16_t> {
             const long long m = m0 + rl;
             f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
             f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
-            if (dk.thr) mask8(a, b, keep8((unsigned long long)m * dk.width + col, dk));
+            if (DROP) mask8(a, b, keep8((unsigned long long)m * dk.width + col, dk));
             uint4 o;
             o.x = pack2(bf_lo(v[p].x) + scale * a[0], bf_hi(v[p].x) + scale * a[1]);
             o.y = pack2(bf_lo(v[p].y) + scale * a[2], bf_hi(v[p].y) + scale * a[3]);
             o.z = pack2(bf_lo(v[p].z) + scale * b[0], bf_hi(v[p].z) + scale * b[1]);
             o.w = pack2(bf_lo(v[p].w) + scale * b[2], bf_hi(v[p].w) + scale * b[3]);
-            if (m < M && col < N) *reinterpret_cast<uint4*>(Y + m * ldy + col) = o;
+            if (FAST || (m < M && col < N)) *reinterpret_cast<uint4*>(Y + m * ldy + col) = o;
         }
     }
 };
@@ -255,16 +312,18 @@ struct YTile<bf16_t> {
 template <>
 struct YTile<float> {
     f32x4 v[4][2];
+    template <bool FAST>
     __device__ __forceinline__ void load(const float* Y, long long ldy, long long m0, int col, int lane,
                                          long long M, int N) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const long long m = m0 + p * 4 + (lane >> 4);
-            const bool ok = (m < M && col < N);
+            const bool ok = FAST || (m < M && col < N);
             v[p][0] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
             v[p][1] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
+    template <bool FAST, bool DROP>
     __device__ __forceinline__ void add_store(float* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
                                               const DropKey& dk) {
@@ -274,8 +333,8 @@ struct YTile<float> {
             const long long m = m0 + rl;
             f32x4 a = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8);
             f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
-            if (dk.thr) mask8(a, b, keep8((unsigned long long)m * dk.width + col, dk));
-            if (m < M && col < N) {
+            if (DROP) mask8(a, b, keep8((unsigned long long)m * dk.width + col, dk));
+            if (FAST || (m < M && col < N)) {
                 *reinterpret_cast<f32x4*>(Y + m * ldy + col) = v[p][0] + scale * a;
                 *reinterpret_cast<f32x4*>(Y + m * ldy + col + 4) = v[p][1] + scale * b;
             }
@@ -283,7 +342,7 @@ struct YTile<float> {
     }
 };
 
-template <typename YT, int RT>
+template <typename YT, int RT, bool DROP>
 __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk) {
@@ -301,25 +360,23 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
         const int col = c0 + ct * 16 + n;
         const bool ok = col < N;
         wlo[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + g * 4) : make_uint2(0u, 0u);
+        whi[ct] = make_uint2(0u, 0u);
         if (RT == 2)
             whi[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + 16 + g * 4) : make_uint2(0u, 0u);
     }
 
-    const long long ntiles = (M + 15) / 16;
-    long long t = (long long)blockIdx.y * tiles_per_wg + wave;
+    const long long ntiles = (M + 15) / 16, nfull = M / 16;
+    const long long t_begin = (long long)blockIdx.y * tiles_per_wg + wave;
     const long long t_end = min((long long)(blockIdx.y + 1) * tiles_per_wg, ntiles);
     const int col = c0 + (lane & 15) * 8;
 
-    YTile<YT> cur, nxt;
-    if (t < t_end) nxt.load(Y, ldy, t * 16, col, lane, M, N);
-    for (; t < t_end; t += 4) {
-        const long long m0 = t * 16;
-        cur = nxt;
-        if (t + 4 < t_end) nxt.load(Y, ldy, (t + 4) * 16, col, lane, M, N);
-        // T fragment (B-operand: k = rank index, n = activation row)
-        const uint2 tlo = *reinterpret_cast<const uint2*>(T + (m0 + n) * RP + g * 4);
-        uint2 thi = make_uint2(0u, 0u);
-        if (RT == 2) thi = *reinterpret_cast<const uint2*>(T + (m0 + n) * RP + 16 + g * 4);
+    // T fragment of a tile (MFMA B-operand: k = rank index, n = activation row); T has Mp >= 16*ntiles rows
+    auto load_t = [&](long long t, uint2& lo, uint2& hi) {
+        lo = *reinterpret_cast<const uint2*>(T + (t * 16 + n) * RP + g * 4);
+        hi = make_uint2(0u, 0u);
+        if (RT == 2) hi = *reinterpret_cast<const uint2*>(T + (t * 16 + n) * RP + 16 + g * 4);
+    };
+    auto delta_to_slab = [&](const uint2& tlo, const uint2& thi) {
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -335,133 +392,177 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
             // lane (n, g): delta[row n][cols ct*16 + g*4 .. +4]
             *reinterpret_cast<f32x4*>(slab + n * LDW + ct * 16 + g * 4) = d;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        cur.add_store(Y, ldy, m0, col, lane, M, N, slab, LDW, scale, dk);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const bool colfull = c0 + CW <= N;
+    const long long t_fast_end = colfull ? min(t_end, nfull) : t_begin;   // tiles with no tail at all
+    long long t = t_begin;
+    if (t < t_fast_end) {
+        // branch-free stream: tile t+4 (and its t fragment, issued first) is in flight while tile t is updated
+        YTile<YT> cur, nxt;
+        uint2 tlo, thi, nlo, nhi;
+        load_t(t, nlo, nhi);
+        nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
+        for (; t < t_fast_end; t += 4) {
+            cur = nxt;
+            tlo = nlo;
+            thi = nhi;
+            const long long tn = t + 4 < t_fast_end ? t + 4 : t;   // last iteration re-reads its own tile (L2 hit)
+            load_t(tn, nlo, nhi);
+            nxt.template load<true>(Y, ldy, tn * 16, col, lane, M, N);
+            delta_to_slab(tlo, thi);
+            wave_sync();
+            cur.template add_store<true, DROP>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk);
+            wave_sync();
+        }
+    }
+    for (; t < t_end; t += 4) {   // ragged tiles (last rows / last column chunk): predicated path
+        YTile<YT> cur;
+        uint2 tlo, thi;
+        load_t(t, tlo, thi);
+        cur.template load<false>(Y, ldy, t * 16, col, lane, M, N);
+        delta_to_slab(tlo, thi);
+        wave_sync();
+        cur.template add_store<false, DROP>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk);
+        wave_sync();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// T3: Gpart[rs][RP][N] = sum_{m in row range rs} TT[:, m] (x) X[m, :]
-//   workgroup = 256 columns x a row range; 64-row stages, double-buffered swizzled LDS tile;
-//   wave w owns column tiles 4w..4w+3; B-operand via ds_read_b64_tr_b16.
+// T3: Gpart[rg][RP][N] = sum_{m in row group rg} T[m, :]^T (x) X[m, :]
+//   WAVE-PRIVATE streaming like T1: workgroup = 128 columns x a row group; each of its 4 waves walks its
+//   own quarter of the rows in 32-row steps (8 coalesced 16-B loads per lane: 4 rows x 256 B per
+//   instruction) through a private 8 KB LDS slab; the B-operand is fetched with ds_read_b64_tr_b16
+//   (hardware transpose); the A-operand (t^T) arrives fragment-major, 1 KB per step, from T1.
+//   No barrier until the end, where the 4 waves' accumulators are added through LDS in fixed order.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename XT, int RT, bool GATHER>
+template <typename XT, int RT, bool GATHER, bool DROP>
 __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
-                                            const bf16_t* __restrict__ TT, float* __restrict__ Gpart,
+                                            const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
                                             long long M, long long Mp, int N, int rows_per_wg, DropKey dk) {
-    constexpr int RP = RT * 16, BR = 64, CW = 256, CPR = CW / 8;
-    __shared__ uint4 xs[2][BR * CPR];
+    constexpr int RP = RT * 16, CW = 128, CPR = 16;
+    __shared__ uint4 xs[4][32 * CPR];      // 32 rows x 256 B per wave; reused as the reduction buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.x * CW;
-    // T3 walks the tensor front to back; T1 walks it back to front (see k_t1), so a T3 that follows a
-    // T1 over the same activation starts on the rows T1 streamed last (still in the Infinity Cache).
-    const int rs = (int)blockIdx.y;
-    const long long r_begin = (long long)rs * rows_per_wg;
-    const long long r_end = min(r_begin + rows_per_wg, Mp);
-    const int nst = (int)((r_end - r_begin) / BR);
-    const int lrow = tid >> 5, lc = tid & 31;
+    const int rg = (int)blockIdx.y;
+    // rows of this wave: quarter `wave` of [rg*rows_per_wg, +rows_per_wg), rows_per_wg % 128 == 0
+    const long long w_begin = (long long)rg * rows_per_wg + (long long)wave * (rows_per_wg / 4);
+    long long w_end = w_begin + rows_per_wg / 4;
+    if (w_end > Mp) w_end = Mp;
+    const int nst = w_end > w_begin ? (int)((w_end - w_begin) / 32) : 0, nst2 = (nst + 1) & ~1;
+    const int lr = lane >> 4, lc = lane & 15;
+    const int col = c0 + lc * 8;
+    const int colc = col < N ? col : N - 8;
+    const unsigned cmask = col < N ? 0xffffffffu : 0u;
 
-    uint4 xr[8];
-    auto gload = [&](int sidx) {
-        const int s = sidx;
-        const int col = c0 + lc * 8;
+    struct Regs {
+        uint4 t[RT];        // t^T fragment of the step (issued BEFORE the x loads: it must land first)
+        Raw8<XT> x[8];
+    };
+    auto gload = [&](int s0, Regs& r_) {
+        const int s = s0 < nst ? s0 : nst - 1;
+        const long long mb = w_begin + (long long)s * 32;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const long long m = r_begin + (long long)s * BR + lrow + 8 * i;
-            xr[i] = (m < M && col < N) ? load8(X + m * ldx + col) : zero4();
-            if (dk.thr) xr[i] = drop8(xr[i], (unsigned long long)m * dk.width + col, dk);
+        for (int rt = 0; rt < RT; ++rt)
+            r_.t[rt] = *reinterpret_cast<const uint4*>(TTf + (((mb >> 5) * RT + rt) * 64 + lane) * 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const long long m = mb + lr + 4 * q;
+            r_.x[q].load(X + (m < M ? m : M - 1) * ldx + colc);
         }
     };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = lrow + 8 * i;
-            xs[buf][row * CPR + (lc ^ (t3_h(row) << 1))] = xr[i];
-        }
-    };
-
-    f32x4 acc[RT][4];
+    f32x4 acc[RT][8];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    if (nst > 0) {
-        gload(0);
-        sstore(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < nst; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nst) gload(s + 1);
-        const long long mbase = r_begin + (long long)s * BR;
+        for (int j = 0; j < 8; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4* slab = xs[wave];
+    auto stage = [&](int s0, const Regs& r_) {
+        const long long mb = w_begin + (long long)s0 * 32;
+        const unsigned smask = s0 < nst ? cmask : 0u;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int k0 = ks * 32;
-            bf16x8 tf[RT];
+        for (int q = 0; q < 8; ++q) {
+            const int row = lr + 4 * q;
+            const long long m = mb + row;
+            uint4 v = and4(r_.x[q].packed(), m < M ? smask : 0u);
+            if (DROP) v = drop8(v, (unsigned long long)m * dk.width + col, dk);
+            slab[row * CPR + (lc ^ (t3_h(row) << 1))] = v;
+        }
+        wave_sync();
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            bf16x8 xf;
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            if (!GATHER) {
+                // 16-lane group g reads the [4 rows x 16 cols] blocks at rows g*8+{0..3} and g*8+{4..7};
+                // lane q supplies the address of row (q>>2), cols (q&3)*4..+3 and receives column q.
+                const int rowA = g * 8 + (n >> 2), rowB = rowA + 4;
+                const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const char* base = reinterpret_cast<const char*>(slab);
+                const char* pa = base + ((rowA * CPR + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
+                const char* pb = base + ((rowB * CPR + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                xf = __builtin_bit_cast(bf16x8, both);
+            } else {
+                // validation path: explicit 2-byte gathers, lane (n, g) <- X[g*8+jj][ct*16+n]
+                const bf16_t* b16 = reinterpret_cast<const bf16_t*>(slab);
+                s16x8 both;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int row = g * 8 + jj;
+                    const int e = ct * 16 + n, c = e >> 3;
+                    both[jj] = (short)b16[(row * CPR + (c ^ (t3_h(row) << 1))) * 8 + (e & 7)];
+                }
+                xf = __builtin_bit_cast(bf16x8, both);
+            }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-                tf[rt] = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const uint4*>(TT + (long long)(rt * 16 + n) * Mp + mbase + k0 + g * 8));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ct = wave * 4 + j;
-                bf16x8 xf;
-                if (!GATHER) {
-                    // 16-lane group g reads the [4 rows x 16 cols] blocks at rows k0+g*8+{0..3} and +{4..7};
-                    // lane q supplies the address of row (q>>2), cols (q&3)*4..+3 and receives column q.
-                    const int rowA = k0 + g * 8 + (n >> 2), rowB = rowA + 4;
-                    const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
-                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                    const char* base = reinterpret_cast<const char*>(&xs[buf][0]);
-                    const char* pa = base + ((rowA * CPR + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
-                    const char* pb = base + ((rowB * CPR + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    xf = __builtin_bit_cast(bf16x8, both);
-                } else {
-                    // validation path: explicit 2-byte gathers, lane (n, g) <- X[k0+g*8+jj][ct*16+n]
-                    const bf16_t* b16 = reinterpret_cast<const bf16_t*>(&xs[buf][0]);
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    s16x8 both;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int row = k0 + g * 8 + jj;
-                        const int e = ct * 16 + n, c = e >> 3;
-                        both[jj] = (short)b16[(row * CPR + (c ^ (t3_h(row) << 1))) * 8 + (e & 7)];
-                    }
-                    xf = __builtin_bit_cast(bf16x8, both);
-                }
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    // D[i = rank idx][n = column] += sum_m TT[i][m] * X[m][col]
-                    acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[rt], xf, acc[rt][j], 0, 0, 0);
-            }
+                // D[i = rank idx][n = column] += sum_m T[m][i] * X[m][col]
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[rt]), xf,
+                                                                     acc[rt][ct], 0, 0, 0);
         }
-        if (s + 1 < nst) sstore(buf ^ 1);
-        __syncthreads();
+        wave_sync();
+    };
+
+    if (nst > 0) {
+        Regs rA, rB;               // distance-1 prefetch, two named register sets (see k_t1)
+        gload(0, rA);
+        for (int s = 0; s < nst2; s += 2) {
+            gload(s + 1, rB);
+            stage(s, rA);
+            gload(s + 2, rA);
+            stage(s + 1, rB);      // zeros if it is the padding step
+        }
     }
-    float* out = Gpart + (long long)rs * RP * N;
+    // fixed-order cross-wave sum ((w0 + w1) + w2) + w3 through LDS, one rank tile at a time; wave w then
+    // writes column tiles 2w and 2w+1 of the partial
+    float* red = reinterpret_cast<float*>(&xs[0][0]);     // [4 waves][8 col tiles][64 lanes][4] floats = 32 KB
+    float* out = Gpart + (long long)rg * RP * N;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = c0 + (wave * 4 + j) * 16 + n;
-            if (col < N) {
+        for (int ct = 0; ct < 8; ++ct)
+            *reinterpret_cast<f32x4*>(red + ((wave * 8 + ct) * 64 + lane) * 4) = acc[rt][ct];
+        __syncthreads();
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) out[(long long)(rt * 16 + g * 4 + jj) * N + col] = acc[rt][j][jj];
+        for (int jc = 0; jc < 2; ++jc) {
+            const int ct = wave * 2 + jc;
+            f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ((0 * 8 + ct) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 8 + ct) * 64 + lane) * 4);
+            const int ocol = c0 + ct * 16 + n;
+            if (ocol < N) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) out[(long long)(rt * 16 + g * 4 + jj) * N + ocol] = s4[jj];
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,19 +648,24 @@ inline int rpad(int rank) { return rank <= 16 ? 16 : 32; }
 inline size_t esize(int dtype) { return dtype == SAM3_LORA_F32 ? 4 : 2; }
 
 struct T3Plan {
-    int nchunks, NR, rows_per_wg;
+    int nchunks, NR, rows_per_wg, br;
 };
+bool env_flag(const char* name);
+
 T3Plan plan_t3(long long Mp, int N) {
+    // workgroup = 128 columns x a row group (4 waves x a quarter each, 32-row steps).  ~190 VGPRs allow
+    // 2 workgroups per CU: keep all of them co-resident (<= 512) so there is no tail round, and keep the
+    // number of row groups (= number of fp32 partials to reduce) small.
     T3Plan p;
-    p.nchunks = (N + 255) / 256;
-    const long long stages = Mp / 64;
-    long long nr = 512 / p.nchunks;  // 64 KB LDS -> 2 workgroups per CU: keep every workgroup co-resident (one round)
-    if (nr < 1) nr = 1;
-    if (nr > stages) nr = stages;
-    if (nr < 1) nr = 1;
-    const long long st_per = (stages + nr - 1) / nr;
-    p.rows_per_wg = (int)(st_per * 64);
-    p.NR = (int)((stages + st_per - 1) / st_per);
+    p.br = 32;
+    p.nchunks = (N + 127) / 128;
+    const long long units = (Mp + 127) / 128;          // 128-row units (4 waves x 32 rows)
+    long long nrg = 512 / p.nchunks;
+    if (nrg > units) nrg = units;
+    if (nrg < 1) nrg = 1;
+    const long long upg = (units + nrg - 1) / nrg;     // units per row group
+    p.rows_per_wg = (int)(upg * 128);
+    p.NR = (int)((units + upg - 1) / upg);
     return p;
 }
 
@@ -661,17 +767,10 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
                int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)(Mp / 64));
     ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
-    // 128-column chunks measured faster than 256 at K=4736 on MI355X (76.6 vs 99.0 us, profiles/r01b):
-    // the 80 KB-LDS variant halves co-residency.  Kept selectable for re-tuning.
-    const bool wide = env_flag("SAM3_LORA_T1_BK256");
-#define T1_LAUNCH(RTV, BKV) \
-    hipLaunchKernelGGL((k_t1<XT, RTV, BKV>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk)
-    if (RT == 1) {
-        if (wide) T1_LAUNCH(1, 256); else T1_LAUNCH(1, 128);
-    } else {
-        if (wide) T1_LAUNCH(2, 256); else T1_LAUNCH(2, 128);
-    }
-#undef T1_LAUNCH
+if (RT == 1)
+        hipLaunchKernelGGL((k_t1<XT, 1, 128>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+    else
+        hipLaunchKernelGGL((k_t1<XT, 2, 128>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
 }
 
 template <typename YT>
@@ -685,10 +784,14 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     tiles_per_wg = round_up(tiles_per_wg, 4);
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
-    if (RT == 1)
-        hipLaunchKernelGGL((k_t2<YT, 1>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk);
-    else
-        hipLaunchKernelGGL((k_t2<YT, 2>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk);
+#define T2_LAUNCH(RTV, DV) \
+    hipLaunchKernelGGL((k_t2<YT, RTV, DV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk)
+    if (RT == 1) {
+        if (dk.thr) T2_LAUNCH(1, true); else T2_LAUNCH(1, false);
+    } else {
+        if (dk.thr) T2_LAUNCH(2, true); else T2_LAUNCH(2, false);
+    }
+#undef T2_LAUNCH
 }
 
 template <typename XT>
@@ -698,7 +801,8 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
     const bool gather = env_flag("SAM3_LORA_T3_GATHER");
     ProfScope ps(stage_bit, N, st);
 #define T3_LAUNCH(RTV, GV) \
-    hipLaunchKernelGGL((k_t3<XT, RTV, GV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk)
+    do { if (dk.thr) hipLaunchKernelGGL((k_t3<XT, RTV, GV, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); \
+         else hipLaunchKernelGGL((k_t3<XT, RTV, GV, false>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); } while (0)
     if (RT == 1) {
         if (gather) T3_LAUNCH(1, true); else T3_LAUNCH(1, false);
     } else {
@@ -715,7 +819,7 @@ FwdWs fwd_ws(long long M, int in_f, int out_f, int rank) {
     const long long Mp = round_up(M, 64);
     FwdWs w;
     size_t off = 0;
-    w.w1 = off; off += al256((size_t)RP * in_f * 2);
+    w.w1 = off; off += al256((size_t)RP * round_up(in_f, 128) * 2);
     w.w2t = off; off += al256((size_t)out_f * RP * 2);
     w.t = off; off += al256((size_t)Mp * RP * 2);
     w.tt = off; off += al256((size_t)RP * Mp * 2);
@@ -734,9 +838,9 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
     w.pB = plan_t3(Mp, out_f);
     w.pA = plan_t3(Mp, in_f);
     size_t off = 0;
-    w.w1b = off; off += al256((size_t)RP * out_f * 2);
+    w.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * 2);
     w.w2tb = off; off += al256((size_t)in_f * RP * 2);
-    w.w1a = off; off += al256((size_t)RP * in_f * 2);
+    w.w1a = off; off += al256((size_t)RP * round_up(in_f, 128) * 2);
     w.gt = off; off += al256((size_t)Mp * RP * 2);
     w.gtt = off; off += al256((size_t)RP * Mp * 2);
     w.t = off; off += al256((size_t)Mp * RP * 2);
@@ -840,8 +944,8 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
     const Strides s = strides_of(layout, in_features, out_features, rank);
 
     // W1[RP][in] = A_c^T ; W2t[out][RP] = B_c^T
-    PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si};
-    PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr};
+    PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0};
+    PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0};
     if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(ja, jb, st);
     if (dtype == SAM3_LORA_BF16) {
         if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
@@ -888,13 +992,13 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     const Strides s = strides_of(layout, in_features, out_features, rank);
 
     // W1b[RP][out] = B_c ; W2tb[in][RP] = A_c
-    PackJob jb{(const float*)B, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so};
-    PackJob ja{(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr};
+    PackJob jb{(const float*)B, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so, 0};
+    PackJob ja{(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0};
     if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(jb, ja, st);
     const bool bf = dtype == SAM3_LORA_BF16;
     if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
-        PackJob j1{(const float*)A, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si};
-        PackJob j2{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+        PackJob j1{(const float*)A, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0};
+        PackJob j2{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
         launch_pack(j1, j2, st);
         bf16_t* TTs = (bf16_t*)(ws + w.tt);
         if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk);
