@@ -652,7 +652,7 @@ struct T3Plan {
 };
 bool env_flag(const char* name);
 
-T3Plan plan_t3(long long Mp, int N) {
+T3Plan plan_t3(long long Mp, int N, int RT) {
     // workgroup = 128 columns x a row group (4 waves x a quarter each, 32-row steps).  ~190 VGPRs allow
     // 2 workgroups per CU: keep all of them co-resident (<= 512) so there is no tail round, and keep the
     // number of row groups (= number of fp32 partials to reduce) small.
@@ -660,7 +660,7 @@ T3Plan plan_t3(long long Mp, int N) {
     p.br = 32;
     p.nchunks = (N + 127) / 128;
     const long long units = (Mp + 127) / 128;          // 128-row units (4 waves x 32 rows)
-    long long nrg = 512 / p.nchunks;
+    long long nrg = (RT == 2 ? 256 : 512) / p.nchunks;   // r > 16: ~230 VGPRs, one workgroup per CU
     if (nrg > units) nrg = units;
     if (nrg < 1) nrg = 1;
     const long long upg = (units + nrg - 1) / nrg;     // units per row group
@@ -835,8 +835,8 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
     const int RP = rpad(rank);
     const long long Mp = round_up(M, 64);
     BwdWs w;
-    w.pB = plan_t3(Mp, out_f);
-    w.pA = plan_t3(Mp, in_f);
+    w.pB = plan_t3(Mp, out_f, RP / 16);
+    w.pA = plan_t3(Mp, in_f, RP / 16);
     size_t off = 0;
     w.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * 2);
     w.w2tb = off; off += al256((size_t)in_f * RP * 2);
