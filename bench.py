@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-trunk", action="store_true", help="skip the whole-ViT-trunk training-step measurement")
+    ap.add_argument("--trunk-steps", type=int, default=3)
     return ap.parse_args()
 
 
@@ -219,6 +221,73 @@ def op_table(w, iters):
     return ops
 
 
+def trunk_step_bench(dev, batch, rank, steps, world):
+    """The adapters in their real host: the SAM3 ViT-Det trunk (sam3_lora_amd/vit.py, 32 blocks, 1008^2 input,
+    random init, frozen weights bf16) with root-API LoRA on fc1/fc2, one training step = forward with per-block
+    activation checkpointing + backward + flat-buffer gradient exchange + AdamW on A/B.  Frozen GEMMs, SDPA,
+    LayerNorm run on PyTorch-ROCm; the adapter arithmetic on the HIP path.  (Neck, text tower, DETR, losses are
+    not part of this measurement -- they are not built yet.)"""
+    import contextlib
+    import io
+    import lora_layers as L
+    from sam3_lora_amd import vit as V
+    from sam3_lora_amd.ddp import LoRAGradReducer
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = V.sam3_vit()
+    with contextlib.redirect_stdout(io.StringIO()):
+        L.apply_lora_to_model(model, L.LoRAConfig(rank=rank, alpha=2 * rank, dropout=0.0, target_modules=["fc1", "fc2"],
+                                                  apply_to_text_encoder=False, apply_to_detr_encoder=False,
+                                                  apply_to_detr_decoder=False))
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, L.LoRALayer):
+                m.lora_B.normal_(0, 0.02)
+    V.to_training_layout(model)
+    model.train()
+    params = L.get_lora_parameters(model)
+    red = LoRAGradReducer(params, bucket_bytes=8 << 20)
+    opt = torch.optim.AdamW(params, lr=5e-5, weight_decay=0.01)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    img = (torch.rand(batch, 3, 1008, 1008, device=dev, generator=g) * 2 - 1).bfloat16()
+    tgt = torch.randn(batch, 1024, 72, 72, device=dev, generator=g).bfloat16()
+
+    def step():
+        red.zero_grad()
+        feat = model(img)[0]
+        loss = (feat.float() * tgt.float()).mean()
+        loss.backward()
+        red.finish()
+        opt.step()
+        return loss
+
+    step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    n_lora = sum(p.numel() for p in params)
+    out = dict(images_per_s=round(world * batch * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 2), steps=steps,
+               loss_finite=bool(torch.isfinite(loss).item()), trainable_parameters=n_lora,
+               peak_mem_gb=round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+               workload=f"SAM3 ViT-Det trunk only (32 blocks, 1024-d, 72x72 tokens), batch {batch}/GPU @ 1008^2, bf16 frozen "
+                        f"weights, LoRA r={rank} on 64 MLP Linears, per-block activation checkpointing, synthetic feature loss, "
+                        f"AdamW on A/B, flat-buffer all-reduce")
+    del model, opt, red, img, tgt
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(rank, seconds_budget=25.0):
     """numpy oracle (kind 'port') on a bounded sample: 1 image through the same 64-Linear
     fwd + recompute + bwd schedule, fp32 (the reference CLI's dtype)."""
@@ -332,6 +401,12 @@ def main():
         out["ops"] = ops
     if world > 1:
         dist.barrier()
+    if not args.no_trunk:
+        del w
+        torch.cuda.empty_cache()
+        tr = trunk_step_bench(dev, args.batch, args.rank, args.trunk_steps, world)
+        if rank == 0:
+            out["trunk_step"] = tr
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.rank)
     if rank == 0:

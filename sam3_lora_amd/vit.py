@@ -1,0 +1,265 @@
+"""
+ViT-Det trunk of the SAM3 image encoder -- the module that HOSTS the 64 adapted Linears
+(SURVEY.md a11-a13).  Written from scratch for PyTorch-ROCm; same mathematics, module names,
+parameter/buffer names and shapes as the reference (``sam3/model/vitdet.py``: PatchEmbed :299-336,
+Attention :339-515, Block :518-613, ViT :616-859, window_partition :93-139, get_abs_pos :175-236,
+2-D RoPE :40-90; timm ``Mlp``/``DropPath``), so a reference state dict loads with ``strict=True`` and
+the reference injectors' module names (``...trunk.blocks.N.mlp.fc1``) are reproduced.
+
+Differences in HOW (MI355X-first), none in WHAT:
+  * RoPE is applied with real cos/sin tables in fp32 (no complex views), then cast back;
+  * window (un)partition is one reshape+permute each (the SAM3 grid 72 = 3 x 24 never pads);
+  * the tiled absolute position embedding is built once and cached per grid size;
+  * frozen weights are meant to live in bf16, LoRA masters in fp32 (``to_training_layout``);
+  * attention is ``F.scaled_dot_product_attention`` (PyTorch-ROCm's fused kernels), the MLP's fc1/fc2
+    become ``LoRALinear`` after injection and run the hand-written HIP adapter path.
+
+Only the configuration surface the SAM3 builder uses (``sam3/model_builder.py:69-96``) is supported:
+no cls token retention, no relative-position bias, no LayerScale.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+__all__ = ["ViT", "Block", "Attention", "Mlp", "PatchEmbed", "DropPath", "sam3_vit", "to_training_layout"]
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm semantics: keep mask ~ Bernoulli(1-p), scaled by 1/(1-p))."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU -> fc2 (timm ``Mlp`` with the defaults the reference uses: no norm, drop=(p, 0))."""
+
+    def __init__(self, in_features: int, hidden_features: int, drop: float = 0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.drop1 = nn.Dropout(drop)
+        self.norm = nn.Identity()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+        self.drop2 = nn.Dropout(0.0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size: int, in_chans: int, embed_dim: int, bias: bool):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.proj(x).permute(0, 2, 3, 1)          # B C H W -> B H W C
+
+
+def axial_rope_table(head_dim: int, size_x: int, size_y: int, theta: float, scale_pos: float) -> torch.Tensor:
+    """complex64 [size_x*size_y, head_dim/2]: first half rotates with x, second half with y
+    (reference ``compute_axial_cis``, vitdet.py:40-57)."""
+    idx = torch.arange(0, head_dim, 4, device="cpu")[: head_dim // 4].float()
+    freqs = 1.0 / (theta ** (idx / head_dim))
+    t = torch.arange(size_x * size_y, dtype=torch.float32, device="cpu")
+    tx = (t % size_x) * scale_pos
+    ty = torch.div(t, size_x, rounding_mode="floor") * scale_pos
+    ang = torch.cat([torch.outer(tx, freqs), torch.outer(ty, freqs)], dim=-1)
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+class Attention(nn.Module):
+    """Fused-qkv multi-head attention with 2-D axial RoPE over a (window or global) token grid."""
+
+    def __init__(self, dim: int, num_heads: int, qkv_bias: bool, input_size: Tuple[int, int],
+                 rope_theta: float = 10000.0, rope_pt_size: Optional[Tuple[int, int]] = None,
+                 rope_interp: bool = False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        pt = rope_pt_size if rope_pt_size is not None else input_size
+        scale_pos = pt[0] / input_size[0] if rope_interp else 1.0
+        # same buffer name/dtype as the reference so state dicts are interchangeable
+        self.register_buffer("freqs_cis", axial_rope_table(self.head_dim, input_size[0], input_size[1],
+                                                           rope_theta, scale_pos))
+        self._cs = None   # (cos, sin) fp32 [L, head_dim/2], derived lazily on the right device
+
+    def _cos_sin(self, device):
+        if self._cs is None or self._cs[0].device != device:
+            f = self.freqs_cis.to(device)
+            self._cs = (f.real.float().contiguous(), f.imag.float().contiguous())
+        return self._cs
+
+    def _rope(self, t: torch.Tensor) -> torch.Tensor:
+        """t [B, heads, L, head_dim]; adjacent pairs (2i, 2i+1) are one complex number."""
+        cos, sin = self._cos_sin(t.device)
+        tf = t.float().unflatten(-1, (-1, 2))
+        a, b = tf[..., 0], tf[..., 1]
+        out = torch.stack((a * cos - b * sin, a * sin + b * cos), dim=-1).flatten(-2)
+        return out.to(t.dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, H, W, C = x.shape
+        L = H * W
+        qkv = self.qkv(x).reshape(B, L, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.unbind(0)
+        q, k = self._rope(q), self._rope(k)
+        o = F.scaled_dot_product_attention(q, k, v)
+        o = o.permute(0, 2, 1, 3).reshape(B, H, W, C)
+        return self.proj(o)
+
+
+def window_partition(x: torch.Tensor, ws: int) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    B, H, W, C = x.shape
+    ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+    if ph or pw:
+        x = F.pad(x, (0, 0, 0, pw, 0, ph))
+    Hp, Wp = H + ph, W + pw
+    x = x.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, ws, ws, C), (Hp, Wp)
+
+
+def window_unpartition(win: torch.Tensor, ws: int, pad_hw: Tuple[int, int], hw: Tuple[int, int]) -> torch.Tensor:
+    Hp, Wp = pad_hw
+    H, W = hw
+    B = win.shape[0] // ((Hp // ws) * (Wp // ws))
+    x = win.reshape(B, Hp // ws, Wp // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, -1)
+    return x[:, :H, :W, :] if (Hp > H or Wp > W) else x
+
+
+class Block(nn.Module):
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float, qkv_bias: bool, drop_path: float,
+                 window_size: int, input_size: Tuple[int, int], rope_pt_size: Tuple[int, int],
+                 rope_interp: bool, dropout: float = 0.0, eps: float = 1e-5):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads, qkv_bias,
+                              input_size=input_size if window_size == 0 else (window_size, window_size),
+                              rope_pt_size=rope_pt_size, rope_interp=rope_interp)
+        self.ls1 = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), drop=dropout)
+        self.ls2 = nn.Identity()
+        self.dropout = nn.Dropout(dropout)
+        self.window_size = window_size
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = self.norm1(x)
+        if self.window_size > 0:
+            H, W = h.shape[1], h.shape[2]
+            h, pad_hw = window_partition(h, self.window_size)
+        h = self.attn(h)
+        if self.window_size > 0:
+            h = window_unpartition(h, self.window_size, pad_hw, (H, W))
+        x = x + self.dropout(self.drop_path(h))
+        return x + self.dropout(self.drop_path(self.mlp(self.norm2(x))))
+
+
+class ViT(nn.Module):
+    """SAM3 ViT-Det trunk.  ``forward(images[B,3,S,S]) -> [features[B, C, S/p, S/p]]``."""
+
+    def __init__(self, img_size: int = 1008, pretrain_img_size: int = 336, patch_size: int = 14,
+                 in_chans: int = 3, embed_dim: int = 1024, depth: int = 32, num_heads: int = 16,
+                 mlp_ratio: float = 4.625, qkv_bias: bool = True, drop_path_rate: float = 0.1,
+                 window_size: int = 24, global_att_blocks: Sequence[int] = (7, 15, 23, 31),
+                 use_interp_rope: bool = True, pretrain_use_cls_token: bool = True, tile_abs_pos: bool = True,
+                 ln_pre: bool = True, ln_post: bool = False, bias_patch_embed: bool = False,
+                 use_act_checkpoint: bool = True, dropout: float = 0.0):
+        super().__init__()
+        self.pretrain_use_cls_token = pretrain_use_cls_token
+        self.tile_abs_pos = tile_abs_pos
+        self.full_attn_ids = list(global_att_blocks)
+        self.use_act_checkpoint = use_act_checkpoint
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, bias_patch_embed)
+        n_pos = (pretrain_img_size // patch_size) ** 2 + (1 if pretrain_use_cls_token else 0)
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_pos, embed_dim))
+        grid = img_size // patch_size
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth, device="cpu")]
+        self.blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias, dpr[i],
+                  window_size=0 if i in self.full_attn_ids else window_size,
+                  input_size=(grid, grid), rope_pt_size=(window_size, window_size),
+                  rope_interp=use_interp_rope, dropout=dropout)
+            for i in range(depth)])
+        self.ln_pre = nn.LayerNorm(embed_dim, eps=1e-5) if ln_pre else nn.Identity()
+        self.ln_post = nn.LayerNorm(embed_dim, eps=1e-5) if ln_post else nn.Identity()
+        self.channel_list = [embed_dim]
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        self.apply(self._init_weights)
+        self._pos_cache = {}
+
+    @staticmethod
+    def _init_weights(m: nn.Module) -> None:
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def abs_pos(self, h: int, w: int) -> torch.Tensor:
+        """[1, h, w, C]: the pretrain grid (cls dropped) tiled -- or bicubically resized -- to (h, w)."""
+        pe = self.pos_embed[:, 1:] if self.pretrain_use_cls_token else self.pos_embed
+        size = int(math.sqrt(pe.shape[1]))
+        if size == h and size == w:
+            return pe.reshape(1, h, w, -1)
+        g = pe.reshape(1, size, size, -1).permute(0, 3, 1, 2)
+        if self.tile_abs_pos:
+            g = g.tile([1, 1, h // size + 1, w // size + 1])[:, :, :h, :w]
+        else:
+            g = F.interpolate(g, size=(h, w), mode="bicubic", align_corners=False)
+        return g.permute(0, 2, 3, 1)
+
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        x = self.patch_embed(x)
+        h, w = x.shape[1], x.shape[2]
+        x = x + self.abs_pos(h, w).to(x.dtype)
+        x = self.ln_pre(x)
+        outs = []
+        for i, blk in enumerate(self.blocks):
+            if self.use_act_checkpoint and self.training:
+                x = checkpoint(blk, x, use_reentrant=False)
+            else:
+                x = blk(x)
+            if i == self.full_attn_ids[-1]:
+                x = self.ln_post(x)
+                outs.append(x.permute(0, 3, 1, 2))
+        return outs
+
+
+def sam3_vit(**overrides) -> ViT:
+    """The one SAM3 image-encoder trunk (``sam3/model_builder.py:69-96``): 1008/14 = 72x72 tokens,
+    1024-d, 32 blocks, 16 heads, MLP 4736, window 24, global blocks 7/15/23/31, interpolated RoPE."""
+    return ViT(**overrides)
+
+
+def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloat16) -> nn.Module:
+    """MI355X training layout: every frozen tensor in bf16, trainable (LoRA) tensors stay fp32."""
+    for p in model.parameters():
+        if not p.requires_grad and p.dtype.is_floating_point:
+            p.data = p.data.to(frozen_dtype)
+    for name, b in model.named_buffers():
+        if b.dtype.is_floating_point and not b.dtype.is_complex:
+            b.data = b.data.to(frozen_dtype)
+    return model

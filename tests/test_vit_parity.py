@@ -1,0 +1,114 @@
+"""ViT-Det trunk (sam3_lora_amd/vit.py) against the reference's own classes run at a tiny config
+(tests/golden/vit_tiny.npz, made by tests/golden/make_vit_golden.py).  CPU test: the frozen trunk alone.
+GPU test: the trunk with the HIP LoRA path injected by our root injector, forward + backward through
+activation checkpointing, against the reference's outputs and A/B gradients."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sam3_lora_amd import vit as V
+
+TINY = dict(img_size=112, pretrain_img_size=56, patch_size=14, embed_dim=64, depth=4, num_heads=2,
+            mlp_ratio=4.625, drop_path_rate=0.0, window_size=4, global_att_blocks=(1, 3))
+
+
+def _load(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vit_tiny.npz"))
+    sd = {}
+    for k in g.files:
+        if k.startswith("sd/"):
+            name = k[3:]
+            if name.endswith(".re"):
+                sd[name[:-3]] = torch.complex(torch.from_numpy(g[k]), torch.from_numpy(g["sd/" + name[:-3] + ".im"]))
+            elif not name.endswith(".im"):
+                sd[name] = torch.from_numpy(g[k])
+    return g, sd
+
+
+def test_state_dict_keys_and_forward_match_reference(golden_dir):
+    g, sd = _load(golden_dir)
+    m = V.ViT(**TINY)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    # our RoPE tables equal the reference's buffers before loading anything
+    for i, blk in enumerate(m.blocks):
+        ref = sd[f"blocks.{i}.attn.freqs_cis"]
+        assert torch.allclose(torch.view_as_real(blk.attn.freqs_cis), torch.view_as_real(ref), atol=1e-6), i
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    with torch.no_grad():
+        feat = m(torch.from_numpy(g["img"]))[0]
+    assert feat.shape == g["feat"].shape
+    err = (feat.numpy() - g["feat"]).__abs__().max() / np.abs(g["feat"]).max()
+    assert err < 2e-5, err
+
+
+def test_sam3_trunk_shape_and_linear_names(golden_dir):
+    """Full-size trunk on the meta device: the Linear names/shapes the reference injectors see."""
+    import json
+    man = json.load(open(os.path.join(golden_dir, "sam3_linears.json")))
+    pref = "backbone.vision_backbone.trunk."
+    want = {n[len(pref):]: (i, o, b) for n, i, o, b in man["linears"] if n.startswith(pref)}
+    with torch.device("meta"):
+        m = V.sam3_vit()
+    got = {n: (l.in_features, l.out_features, l.bias is not None) for n, l in m.named_modules()
+           if isinstance(l, torch.nn.Linear)}
+    assert got == want
+    assert sum(p.numel() for p in m.parameters()) == 32 * (1024 * 3072 + 3072 + 1024 * 1024 + 1024 + 2 * 2048 +
+                                                          1024 * 4736 + 4736 + 4736 * 1024 + 1024) \
+        + 3 * 14 * 14 * 1024 + 577 * 1024 + 2 * 1024
+
+
+def test_window_partition_roundtrip_and_droppath():
+    x = torch.randn(2, 10, 7, 5)
+    w, pad = V.window_partition(x, 4)
+    assert w.shape == (2 * 3 * 2, 4, 4, 5)
+    assert torch.equal(V.window_unpartition(w, 4, pad, (10, 7)), x)
+    dp = V.DropPath(0.5)
+    dp.train()
+    torch.manual_seed(0)
+    y = dp(torch.ones(64, 3, 3))
+    assert set(y.unique().tolist()) <= {0.0, 2.0} and 0 < (y == 0).float().mean() < 1
+    dp.eval()
+    assert torch.equal(dp(torch.ones(4, 2)), torch.ones(4, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_trunk_with_hip_lora_matches_reference(golden_dir, dtype):
+    import lora_layers as L
+    g, sd = _load(golden_dir)
+    m = V.ViT(**TINY)
+    m.load_state_dict(sd, strict=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        L.apply_lora_to_model(m, L.LoRAConfig(rank=4, alpha=8, dropout=0.0, target_modules=["fc1", "fc2"]))
+    names = [n for n, mod in m.named_modules() if isinstance(mod, L.LoRALinear)]
+    assert names == list(g["lora_module_names"])
+    with torch.no_grad():
+        for n, mod in m.named_modules():
+            if isinstance(mod, L.LoRALayer):
+                mod.lora_A.copy_(torch.from_numpy(g[f"lora/{n}.lora_A"]))
+                mod.lora_B.copy_(torch.from_numpy(g[f"lora/{n}.lora_B"]))
+    m.to("cuda:0")
+    td = torch.float32
+    if dtype == "bf16":
+        V.to_training_layout(m)
+        td = torch.bfloat16
+    m.train()
+    x = torch.from_numpy(g["img"]).to("cuda:0", td).requires_grad_(True)
+    feat = m(x)[0]
+    (feat.float() * torch.from_numpy(g["gout"]).to("cuda:0")).sum().backward()
+    tol = 2e-3 if dtype == "f32" else 4e-2          # bf16: 4 blocks of bf16 GEMMs/LN/SDPA vs fp32 reference
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(feat.detach().float().cpu().numpy(), g["feat_lora"]) < tol
+    assert rel(x.grad.float().cpu().numpy(), g["gimg"]) < tol
+    for n, mod in m.named_modules():
+        if isinstance(mod, L.LoRALayer):
+            assert mod.lora_A.grad.dtype == torch.float32
+            assert rel(mod.lora_A.grad.cpu().numpy(), g[f"gA/{n}"]) < 10 * tol, n
+            assert rel(mod.lora_B.grad.cpu().numpy(), g[f"gB/{n}"]) < 10 * tol, n

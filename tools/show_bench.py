@@ -9,5 +9,8 @@ for k in d.get("kernels", []):
     print(f"  {k['kernel']:9s} dim={k['dim']:5d} n={k['launches']:4d} avg={k['avg_us']:8.2f} med={k['median_us']:8.2f} min={k['min_us']:8.2f} tot={k['total_us']:9.1f} {k['GBps']:7.1f} GB/s")
 for k in d.get("ops", []):
     print(f"  {k['op']:34s} {k['avg_us']:8.2f} us {k['GBps']:7.1f} GB/s frac {k['frac_of_peak']}")
+if "trunk_step" in d:
+    t = d["trunk_step"]
+    print("trunk_step", t["images_per_s"], "img/s", t["ms_per_step"], "ms/step, peak", t["peak_mem_gb"], "GB, finite", t["loss_finite"])
 if "cpu_baseline" in d:
     print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
