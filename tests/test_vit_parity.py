@@ -103,12 +103,15 @@ def test_trunk_with_hip_lora_matches_reference(golden_dir, dtype):
     x = torch.from_numpy(g["img"]).to("cuda:0", td).requires_grad_(True)
     feat = m(x)[0]
     (feat.float() * torch.from_numpy(g["gout"]).to("cuda:0")).sum().backward()
-    tol = 2e-3 if dtype == "f32" else 4e-2          # bf16: 4 blocks of bf16 GEMMs/LN/SDPA vs fp32 reference
+    # f32: the frozen trunk is exact fp32, the adapter still contracts bf16 operands (2^-9 per rounding);
+    # bf16: 4 blocks of bf16 GEMMs / LayerNorm / SDPA against the fp32 reference
+    tol = 1e-2 if dtype == "f32" else 4e-2
     rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
-    assert rel(feat.detach().float().cpu().numpy(), g["feat_lora"]) < tol
-    assert rel(x.grad.float().cpu().numpy(), g["gimg"]) < tol
+    e_feat = rel(feat.detach().float().cpu().numpy(), g["feat_lora"])
+    e_gimg = rel(x.grad.float().cpu().numpy(), g["gimg"])
+    assert e_feat < tol and e_gimg < tol, (e_feat, e_gimg)
     for n, mod in m.named_modules():
         if isinstance(mod, L.LoRALayer):
             assert mod.lora_A.grad.dtype == torch.float32
-            assert rel(mod.lora_A.grad.cpu().numpy(), g[f"gA/{n}"]) < 10 * tol, n
-            assert rel(mod.lora_B.grad.cpu().numpy(), g[f"gB/{n}"]) < 10 * tol, n
+            eA, eB = rel(mod.lora_A.grad.cpu().numpy(), g[f"gA/{n}"]), rel(mod.lora_B.grad.cpu().numpy(), g[f"gB/{n}"])
+            assert eA < 5 * tol and eB < 5 * tol, (n, eA, eB)
