@@ -69,6 +69,11 @@ def _declare(lib):
     lib.sam3_lora_prof_start.argtypes = [ctypes.c_uint, c_int]
     lib.sam3_lora_prof_stop.restype = c_int
     lib.sam3_lora_prof_stop.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
+    for f in (lib.sam3_vit_qkv_rope_fwd, lib.sam3_vit_qkv_rope_bwd):
+        f.restype = c_int
+    lib.sam3_vit_qkv_rope_fwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_int, c_void_p]
+    lib.sam3_vit_qkv_rope_bwd.argtypes = [c_void_p] * 3 + [c_int64] * 3 + [c_void_p] * 3 + [c_int64, c_int, c_int, c_int,
+                                                                                      c_int, c_void_p]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]
@@ -92,7 +97,7 @@ def load(path: str | None = None):
             lib = ctypes.CDLL(p)
         except OSError as e:  # missing libamdhip64 etc.
             raise LoRAKernelError(f"sam3_lora_amd: cannot load {p}: {e}") from e
-        missing = [s for s in EXPORTS if not hasattr(lib, s)]
+        missing = [s for s in EXPORTS + ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd") if not hasattr(lib, s)]
         if missing:
             raise LoRAKernelError(f"sam3_lora_amd: {p} lacks symbols {missing}")
         _declare(lib)

@@ -8,6 +8,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 SRC = os.path.join(PKG_DIR, "csrc", "lora_kernels.hip")
+SRCS = [SRC, os.path.join(PKG_DIR, "csrc", "vit_kernels.hip")]
 INCLUDE = os.path.join(REPO_DIR, "include")
 LIB_NAME = "libsam3_lora_amd.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
@@ -24,16 +25,16 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [SRC, os.path.join(INCLUDE, "sam3_lora_amd.h")]
+    deps = SRCS + [os.path.join(INCLUDE, "sam3_lora_amd.h"), os.path.join(INCLUDE, "sam3_vit_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/lora_kernels.hip -> sam3_lora_amd/libsam3_lora_amd.so for gfx950."""
+    """Compile csrc/*.hip -> sam3_lora_amd/libsam3_lora_amd.so for gfx950."""
     if not force and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", INCLUDE, SRC, "-o", LIB_PATH + ".tmp"]
+           "-I", INCLUDE] + SRCS + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,154 @@
+// sam3_lora_amd -- host-model helper kernels for the ViT trunk that hosts the adapters (gfx950).
+//
+// qkv split + 2-D axial RoPE in ONE pass (reference: sam3/model/vitdet.py:68-90 apply_rotary_enc via complex
+// fp32 views, :466-471 the qkv reshape/permute).  On PyTorch-ROCm the unfused form costs ~10 elementwise
+// passes over q and k per attention call (fp32 up-casts, complex multiply, stack/flatten, permute copies) and
+// was 35 % of the trunk's training step; here q, k are rotated and q, k, v are split out of the fused qkv
+// activation with one read and one write, 16 bytes per lane both ways.
+//
+//   qkv   [B, L, 3, H, D]  (the qkv Linear's output, row = token)       bf16 or fp32
+//   q,k,v [B, L, H, D]     contiguous (callers hand .transpose(1, 2) views to SDPA -- no permute copy)
+//   cos/sin [L, D/2] fp32  (adjacent element pairs (2i, 2i+1) are one complex number)
+//
+// backward: gqkv[b,l,0,h,:] = R(-theta) gq[b,l,h,:], same for k, copy for v; gq/gk/gv may be arbitrary
+// [B, H, L, D]-shaped strided views with unit last stride (whatever SDPA's backward returns).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+
+namespace {
+
+__device__ __forceinline__ unsigned vpack2(float a, float b) {
+    bf16x2v v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float vlo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float vhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+struct F8 {
+    float v[8];
+};
+__device__ __forceinline__ F8 ld8(const bf16_t* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    return F8{{vlo(u.x), vhi(u.x), vlo(u.y), vhi(u.y), vlo(u.z), vhi(u.z), vlo(u.w), vhi(u.w)}};
+}
+__device__ __forceinline__ F8 ld8(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    return F8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void st8(bf16_t* p, const F8& f) {
+    *reinterpret_cast<uint4*>(p) =
+        make_uint4(vpack2(f.v[0], f.v[1]), vpack2(f.v[2], f.v[3]), vpack2(f.v[4], f.v[5]), vpack2(f.v[6], f.v[7]));
+}
+__device__ __forceinline__ void st8(float* p, const F8& f) {
+    *reinterpret_cast<float4*>(p) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+// rotate the 4 complex pairs of f by +theta (sign = +1) or -theta (sign = -1)
+__device__ __forceinline__ F8 rot(const F8& f, const float4 c, const float4 s, float sign) {
+    const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x * sign, s.y * sign, s.z * sign, s.w * sign};
+    F8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = f.v[2 * i], b = f.v[2 * i + 1];
+        o.v[2 * i] = a * cc[i] - b * ss[i];
+        o.v[2 * i + 1] = a * ss[i] + b * cc[i];
+    }
+    return o;
+}
+
+// one thread = 8 consecutive elements of one (token, which in {q,k,v}, head); consecutive threads walk the
+// 3*H*D row of a token, so both the read and the three writes are fully coalesced
+template <typename T>
+__global__ __launch_bounds__(256) void k_qkv_rope_fwd(const T* __restrict__ qkv, const float* __restrict__ cs,
+                                                      const float* __restrict__ sn, T* __restrict__ q,
+                                                      T* __restrict__ k, T* __restrict__ v, long long ntok, int L,
+                                                      int H, int D) {
+    const int cpr = 3 * H * D / 8;   // 16-byte chunks per token row
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ntok * cpr) return;
+    const long long tok = idx / cpr;
+    const int c = (int)(idx % cpr);
+    const int hd8 = H * D / 8;
+    const int which = c / hd8, ch = c % hd8;     // chunk inside the [H, D] slab
+    const int d0 = (ch * 8) % D;                 // first element index inside the head
+    F8 f = ld8(qkv + tok * (3LL * H * D) + (long long)c * 8);
+    T* dst = (which == 0 ? q : which == 1 ? k : v) + tok * ((long long)H * D) + (long long)ch * 8;
+    if (which < 2) {
+        const int l = (int)(tok % L);
+        const float4 cc = *reinterpret_cast<const float4*>(cs + (long long)l * (D / 2) + d0 / 2);
+        const float4 ss = *reinterpret_cast<const float4*>(sn + (long long)l * (D / 2) + d0 / 2);
+        f = rot(f, cc, ss, 1.f);
+    }
+    st8(dst, f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_qkv_rope_bwd(const T* __restrict__ gq, const T* __restrict__ gk,
+                                                      const T* __restrict__ gv, long long sb, long long sh,
+                                                      long long sl, const float* __restrict__ cs,
+                                                      const float* __restrict__ sn, T* __restrict__ gqkv,
+                                                      long long ntok, int L, int H, int D) {
+    const int cpr = 3 * H * D / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ntok * cpr) return;
+    const long long tok = idx / cpr;
+    const int c = (int)(idx % cpr);
+    const int hd8 = H * D / 8;
+    const int which = c / hd8, ch = c % hd8;
+    const int h = (ch * 8) / D, d0 = (ch * 8) % D;
+    const long long b = tok / L;
+    const int l = (int)(tok % L);
+    const T* src = (which == 0 ? gq : which == 1 ? gk : gv) + b * sb + (long long)h * sh + (long long)l * sl + d0;
+    F8 f = ld8(src);
+    if (which < 2) {
+        const float4 cc = *reinterpret_cast<const float4*>(cs + (long long)l * (D / 2) + d0 / 2);
+        const float4 ss = *reinterpret_cast<const float4*>(sn + (long long)l * (D / 2) + d0 / 2);
+        f = rot(f, cc, ss, -1.f);
+    }
+    st8(gqkv + tok * (3LL * H * D) + (long long)c * 8, f);
+}
+
+}  // namespace
+
+extern "C" {
+
+// returns 0 on success, -22 on bad arguments, -5 on a launch error (same codes as sam3_lora_amd.h)
+int sam3_vit_qkv_rope_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* q, void* k, void* v,
+                          int64_t B, int L, int H, int D, int dtype, void* stream) {
+    if (!qkv || !cos_t || !sin_t || !q || !k || !v || B <= 0 || L <= 0 || H <= 0 || D <= 0 || (D % 8)) return -22;
+    const long long ntok = B * L, total = ntok * (3LL * H * D / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_qkv_rope_fwd<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, cos_t,
+                           sin_t, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, ntok, L, H, D);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(k_qkv_rope_fwd<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, cos_t,
+                           sin_t, (float*)q, (float*)k, (float*)v, ntok, L, H, D);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// gq/gk/gv: [B, H, L, D]-shaped views with element strides (sb, sh, sl, 1), identical for the three
+int sam3_vit_qkv_rope_bwd(const void* gq, const void* gk, const void* gv, int64_t sb, int64_t sh, int64_t sl,
+                          const float* cos_t, const float* sin_t, void* gqkv, int64_t B, int L, int H, int D,
+                          int dtype, void* stream) {
+    if (!gq || !gk || !gv || !cos_t || !sin_t || !gqkv || B <= 0 || L <= 0 || H <= 0 || D <= 0 || (D % 8)) return -22;
+    const long long ntok = B * L, total = ntok * (3LL * H * D / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_qkv_rope_bwd<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gq,
+                           (const bf16_t*)gk, (const bf16_t*)gv, sb, sh, sl, cos_t, sin_t, (bf16_t*)gqkv, ntok, L, H, D);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(k_qkv_rope_bwd<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)gq,
+                           (const float*)gk, (const float*)gv, sb, sh, sl, cos_t, sin_t, (float*)gqkv, ntok, L, H, D);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // extern "C"

@@ -120,12 +120,65 @@ class Attention(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, H, W, C = x.shape
         L = H * W
-        qkv = self.qkv(x).reshape(B, L, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv.unbind(0)
-        q, k = self._rope(q), self._rope(k)
-        o = F.scaled_dot_product_attention(q, k, v)
-        o = o.permute(0, 2, 1, 3).reshape(B, H, W, C)
+        qkv = self.qkv(x)
+        if qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float32):
+            # one HIP pass: split q/k/v and rotate q, k; outputs are [B, L, heads, d] so SDPA gets
+            # transposed VIEWS (no permute copies) and its output reshapes to [B, H, W, C] for free
+            cos, sin = self._cos_sin(qkv.device)
+            q, k, v = _QKVRope.apply(qkv.reshape(B * L, 3 * C), cos, sin, B, L, self.num_heads, self.head_dim)
+            o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+            o = o.transpose(1, 2).reshape(B, H, W, C)
+        else:   # plain PyTorch formulation (CPU / other dtypes); same mathematics
+            qkv = qkv.reshape(B, L, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv.unbind(0)
+            q, k = self._rope(q), self._rope(k)
+            o = F.scaled_dot_product_attention(q, k, v)
+            o = o.permute(0, 2, 1, 3).reshape(B, H, W, C)
         return self.proj(o)
+
+
+class _QKVRope(torch.autograd.Function):
+    """qkv[B*L, 3*H*D] -> q, k (RoPE-rotated), v as [B, L, H, D]; C-ABI ``sam3_vit_qkv_rope_fwd/bwd``."""
+
+    @staticmethod
+    def forward(ctx, qkv2, cos, sin, B, L, H, D):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        qkv2 = qkv2.contiguous()
+        q, k, v = (torch.empty(B, L, H, D, device=qkv2.device, dtype=qkv2.dtype) for _ in range(3))
+        dt = 0 if qkv2.dtype == torch.bfloat16 else 1
+        rc = lib.sam3_vit_qkv_rope_fwd(qkv2.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(), k.data_ptr(),
+                                       v.data_ptr(), B, L, H, D, dt,
+                                       ctypes.c_void_p(torch.cuda.current_stream(qkv2.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_vit_qkv_rope_fwd failed ({rc})")
+        ctx.save_for_backward(cos, sin)
+        ctx.dims = (B, L, H, D, dt)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        cos, sin = ctx.saved_tensors
+        B, L, H, D, dt = ctx.dims
+        # grads arrive [B, L, H, D]-shaped; view them as [B, H, L, D] with explicit strides for the kernel
+        def canon(g):
+            g = g if g.stride(-1) == 1 else g.contiguous()
+            return g
+        gq, gk, gv = canon(gq), canon(gk), canon(gv)
+        if not (gq.stride() == gk.stride() == gv.stride()):
+            gq, gk, gv = gq.contiguous(), gk.contiguous(), gv.contiguous()
+        sb, sl, sh, _ = gq.stride()
+        gqkv = torch.empty(B * L, 3 * H * D, device=gq.device, dtype=gq.dtype)
+        rc = lib.sam3_vit_qkv_rope_bwd(gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), sb, sh, sl, cos.data_ptr(),
+                                       sin.data_ptr(), gqkv.data_ptr(), B, L, H, D, dt,
+                                       ctypes.c_void_p(torch.cuda.current_stream(gq.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_vit_qkv_rope_bwd failed ({rc})")
+        return gqkv, None, None, None, None, None, None
 
 
 def window_partition(x: torch.Tensor, ws: int) -> Tuple[torch.Tensor, Tuple[int, int]]:
@@ -171,8 +224,21 @@ class Block(nn.Module):
         h = self.attn(h)
         if self.window_size > 0:
             h = window_unpartition(h, self.window_size, pad_hw, (H, W))
-        x = x + self.dropout(self.drop_path(h))
-        return x + self.dropout(self.drop_path(self.mlp(self.norm2(x))))
+        x = self._residual(x, h)
+        return self._residual(x, self.mlp(self.norm2(x)))
+
+    def _residual(self, x: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+        """x + dropout(drop_path(h)); with stochastic depth active the mask-multiply and the add are one
+        fused pass (addcmul) instead of two elementwise kernels over [B, 72, 72, C]."""
+        h = self.dropout(h)
+        dp = self.drop_path
+        if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
+            keep = 1.0 - dp.drop_prob
+            mask = h.new_empty((h.shape[0],) + (1,) * (h.ndim - 1)).bernoulli_(keep)
+            if keep > 0.0 and dp.scale_by_keep:
+                mask.div_(keep)
+            return torch.addcmul(x, h, mask)
+        return x + h
 
 
 class ViT(nn.Module):
