@@ -1,0 +1,157 @@
+"""
+Hungarian matching of DETR queries to ground-truth boxes -- the parity surface right after the model
+forward in the training step (reference ``sam3/train/matcher.py``:
+``BinaryHungarianMatcherV2`` :431-668, ``_do_matching`` :15-29, box utilities ``sam3/model/box_ops.py``
+:11-143).  Indices must be bit-exact, so the assignment itself stays on the host with the same solver
+(``scipy.optimize.linear_sum_assignment``); the cost matrix is built on the device in fp32 in ONE batched
+expression and crosses to the host once per call.
+
+    cost = w_bbox * L1(cxcywh) + w_class * focal_class_cost + w_giou * (-GIoU)
+
+The native CLI constructs it as ``BinaryHungarianMatcherV2(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0,
+focal=True)`` (``train_sam3_lora_native.py:743-745``).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+__all__ = ["BinaryHungarianMatcherV2", "box_cxcywh_to_xyxy", "box_iou", "generalized_box_iou"]
+
+INVALID_COST = 1e9      # cost given to masked-out predictions / targets
+VALID_THRESH = 1e8      # assignments at or above this are dropped after the solve
+
+
+def box_cxcywh_to_xyxy(x: torch.Tensor) -> torch.Tensor:
+    cx, cy, w, h = x.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+def box_iou(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pairwise IoU and union of xyxy boxes a[..., N, 4], b[..., M, 4] -> [..., N, M]."""
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    lt = torch.max(a[..., :, None, :2], b[..., None, :, :2])
+    rb = torch.min(a[..., :, None, 2:], b[..., None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a[..., None] + area_b[..., None, :] - inter
+    return inter / union, union
+
+
+def generalized_box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    iou, union = box_iou(a, b)
+    lt = torch.min(a[..., :, None, :2], b[..., None, :, :2])
+    rb = torch.max(a[..., :, None, 2:], b[..., None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    hull = wh[..., 0] * wh[..., 1]
+    return iou - (hull - union) / hull
+
+
+def _solve(cost: np.ndarray, repeats: int, want_tgt: bool, filter_invalid: bool):
+    """One image: rows = queries, cols = its targets (tiled ``repeats`` times for one-to-many)."""
+    if repeats > 1:
+        cost = np.tile(cost, (1, repeats))
+    rows, cols = linear_sum_assignment(cost)
+    if filter_invalid:
+        keep = cost[rows, cols] < VALID_THRESH
+        rows, cols = rows[keep].astype(np.int64), cols[keep].astype(np.int64)
+    if want_tgt:
+        return rows, cols
+    return rows[np.argsort(cols)]       # query index of target 0, 1, 2, ...
+
+
+class BinaryHungarianMatcherV2(nn.Module):
+    """Returns ``(batch_idx, src_idx, tgt_idx)``; ``tgt_idx`` is None when every image has fewer targets
+    than queries and nothing is masked (then matches are listed in target order per image)."""
+
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, focal: bool = False,
+                 alpha: float = 0.25, gamma: float = 2.0, stable: bool = False,
+                 remove_samples_with_0_gt: bool = True):
+        super().__init__()
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        self.norm = nn.Sigmoid()
+        self.focal = focal
+        if focal:
+            self.alpha, self.gamma, self.stable = alpha, gamma, stable
+        self.remove_samples_with_0_gt = remove_samples_with_0_gt
+
+    def cost_matrix(self, score: torch.Tensor, boxes: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+        """score [B, Q] logits, boxes [B, Q, 4] cxcywh, tgt [B, T, 4] cxcywh (padded) -> [B, Q, T]."""
+        c_l1 = torch.cdist(boxes, tgt, p=1)
+        c_giou = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt))
+        prob = self.norm(score)
+        if not self.focal:
+            c_cls = -prob.unsqueeze(-1).expand_as(c_l1)
+        elif self.stable:
+            p = prob.unsqueeze(-1).expand_as(c_l1) * ((-c_giou + 1) / 2)
+            c_cls = -self.alpha * (1 - p) ** self.gamma * torch.log(p) + (1 - self.alpha) * p ** self.gamma * torch.log(1 - p)
+        else:
+            c_cls = (-self.alpha * (1 - prob) ** self.gamma * torch.nn.functional.logsigmoid(score)
+                     + (1 - self.alpha) * prob ** self.gamma * torch.nn.functional.logsigmoid(-score))
+            c_cls = c_cls.unsqueeze(-1).expand_as(c_l1)
+        return self.cost_bbox * c_l1 + self.cost_class * c_cls + self.cost_giou * c_giou
+
+    @torch.no_grad()
+    def forward(self, outputs: Dict[str, torch.Tensor], batched_targets: Dict[str, torch.Tensor], repeats: int = 1,
+                repeat_batch: int = 1, out_is_valid: Optional[torch.Tensor] = None,
+                target_is_valid_padded: Optional[torch.Tensor] = None):
+        num_queries = outputs["pred_logits"].shape[1]
+        score = outputs["pred_logits"].squeeze(-1)
+        boxes = outputs["pred_boxes"]
+        device = score.device
+        num_boxes = batched_targets["num_boxes"].cpu()
+        tgt = batched_targets["boxes_padded"]
+        keep = None
+        if self.remove_samples_with_0_gt:
+            keep = num_boxes > 0
+            num_boxes, tgt = num_boxes[keep], tgt[keep]
+            if target_is_valid_padded is not None:
+                target_is_valid_padded = target_is_valid_padded[keep]
+        if repeat_batch > 1:        # final + auxiliary outputs concatenated along the batch
+            num_boxes = num_boxes.repeat(repeat_batch)
+            tgt = tgt.repeat(repeat_batch, 1, 1)
+            if target_is_valid_padded is not None:
+                target_is_valid_padded = target_is_valid_padded.repeat(repeat_batch, 1)
+        if self.remove_samples_with_0_gt:
+            if repeat_batch > 1:
+                keep = keep.repeat(repeat_batch)
+            score, boxes = score[keep], boxes[keep]
+            if out_is_valid is not None:
+                out_is_valid = out_is_valid[keep]
+        assert boxes.shape[0] == tgt.shape[0] == num_boxes.shape[0]
+
+        C = self.cost_matrix(score, boxes, tgt)
+        filtering = out_is_valid is not None or target_is_valid_padded is not None
+        if out_is_valid is not None:
+            C = torch.where(out_is_valid[:, :, None], C, INVALID_COST)
+        if target_is_valid_padded is not None:
+            C = torch.where(target_is_valid_padded[:, None, :], C, INVALID_COST)
+        C = C.cpu().numpy()                                          # the one device->host crossing
+        counts = num_boxes.tolist()
+        per_image = [C[i, :, :n] for i, n in enumerate(counts)]
+        want_tgt = filtering or bool(torch.any(num_queries < num_boxes * max(repeats, 1)).item())
+
+        if not per_image:
+            src_lists = []
+            tgt_idx = torch.zeros(0, dtype=torch.long, device=device) if want_tgt else None
+        elif want_tgt:
+            solved = [_solve(c, repeats, True, filtering) for c in per_image]
+            src_lists = [s for s, _ in solved]
+            offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+            tgt_idx = torch.from_numpy(np.concatenate([t + o for (_, t), o in zip(solved, offsets)])).long().to(device)
+        else:
+            src_lists = [_solve(c, repeats, False, filtering) for c in per_image]
+            tgt_idx = None
+
+        image_ids = keep.nonzero().squeeze(1).tolist() if self.remove_samples_with_0_gt else list(range(len(src_lists)))
+        batch_idx = torch.as_tensor([image_ids[i] for i, s in enumerate(src_lists) for _ in range(len(s))],
+                                    dtype=torch.long, device=device)
+        src_idx = (torch.from_numpy(np.concatenate(src_lists)).long().to(device) if src_lists
+                   else torch.empty(0, dtype=torch.long, device=device))
+        return batch_idx, src_idx, tgt_idx
