@@ -261,10 +261,16 @@ def trunk_step_bench(dev, batch, rank, steps, world):
         opt.step()
         return loss
 
+    tw = time.perf_counter()
     step()
     torch.cuda.synchronize()
+    warm_s = time.perf_counter() - tw
+    slow = torch.tensor([1.0 if warm_s > 20.0 else 0.0], device=dev)
     if world > 1:
+        dist.all_reduce(slow, op=dist.ReduceOp.MAX)
         dist.barrier()
+    if slow.item() > 0:      # something is badly wrong on this box (e.g. ranks sharing a GPU): do not stall the bench
+        steps = 1
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
@@ -342,11 +348,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an AMD GPU (the LoRA path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    # test hook: BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, so the N>1 code path (init, bucketed
+    # side-stream all-reduce, barriers, MAX-over-ranks timing) can be exercised on a 1-GPU box.  Never set by the driver.
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank)
 
     def barrier():
@@ -385,8 +399,12 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": w.reducer.nbytes, "finite": bool(finite)},
         }
-    if rank == 0 and not args.no_roofline:
+    rows = None
+    if not args.no_roofline:
+        # every rank runs the instrumented steps (they contain the gradient all-reduce: a rank-0-only run would
+        # deadlock the others); only rank 0 reports
         rows = insitu_kernels(w)
+    if rank == 0 and not args.no_roofline:
         ops = op_table(w, args.kernel_iters)
         dom = rows[0]             # largest share of the step's kernel time
         dimname = {"k_t1": "K", "k_t2": "N", "k_t3": "N"}.get(dom["kernel"], "dim")
