@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (weak scaling)")
     ap.add_argument("--blocks", type=int, default=N_BLOCKS)
+    ap.add_argument("--dropout", type=float, default=0.0, help="LoRA dropout p (literal full_lora_config.yaml: 0.1)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -54,11 +55,12 @@ def parse():
 class Workload:
     """Synthetic, HBM-resident state of the adapter path of one ViT trunk."""
 
-    def __init__(self, dev, batch, rank, blocks, seed):
+    def __init__(self, dev, batch, rank, blocks, seed, dropout=0.0):
         from sam3_lora_amd.ddp import LoRAGradReducer
         self.dev, self.rank, self.blocks = dev, rank, blocks
         self.M = batch * TOKENS
         self.scaling = 2.0  # alpha = 2*rank in every shipped config
+        self.dropout = dropout
         g = torch.Generator(device=dev).manual_seed(seed)
         M = self.M
 
@@ -87,21 +89,21 @@ class Workload:
 
     def step(self):
         from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
-        s, L = self.scaling, 0
+        s, L, p = self.scaling, 0, self.dropout
         self.reducer.zero_grad()
         with torch.no_grad():
             for b in range(self.blocks):                       # forward
                 k = b & 1
-                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L)
-                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L)
+                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, drop_p=p, seed=2 * b)
+                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, drop_p=p, seed=2 * b + 1)
             for b in reversed(range(self.blocks)):             # per-block recompute, then backward
                 k = b & 1
-                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True)
-                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True)
+                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True, drop_p=p, seed=2 * b)
+                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True, drop_p=p, seed=2 * b + 1)
                 lora_bwd_(self.g2[k], self.h[k], t2, self.A2[b], self.B2[b], self.gh[k],
-                          self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True)
+                          self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True, drop_p=p, seed=2 * b + 1)
                 lora_bwd_(self.gh[k], self.x1[k], t1, self.A1[b], self.B1[b], self.g1[k],
-                          self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True)
+                          self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True, drop_p=p, seed=2 * b)
                 for p in (self.A1[b], self.B1[b], self.A2[b], self.B2[b]):
                     self.reducer.notify(p)
         self.reducer.finish()
@@ -361,7 +363,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank)
+    w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank, dropout=args.dropout)
 
     def barrier():
         if world > 1:
