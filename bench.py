@@ -89,21 +89,21 @@ class Workload:
 
     def step(self):
         from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
-        s, L, p = self.scaling, 0, self.dropout
+        s, L, dp = self.scaling, 0, self.dropout
         self.reducer.zero_grad()
         with torch.no_grad():
             for b in range(self.blocks):                       # forward
                 k = b & 1
-                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, drop_p=p, seed=2 * b)
-                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, drop_p=p, seed=2 * b + 1)
+                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, drop_p=dp, seed=2 * b)
+                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, drop_p=dp, seed=2 * b + 1)
             for b in reversed(range(self.blocks)):             # per-block recompute, then backward
                 k = b & 1
-                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True, drop_p=p, seed=2 * b)
-                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True, drop_p=p, seed=2 * b + 1)
+                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True, drop_p=dp, seed=2 * b)
+                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True, drop_p=dp, seed=2 * b + 1)
                 lora_bwd_(self.g2[k], self.h[k], t2, self.A2[b], self.B2[b], self.gh[k],
-                          self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True, drop_p=p, seed=2 * b + 1)
+                          self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b + 1)
                 lora_bwd_(self.gh[k], self.x1[k], t1, self.A1[b], self.B1[b], self.g1[k],
-                          self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True, drop_p=p, seed=2 * b)
+                          self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b)
                 for p in (self.A1[b], self.B1[b], self.A2[b], self.B2[b]):
                     self.reducer.notify(p)
         self.reducer.finish()
