@@ -118,6 +118,29 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
                     void* stream);
 
 /*
+ * "Augmented frozen GEMM" mode (bf16, no dropout): the rank-r intermediates come out of the frozen GEMMs the
+ * caller runs anyway, so the row-reduction kernel disappears from both directions.
+ * The caller stores the frozen weight inside  Waug[out + r_pad, in + r_pad]  (bf16, row pitch ldw, r_pad = 16
+ * for r <= 16 else 32):   Waug[:out, :in] = W,   Waug[out:, :in] = A_c^T,   Waug[:out, in:] = B_c^T,  and computes
+ *     forward   [ W x + b | t  ] = x  @ Waug[:, :in]^T  (+ [b | 0])        t  = x  A_c      [M, r_pad]
+ *     backward  [ gy W    | gt ] = gy @ Waug[:out, :]                       gt = gy B_c^T    [M, r_pad] (unscaled)
+ * sam3_lora_aug_scatter refreshes the A/B slots from the fp32 masters (call it whenever A or B changed).
+ * sam3_lora_fwd_fused:  y_inout += scaling * t @ B_c ; emits tT for the backward.      (replaces sam3_lora_fwd)
+ * sam3_lora_bwd_fused:  gB += scaling * t^T gy ; gA += scaling * x^T gt ; gx_inout += scaling * gt @ A_c^T.
+ * t / gt are the [M, r_pad] column slices of the GEMM outputs (row pitch ldt / ldgt in elements, 8-byte aligned).
+ */
+int sam3_lora_aug_scatter(const void* A, const void* B, void* Waug, int64_t ldw, int in_features, int out_features,
+                          int rank, int layout, void* stream);
+size_t sam3_lora_fused_workspace_bytes(int64_t M, int in_features, int out_features, int rank);
+int sam3_lora_fwd_fused(const void* t, int64_t ldt, const void* B, void* y_inout, void* tT_out, int64_t M,
+                        int in_features, int out_features, int rank, int64_t ldy, int layout, float scaling, int dtype,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, const void* gt, int64_t ldgt, const void* A,
+                        void* gx_inout, float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features,
+                        int rank, int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, int dtype,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Profiling aid, not part of the training path: restrict which internal stages the NEXT calls of
  * sam3_lora_fwd / sam3_lora_bwd launch (process-wide; returns the previous mask; default all).
  * bench.py uses it to time one kernel at a time with HIP events on the caller's stream.  With a

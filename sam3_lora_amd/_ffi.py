@@ -25,6 +25,7 @@ EXPORTS = (
     "sam3_lora_fwd_workspace_bytes", "sam3_lora_bwd_workspace_bytes",
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
+    "sam3_lora_aug_scatter", "sam3_lora_fused_workspace_bytes", "sam3_lora_fwd_fused", "sam3_lora_bwd_fused",
 )
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
@@ -69,6 +70,17 @@ def _declare(lib):
     lib.sam3_lora_prof_start.argtypes = [ctypes.c_uint, c_int]
     lib.sam3_lora_prof_stop.restype = c_int
     lib.sam3_lora_prof_stop.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
+    lib.sam3_lora_aug_scatter.restype = c_int
+    lib.sam3_lora_aug_scatter.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]
+    lib.sam3_lora_fused_workspace_bytes.restype = c_size_t
+    lib.sam3_lora_fused_workspace_bytes.argtypes = [c_int64, c_int, c_int, c_int]
+    lib.sam3_lora_fwd_fused.restype = c_int
+    lib.sam3_lora_fwd_fused.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                        c_int64, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]
+    lib.sam3_lora_bwd_fused.restype = c_int
+    lib.sam3_lora_bwd_fused.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_float,
+                                        c_int, c_int, c_void_p, c_size_t, c_void_p]
     for f in (lib.sam3_vit_qkv_rope_fwd, lib.sam3_vit_qkv_rope_bwd):
         f.restype = c_int
     lib.sam3_vit_qkv_rope_fwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_int, c_void_p]

@@ -98,28 +98,19 @@ __device__ __forceinline__ uint4 drop8(uint4 v, unsigned long long e8, const Dro
 struct PackJob {
     const float* src;
     bf16_t* dst;
-    int I, J, Iv, Jv;     // dst is I x J (J already padded), valid region Iv x Jv
+    int I, J, Iv, Jv;     // dst is I x J, valid region Iv x Jv (the rest is zero-filled)
     long long si, sj;
-    int frag;             // 1: dst is the fragment-major W1f image (see k_t1), I = RP, J = K padded to 128
+    int ldd;              // row pitch of dst in elements (0 => J); > J when packing into a slice of a wider buffer
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackJob j0, PackJob j1) {
     const PackJob jb = blockIdx.y == 0 ? j0 : j1;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)jb.I * jb.J) return;
-    int i, j;
-    if (jb.frag) {   // idx = ((kstep*RT + rt)*64 + g*16 + n)*8 + e  ->  i = rt*16 + n, j = kstep*32 + g*8 + e
-        const int RT = jb.I / 16, e = (int)(idx & 7), nn = (int)(idx >> 3) & 15, gg = (int)(idx >> 7) & 3;
-        const int blk = (int)(idx >> 9);
-        i = (blk % RT) * 16 + nn;
-        j = (blk / RT) * 32 + gg * 8 + e;
-    } else {
-        i = (int)(idx / jb.J);
-        j = (int)(idx % jb.J);
-    }
+    const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
     const float v = (i < jb.Iv && j < jb.Jv) ? jb.src[i * jb.si + j * jb.sj] : 0.f;
     bf16x2 t = {(__bf16)v, (__bf16)0.f};
-    jb.dst[idx] = (bf16_t)(__builtin_bit_cast(unsigned, t) & 0xffffu);
+    jb.dst[(long long)i * (jb.ldd ? jb.ldd : jb.J) + j] = (bf16_t)(__builtin_bit_cast(unsigned, t) & 0xffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -568,6 +559,30 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// repack: strided bf16 t[M, RP] (a column slice of the augmented frozen GEMM's output, row pitch ldt)
+//   -> T[Mp, RP] row-major (k_t2's operand) and TTf fragment-major (k_t3's operand); rows >= M are zero.
+// ------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(256) void k_repack(const bf16_t* __restrict__ t, long long ldt, bf16_t* __restrict__ T,
+                                                bf16_t* __restrict__ TTf, long long M, long long Mp) {
+    constexpr int RP = RT * 16;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 4 consecutive rank entries
+    if (idx >= Mp * (RP / 4)) return;
+    const long long m = idx / (RP / 4);
+    const int r0 = (int)(idx % (RP / 4)) * 4;
+    uint2 v = make_uint2(0u, 0u);
+    if (m < M) v = *reinterpret_cast<const uint2*>(t + m * ldt + r0);
+    *reinterpret_cast<uint2*>(T + m * RP + r0) = v;
+    const long long blk = m >> 5;
+    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7), rt = r0 >> 4, n0 = r0 & 15;
+    bf16_t* tb = TTf + (((blk * RT + rt) * 4 + gq) * 16 + n0) * 8 + jq;
+    tb[0] = (bf16_t)(v.x & 0xffffu);
+    tb[8] = (bf16_t)(v.x >> 16);
+    tb[16] = (bf16_t)(v.y & 0xffffu);
+    tb[24] = (bf16_t)(v.y >> 16);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1033,6 +1048,122 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
         hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling * inv_keep, accumulate);
     }
     return launch_ok("sam3_lora_bwd");
+}
+
+// ---- "augmented frozen GEMM" mode --------------------------------------------------------------------
+// The caller keeps the frozen weight inside Waug[out + r_pad, in + r_pad] (bf16, row pitch ldw):
+//     Waug[:out, :in] = W         Waug[out:, :in] = A_c^T        Waug[:out, in:] = B_c^T
+// so the frozen GEMMs it runs anyway also produce the rank-r intermediates for free:
+//     x  @ Waug[:, :in]^T = [ W x | t  ]      (forward)        gy @ Waug[:out, :] = [ gy W | gt ]   (backward)
+// and k_t1 disappears from both directions; only the rank-r update (k_t2) and the M-reductions (k_t3) remain.
+
+int sam3_lora_aug_scatter(const void* A, const void* B, void* Waug, int64_t ldw, int in_features, int out_features,
+                          int rank, int layout, void* stream) {
+    g_err[0] = 0;
+    int rc;
+    if ((rc = check_common(1, in_features, out_features, rank, layout, SAM3_LORA_BF16))) return rc;
+    if (!A || !B || !Waug) return fail(SAM3_LORA_EINVAL, "NULL pointer");
+    const int RP = rpad(rank);
+    if (ldw < in_features + RP) return fail(SAM3_LORA_EINVAL, "ldw (%lld) < in_features + r_pad", (long long)ldw);
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+    bf16_t* W = (bf16_t*)Waug;
+    // rows out..out+RP: A_c^T [RP, in] ; columns in..in+RP of rows 0..out: B_c^T [out, RP]
+    PackJob ja{(const float*)A, W + (long long)out_features * ldw, RP, in_features, rank, in_features, s.a_sr, s.a_si, (int)ldw};
+    PackJob jb{(const float*)B, W + in_features, out_features, RP, out_features, rank, s.b_so, s.b_sr, (int)ldw};
+    launch_pack(ja, jb, (hipStream_t)stream);
+    return launch_ok("sam3_lora_aug_scatter");
+}
+
+size_t sam3_lora_fused_workspace_bytes(int64_t M, int in_features, int out_features, int rank) {
+    if (check_common(M, in_features, out_features, rank, 0, SAM3_LORA_BF16)) return 0;
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank);   // superset of what the fused calls need
+    return w.total;
+}
+
+int sam3_lora_fwd_fused(const void* t, int64_t ldt, const void* B, void* y_inout, void* tT_out, int64_t M,
+                        int in_features, int out_features, int rank, int64_t ldy, int layout, float scaling, int dtype,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    g_err[0] = 0;
+    int rc;
+    if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
+    if (dtype != SAM3_LORA_BF16) return fail(SAM3_LORA_ENOTSUP, "fused mode is bf16 only");
+    if ((rc = check_act(y_inout, ldy, out_features, dtype, "y_inout"))) return rc;
+    if (!t || !B) return fail(SAM3_LORA_EINVAL, "t or B is NULL");
+    if (((uintptr_t)t & 7) || ((ldt * 2) & 7)) return fail(SAM3_LORA_EINVAL, "t: base and row pitch must be 8-byte aligned");
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank);
+    if (!workspace || workspace_bytes < w.total)
+        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int RP = rpad(rank), RT = RP / 16;
+    const long long Mp = round_up(M, 64);
+    char* ws = (char*)workspace;
+    bf16_t* T = (bf16_t*)(ws + w.t);
+    bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+    // W2t[out][RP] = B_c^T lives in the PB partial slot (>= out*RP*2 bytes, unused in forward)
+    bf16_t* W2t = (bf16_t*)(ws + w.pb);
+    PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0};
+    PackJob j0{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(jb, j0, st);
+    {
+        ProfScope ps(SAM3_LORA_STAGE_T1, RP, st);   // reported as the (tiny) stand-in of T1
+        const long long nth = Mp * (RP / 4);
+        if (RT == 1) hipLaunchKernelGGL(k_repack<1>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)t, ldt, T, TT, M, Mp);
+        else hipLaunchKernelGGL(k_repack<2>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)t, ldt, T, TT, M, Mp);
+    }
+    if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
+    return launch_ok("sam3_lora_fwd_fused");
+}
+
+int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, const void* gt, int64_t ldgt, const void* A,
+                        void* gx_inout, float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features,
+                        int rank, int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, int dtype,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    g_err[0] = 0;
+    int rc;
+    if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
+    if (dtype != SAM3_LORA_BF16) return fail(SAM3_LORA_ENOTSUP, "fused mode is bf16 only");
+    if ((rc = check_act(gy, ldgy, out_features, dtype, "gy"))) return rc;
+    if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
+    if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
+    if (!tT_saved || !gt || !A) return fail(SAM3_LORA_EINVAL, "tT_saved, gt or A is NULL");
+    if (((uintptr_t)gt & 7) || ((ldgt * 2) & 7)) return fail(SAM3_LORA_EINVAL, "gt: base and row pitch must be 8-byte aligned");
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank);
+    if (!workspace || workspace_bytes < w.total)
+        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int RP = rpad(rank), RT = RP / 16;
+    const long long Mp = round_up(M, 64);
+    char* ws = (char*)workspace;
+    bf16_t* W2tb = (bf16_t*)(ws + w.w2tb);
+    bf16_t* GT = (bf16_t*)(ws + w.gt);
+    bf16_t* GTT = (bf16_t*)(ws + w.gtt);
+    float* PB = (float*)(ws + w.pb);
+    float* PA = (float*)(ws + w.pa);
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+    PackJob ja{(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0};
+    PackJob j0{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(ja, j0, st);
+    {
+        ProfScope ps(SAM3_LORA_STAGE_T1, RP, st);
+        const long long nth = Mp * (RP / 4);
+        if (RT == 1) hipLaunchKernelGGL(k_repack<1>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)gt, ldgt, GT, GTT, M, Mp);
+        else hipLaunchKernelGGL(k_repack<2>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)gt, ldgt, GT, GTT, M, Mp);
+    }
+    if (gB_accum && stage_on(SAM3_LORA_STAGE_T3_GB))
+        launch_t3<bf16_t>(gy, ldgy, (const bf16_t*)tT_saved, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);
+    if (gA_accum && stage_on(SAM3_LORA_STAGE_T3_GA))
+        launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st);
+    if (gx_inout && stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
+    if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
+        ReduceJob rb{PB, gB_accum, w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
+        ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
+        const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
+        dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);
+        ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
+        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling, accumulate);
+    }
+    return launch_ok("sam3_lora_bwd_fused");
 }
 
 int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm, int in_features, int out_features,

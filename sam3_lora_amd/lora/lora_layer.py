@@ -13,7 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
-from ..functional import LAYOUT_PACKAGE, lora_linear, merge_weight
+from ..functional import LAYOUT_PACKAGE, AugmentedWeight, lora_linear, merge_weight
 
 
 class LoRALayer(nn.Module):
@@ -59,6 +59,7 @@ class LinearWithLoRA(nn.Module):
         self.out_features = linear.out_features
         self.lora = LoRALayer(linear.in_features, linear.out_features, rank=rank, alpha=alpha,
                               dropout=dropout)
+        self._aug = AugmentedWeight()     # plain attribute: not a parameter/buffer, not in state_dict
 
     # nn.MultiheadAttention and friends read these off the wrapped module
     @property
@@ -72,7 +73,7 @@ class LinearWithLoRA(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lo = self.lora
         return lora_linear(x, self.linear.weight, self.linear.bias, lo.lora_A, lo.lora_B, lo.scaling,
-                           LAYOUT_PACKAGE, lo.dropout_p, self.training)
+                           LAYOUT_PACKAGE, lo.dropout_p, self.training, aug=self._aug)
 
     def merge_weights(self) -> nn.Linear:
         """A plain nn.Linear whose weight is ``W + scaling * B @ A`` (bias cloned)."""

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from .functional import LAYOUT_ROOT, lora_linear
+from .functional import LAYOUT_ROOT, AugmentedWeight, lora_linear
 
 __all__ = [
     "LoRALayer", "LoRALinear", "LoRAConfig", "apply_lora_to_model", "get_lora_parameters",
@@ -66,11 +66,12 @@ class LoRALinear(nn.Module):
             p.requires_grad = False
         self.lora = LoRALayer(original_layer.in_features, original_layer.out_features,
                               rank=rank, alpha=alpha, dropout=dropout)
+        self._aug = AugmentedWeight()     # plain attribute: not a parameter/buffer, not in state_dict
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lo = self.lora
         return lora_linear(x, self.original_layer.weight, self.original_layer.bias, lo.lora_A, lo.lora_B,
-                           lo.scaling, LAYOUT_ROOT, lo.dropout_p, self.training)
+                           lo.scaling, LAYOUT_ROOT, lo.dropout_p, self.training, aug=self._aug)
 
 
 class LoRAConfig:

@@ -321,3 +321,39 @@ def test_errors_are_loud():
                      torch.zeros(4, 16, device=DEV), 1.0, 0)   # in_features not a multiple of 8
     with pytest.raises(Fn.LoRAKernelError):
         root_api.LoRALinear(torch.nn.Linear(16, 16))(torch.zeros(2, 16))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("api", ["root", "package"])
+def test_augmented_gemm_mode_matches_standalone(api, monkeypatch):
+    """t / gt taken from the augmented frozen GEMMs == the standalone kernels (same roundings: bf16 t, gt)."""
+    torch.manual_seed(3)
+    fin, fout, r = 256, 384, 16
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SAM3_LORA_FUSED", fused)
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(fin, fout)
+        mod = (root_api.LoRALinear(lin, rank=r, alpha=32) if api == "root" else pkg_api.LinearWithLoRA(lin, rank=r, alpha=32.0))
+        with torch.no_grad():
+            mod.lora.lora_B.normal_(0, 0.05)
+        mod.to(DEV)
+        base = mod.original_layer if api == "root" else mod.linear
+        base.to(torch.bfloat16)
+        x = torch.randn(3, 50, fin, device=DEV).bfloat16().requires_grad_(True)
+        y = mod(x)
+        y.float().square().sum().backward()
+        outs[fused] = (y.detach().float(), x.grad.float(), mod.lora.lora_A.grad.clone(), mod.lora.lora_B.grad.clone())
+        if fused == "1":
+            assert mod._aug.Waug is not None and base.weight.data_ptr() == mod._aug.Waug.data_ptr()   # aliased, no copy
+            # masters change -> slots refresh on the next call
+            with torch.no_grad():
+                mod.lora.lora_A.mul_(2.0)
+            y2 = mod(x.detach())
+            want = torch.nn.functional.linear(x.detach(), base.weight, base.bias).float() + 2.0 * (
+                (x.detach().float() @ (mod.lora.lora_A if api == "root" else mod.lora.lora_A.t()).float())
+                @ (mod.lora.lora_B if api == "root" else mod.lora.lora_B.t()).float())
+            assert ((y2.float() - want).abs().max() / want.abs().max()).item() < 2e-2
+        else:
+            assert mod._aug.Waug is None
+    for a, b in zip(outs["1"], outs["0"]):
+        assert ((a - b).abs().max() / b.abs().max()).item() < 1.5e-2
