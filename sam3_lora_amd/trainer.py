@@ -1,0 +1,266 @@
+"""
+The training loop around the adapter path -- the caller side of SURVEY section 8 row a14 (reference
+``train_sam3_lora_native.py``: ``SAM3TrainerNative.__init__`` :689-793, ``train`` :795-1046, ``main``
+:1049-1060).
+
+What is restated here is the part of that script that belongs to the LoRA path and its boundary:
+
+  * the YAML surface: exactly the keys the reference reads (ten mandatory ``lora.*`` keys,
+    ``training.{data_dir,batch_size,learning_rate,weight_decay,num_epochs}``, ``output.output_dir``); a missing
+    key is a ``KeyError`` as it is there, every other key is accepted and ignored as it is there;
+  * adapter injection, AdamW over the ``requires_grad`` tensors only, the matcher / loss constants of
+    :743-793, the per-step order forward -> back_convert -> match every step and aux output -> loss ->
+    zero_grad / backward / step, the epoch loop with validation, and the artefacts: ``last_lora_weights.pt``,
+    ``best_lora_weights.pt`` (copy of last when there is no validation split) and one JSON line per epoch in
+    ``val_stats.json``;
+  * what the reference does not have on this script (it trains on one GPU): launched under torchrun with
+    WORLD_SIZE > 1 the A/B gradients go through :class:`sam3_lora_amd.ddp.LoRAGradReducer`, the loss is
+    normalised over ranks ("global") and rank 0 writes the artefacts.
+
+What is NOT here: the SAM3 image model itself (neck, text tower, DETR, mask head) and the COCO pipeline are
+outside this library's scope (DESIGN.md "Out of scope").  They plug in through two builders,
+
+    model_builder(config, device) -> nn.Module       model(input_batch) -> per-stage outputs; model.back_convert(t)
+    data_builder(config, split)   -> sized iterable  of batches ({"input": batch} or batch), or None for no split
+
+named as ``module:function`` on the command line or in ``SAM3_LORA_MODEL_BUILDER`` / ``SAM3_LORA_DATA_BUILDER``.
+A maintainer of the reference passes thin wrappers of ``build_sam3_image_model`` and ``COCOSegmentDataset`` +
+``collate_fn_api``; without builders the trainer stops with that explanation rather
+than pretending.
+"""
+from __future__ import annotations
+
+import importlib
+import json
+import os
+import shutil
+from pathlib import Path
+from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import yaml
+from torch.optim import AdamW
+
+from .ddp import LoRAGradReducer
+from .lora_layers import LoRAConfig, apply_lora_to_model, count_parameters, save_lora_weights
+from .losses import CORE_LOSS_KEY, Boxes, BinaryOneToManyMatcher, IABCEMdetr, Masks, Sam3LossWrapper
+from .matcher import BinaryHungarianMatcherV2
+
+__all__ = ["SAM3TrainerNative", "load_config", "lora_config_from", "build_criterion", "resolve_builder",
+           "match_all_steps", "move_to_device", "DEFAULT_CONFIG"]
+
+DEFAULT_CONFIG = "configs/full_lora_config.yaml"       # train_sam3_lora_native.py:1051
+LORA_KEYS = ("rank", "alpha", "dropout", "target_modules", "apply_to_vision_encoder", "apply_to_text_encoder",
+             "apply_to_geometry_encoder", "apply_to_detr_encoder", "apply_to_detr_decoder", "apply_to_mask_decoder")
+
+
+def load_config(path: str) -> Dict[str, Any]:
+    with open(path, "r") as f:
+        return yaml.safe_load(f)
+
+
+def lora_config_from(config: Dict[str, Any]) -> LoRAConfig:
+    """All ten keys are mandatory (:713-725): a config without one raises KeyError naming it."""
+    section = config["lora"]
+    return LoRAConfig(**{k: section[k] for k in LORA_KEYS})
+
+
+def build_criterion(normalization: str = "local"):
+    """Matcher and loss stack with the constants the native script hard-codes (:743-793)."""
+    matcher = BinaryHungarianMatcherV2(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0, focal=True)
+    losses = [
+        Boxes(weight_dict={"loss_bbox": 5.0, "loss_giou": 2.0}),
+        IABCEMdetr(pos_weight=10.0, weight_dict={"loss_ce": 20.0, "presence_loss": 20.0}, pos_focal=False,
+                   alpha=0.25, gamma=2, use_presence=True, pad_n_queries=200),
+        Masks(weight_dict={"loss_mask": 200.0, "loss_dice": 10.0}, focal_alpha=0.25, focal_gamma=2.0,
+              compute_aux=False),
+    ]
+    wrapper = Sam3LossWrapper(loss_fns_find=losses, matcher=matcher,
+                              o2m_matcher=BinaryOneToManyMatcher(alpha=0.3, threshold=0.4, topk=4), o2m_weight=2.0,
+                              use_o2m_matcher_on_o2m_aux=False, normalization=normalization)
+    return matcher, wrapper
+
+
+def resolve_builder(spec: Optional[str], env: str, what: str) -> Callable:
+    spec = spec or os.environ.get(env)
+    if not spec:
+        raise RuntimeError(
+            f"no {what} builder: this library accelerates the LoRA adapter path and ships the ViT trunk, matcher and "
+            f"losses, not the whole SAM3 image model or its COCO pipeline.  Pass --{what}-builder module:function "
+            f"(or set {env}); INTEGRATION.md section 5 shows the two wrappers for the reference's "
+            f"build_sam3_image_model and COCOSegmentDataset.")
+    mod, _, fn = spec.partition(":")
+    if not fn:
+        raise ValueError(f"{what} builder must be 'module:function', got {spec!r}")
+    return getattr(importlib.import_module(mod), fn)
+
+
+def move_to_device(obj, device):
+    """Tensors inside lists / tuples / dicts / dataclasses (:864-879); dataclasses are updated in place."""
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, list):
+        return [move_to_device(x, device) for x in obj]
+    if isinstance(obj, tuple):
+        return tuple(move_to_device(x, device) for x in obj)
+    if isinstance(obj, dict):
+        return {k: move_to_device(v, device) for k, v in obj.items()}
+    if hasattr(obj, "__dataclass_fields__"):
+        for name in obj.__dataclass_fields__:
+            setattr(obj, name, move_to_device(getattr(obj, name), device))
+    return obj
+
+
+def _steps(stage) -> List[Dict]:
+    """A stage is one output dict or the list of its interactive steps (SAM3Output's ALL_STEPS_PER_STAGE view)."""
+    return [stage] if isinstance(stage, dict) else list(stage)
+
+
+def match_all_steps(matcher, stage_outputs: Sequence, stage_targets: Sequence[Dict]) -> None:
+    """``outputs["indices"]`` for every step of every stage and each of its aux outputs (:914-927)."""
+    for stage, targets in zip(stage_outputs, stage_targets):
+        for outputs in _steps(stage):
+            outputs["indices"] = matcher(outputs, targets)
+            for aux in outputs.get("aux_outputs", ()):
+                aux["indices"] = matcher(aux, targets)
+
+
+class SAM3TrainerNative:
+    def __init__(self, config_path: str, model_builder: Optional[Callable] = None,
+                 data_builder: Optional[Callable] = None, bf16_frozen: bool = False):
+        self.config_path = config_path
+        self.config = load_config(config_path)
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            self.device = torch.device("cuda", local_rank % torch.cuda.device_count())
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = torch.device("cpu")
+        if self.world_size > 1 and not dist.is_initialized():
+            backend = os.environ.get("SAM3_LORA_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
+            dist.init_process_group(backend)
+
+        model_builder = model_builder or resolve_builder(None, "SAM3_LORA_MODEL_BUILDER", "model")
+        self.data_builder = data_builder or resolve_builder(None, "SAM3_LORA_DATA_BUILDER", "data")
+        self._say("Building SAM3 model...")
+        self.model = model_builder(self.config, self.device)
+        self._say("Applying LoRA...")
+        self.model = apply_lora_to_model(self.model, lora_config_from(self.config))
+        stats = count_parameters(self.model)
+        self._say(f"Trainable params: {stats['trainable_parameters']:,} ({stats['trainable_percentage']:.2f}%)")
+        self.model.to(self.device)
+        if bf16_frozen:         # MI355X layout: frozen tensors bf16, A/B fp32 masters (not a reference behaviour)
+            from .vit import to_training_layout
+            to_training_layout(self.model)
+
+        trainable = [p for p in self.model.parameters() if p.requires_grad]
+        self.optimizer = AdamW(trainable, lr=float(self.config["training"]["learning_rate"]),
+                               weight_decay=self.config["training"]["weight_decay"])
+        self.reducer = LoRAGradReducer(trainable) if self.world_size > 1 else None
+        self.matcher, self.loss_wrapper = build_criterion("global" if self.world_size > 1 else "local")
+
+    # ------------------------------------------------------------------------------------------------
+    def _say(self, msg: str) -> None:
+        if self.rank == 0:
+            print(msg, flush=True)
+
+    def _loss(self, batch) -> torch.Tensor:
+        input_batch = batch["input"] if isinstance(batch, dict) and "input" in batch else batch
+        input_batch = move_to_device(input_batch, self.device)
+        outputs = self.model(input_batch)
+        targets = [self.model.back_convert(t) for t in input_batch.find_targets]
+        targets = [move_to_device(t, self.device) for t in targets]
+        match_all_steps(self.matcher, outputs, targets)
+        return self.loss_wrapper([_steps(s)[-1] for s in outputs], targets)[CORE_LOSS_KEY]
+
+    def train_step(self, batch) -> float:
+        loss = self._loss(batch)
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+            loss.backward()
+            self.reducer.finish()
+        else:
+            self.optimizer.zero_grad()
+            loss.backward()
+        self.optimizer.step()
+        return loss.item()
+
+    @torch.no_grad()
+    def validate(self, loader: Iterable) -> float:
+        self.model.eval()
+        losses = [self._loss(b).item() for b in loader]
+        self.model.train()
+        mean = torch.tensor([sum(losses), float(len(losses))], dtype=torch.float64, device=self.device)
+        if self.world_size > 1:
+            dist.all_reduce(mean)
+        return (mean[0] / mean[1]).item()
+
+    def _save(self, path: Path) -> None:
+        if self.rank == 0:
+            save_lora_weights(self.model, str(path))
+
+    def train(self) -> Dict[str, Any]:
+        cfg = self.config
+        data_dir = cfg["training"]["data_dir"]
+        self._say(f"\nLoading training data from {data_dir}...")
+        train_loader = self.data_builder(cfg, "train")
+        try:
+            val_loader = self.data_builder(cfg, "valid")
+            if val_loader is not None and len(val_loader) == 0:
+                val_loader = None
+        except Exception as e:                      # a missing split is not an error (:805-816)
+            self._say(f"Could not load validation data: {e}")
+            val_loader = None
+
+        epochs = cfg["training"]["num_epochs"]
+        out_dir = Path(cfg["output"]["output_dir"])
+        if self.rank == 0:
+            out_dir.mkdir(parents=True, exist_ok=True)
+        self.model.train()
+        best = float("inf")
+        history = []
+        self._say(f"Starting training for {epochs} epochs...")
+        for epoch in range(epochs):
+            if hasattr(train_loader, "set_epoch"):
+                train_loader.set_epoch(epoch)
+            losses = [self.train_step(b) for b in train_loader]
+            avg_train = sum(losses) / len(losses) if losses else 0.0
+            record = {"epoch": epoch + 1, "train_loss": avg_train}
+            self._save(out_dir / "last_lora_weights.pt")
+            if val_loader is not None:
+                avg_val = self.validate(val_loader)
+                record["val_loss"] = avg_val
+                self._say(f"\nEpoch {epoch + 1}/{epochs} - Train Loss: {avg_train:.6f}, Val Loss: {avg_val:.6f}")
+                if avg_val < best:
+                    best = avg_val
+                    self._save(out_dir / "best_lora_weights.pt")
+                    self._say(f"✓ New best model saved (val_loss: {avg_val:.6f})")
+                if self.rank == 0:
+                    with open(out_dir / "val_stats.json", "a") as f:
+                        f.write(json.dumps(record) + "\n")
+            history.append(record)
+        if val_loader is None and self.rank == 0 and (out_dir / "last_lora_weights.pt").exists():
+            shutil.copy(out_dir / "last_lora_weights.pt", out_dir / "best_lora_weights.pt")
+        if self.reducer is not None:
+            dist.barrier()
+        self._say(f"\nTraining complete. Models saved to {out_dir}: best_lora_weights.pt, last_lora_weights.pt")
+        return {"history": history, "best_val_loss": best if val_loader is not None else None}
+
+
+def main(argv: Optional[Sequence[str]] = None) -> None:
+    import argparse
+    parser = argparse.ArgumentParser(description="Train SAM3 with LoRA (MI355X adapter path)")
+    parser.add_argument("--config", type=str, default=DEFAULT_CONFIG, help="Path to YAML configuration file")
+    parser.add_argument("--model-builder", type=str, default=None, help="module:function -> nn.Module (see trainer.py)")
+    parser.add_argument("--data-builder", type=str, default=None, help="module:function -> batches for a split")
+    parser.add_argument("--bf16-frozen", action="store_true", help="keep frozen tensors in bf16 (A/B stay fp32)")
+    args = parser.parse_args(argv)
+    trainer = SAM3TrainerNative(
+        args.config,
+        model_builder=resolve_builder(args.model_builder, "SAM3_LORA_MODEL_BUILDER", "model"),
+        data_builder=resolve_builder(args.data_builder, "SAM3_LORA_DATA_BUILDER", "data"),
+        bf16_frozen=args.bf16_frozen)
+    trainer.train()
