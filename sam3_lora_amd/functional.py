@@ -75,6 +75,30 @@ def _rank_of(A: torch.Tensor, layout: int) -> int:
     return A.shape[1] if layout == LAYOUT_ROOT else A.shape[0]
 
 
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def _pad_cols(t2: torch.Tensor, width: int) -> torch.Tensor:
+    if t2.shape[1] == width:
+        return t2
+    out = t2.new_zeros(t2.shape[0], width)
+    out[:, :t2.shape[1]] = t2
+    return out
+
+
+def _pad_masters(A: torch.Tensor, B: torch.Tensor, layout: int, fin: int, fout: int, fin_p: int, fout_p: int):
+    """Zero-padded fp32 copies of A/B (caller layout) for feature widths rounded up to a multiple of 8."""
+    r = _rank_of(A, layout)
+    if layout == LAYOUT_ROOT:
+        Ap, Bp = A.new_zeros(fin_p, r), B.new_zeros(r, fout_p)
+        Ap[:fin], Bp[:, :fout] = A, B
+    else:
+        Ap, Bp = A.new_zeros(r, fin_p), B.new_zeros(fout_p, r)
+        Ap[:, :fin], Bp[:fout] = A, B
+    return Ap, Bp
+
+
 def saved_t_like(M: int, rank: int, device) -> torch.Tensor:
     n = _ffi.load().sam3_lora_saved_t_bytes(M, rank)
     return torch.empty(n, dtype=torch.uint8, device=device)
@@ -170,7 +194,22 @@ class _LoRALinearFn(torch.autograd.Function):
                 y2 = F.linear(x2, w, b)                  # frozen GEMM: PyTorch-ROCm / hipBLASLt
         Am, Bm = _master(A), _master(B)
         need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        tT = lora_fwd_(x2, Am, Bm, y2, scaling, layout, save_t=need_w, drop_p=drop_p, seed=seed)
+        fin, fout = x2.shape[1], y2.shape[1]
+        ctx.pad = None
+        tT = None
+        if x2.shape[0] == 0:
+            pass                                         # no rows (e.g. no geometric prompts): y is empty, grads are zero
+        elif fin % 8 or fout % 8:
+            # widths the 16-byte vector path cannot address (SAM3: geometry_encoder.*_direct_project, in = 2 / 4 /
+            # 258): run the kernels on zero-padded copies.  The dropout counter then runs over the padded width.
+            ctx.pad = (fin, fout, _pad8(fin), _pad8(fout))
+            Ap, Bp = _pad_masters(Am, Bm, layout, *ctx.pad)
+            x2 = _pad_cols(x2, ctx.pad[2])
+            delta = x2.new_zeros(x2.shape[0], ctx.pad[3])
+            tT = lora_fwd_(x2, Ap, Bp, delta, scaling, layout, save_t=need_w, drop_p=drop_p, seed=seed)
+            y2 = y2 + delta[:, :fout]
+        else:
+            tT = lora_fwd_(x2, Am, Bm, y2, scaling, layout, save_t=need_w, drop_p=drop_p, seed=seed)
         ctx.scaling, ctx.layout, ctx.drop_p, ctx.seed = scaling, layout, drop_p, seed
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         ctx.save_for_backward(x2, w, A, B, tT)
@@ -186,13 +225,30 @@ class _LoRALinearFn(torch.autograd.Function):
         gx2 = None
         if need_x:
             if w is None:
-                gx2 = torch.zeros_like(x2)
+                gx2 = gy2.new_zeros(gy2.shape[0], ctx.x_shape[-1])
             else:
                 with torch.autocast("cuda", enabled=False):
                     gx2 = gy2 @ w                        # frozen GEMM
         gA = torch.empty_like(Am) if need_w else None
         gB = torch.empty_like(Bm) if need_w else None
-        if need_x or need_w:
+        if gy2.shape[0] == 0:
+            if need_w:
+                gA.zero_(), gB.zero_()
+        elif ctx.pad is not None:
+            fin, fout, fin_p, fout_p = ctx.pad
+            Ap, Bp = _pad_masters(Am, Bm, ctx.layout, *ctx.pad)
+            gxp = x2.new_zeros(x2.shape[0], fin_p) if need_x else None
+            gAp = torch.empty_like(Ap) if need_w else None
+            gBp = torch.empty_like(Bp) if need_w else None
+            lora_bwd_(_pad_cols(gy2, fout_p), x2, tT, Ap, Bp, gxp, gAp, gBp, ctx.scaling, ctx.layout,
+                      drop_p=ctx.drop_p, seed=ctx.seed)
+            if need_x:
+                gx2 = gx2 + gxp[:, :fin]
+            if need_w:
+                root = ctx.layout == LAYOUT_ROOT
+                gA.copy_(gAp[:fin] if root else gAp[:, :fin])
+                gB.copy_(gBp[:, :fout] if root else gBp[:fout])
+        elif need_x or need_w:
             lora_bwd_(gy2, x2, tT, Am, Bm, gx2, gA, gB, ctx.scaling, ctx.layout,
                       drop_p=ctx.drop_p, seed=ctx.seed)
         gx = gx2.view(ctx.x_shape).to(ctx.x_dtype) if need_x else None

@@ -357,3 +357,82 @@ def test_augmented_gemm_mode_matches_standalone(api, monkeypatch):
             assert mod._aug.Waug is None            # standalone mode (the default) never builds the augmented buffer
     for a, b in zip(outs["1"], outs["0"]):
         assert ((a - b).abs().max() / b.abs().max()).item() < 1.5e-2
+
+
+# SAM3 Linears the package API's substring targets reach that are not multiples of 8 wide
+# (tests/golden/sam3_linears.json: geometry_encoder.points_direct_project 2->256, boxes_direct_project 4->256,
+#  boxes_pos_enc_project 258->256; heads 256->4 and 256->1 for completeness)
+ODD_SHAPES = [(2, 256), (4, 256), (258, 256), (256, 4), (256, 1), (12, 20)]
+
+
+@pytest.mark.parametrize("fin,fout", ODD_SHAPES)
+@pytest.mark.parametrize("api", ["root", "package"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_feature_widths_not_multiple_of_8(fin, fout, api, dtype):
+    rng = np.random.default_rng(fin * 1000 + fout)
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    rank, alpha, M = 4, 8, (3, 37)
+    lin = torch.nn.Linear(fin, fout)
+    mod = (root_api.LoRALinear(lin, rank=rank, alpha=alpha) if api == "root"
+           else pkg_api.LinearWithLoRA(lin, rank=rank, alpha=alpha))
+    lay = cases.LAYOUT_ROOT if api == "root" else cases.LAYOUT_PACKAGE
+    with torch.no_grad():
+        mod.lora.lora_A.copy_(torch.from_numpy(rng.standard_normal(mod.lora.lora_A.shape).astype(np.float32)))
+        mod.lora.lora_B.copy_(torch.from_numpy(rng.standard_normal(mod.lora.lora_B.shape).astype(np.float32)))
+    mod.to(DEV)
+    xn = rng.standard_normal(M + (fin,)).astype(np.float32)
+    gyn = rng.standard_normal(M + (fout,)).astype(np.float32)
+    if dtype == "bf16":
+        lin.to(torch.bfloat16)
+        xn, gyn = O.bf16_round(xn), O.bf16_round(gyn)
+    x = _t(xn, td).requires_grad_(True)
+    y = mod(x)
+    y.backward(_t(gyn, td))
+    W, b = lin.weight.detach().float().cpu().numpy(), lin.bias.detach().float().cpu().numpy()
+    A, B = mod.lora.lora_A.detach().cpu().numpy(), mod.lora.lora_B.detach().cpu().numpy()
+    s = alpha / rank
+    y_r = O.lora_linear_forward(xn, W, b, A, B, s, lay, acc_dtype=np.float64)
+    gx_r, gA_r, gB_r = O.lora_linear_backward(gyn, xn, W, A, B, s, lay, acc_dtype=np.float64)
+    tol = 1e-2 if dtype == "f32" else 2e-2
+    assert y.shape == y_r.shape
+    assert _relmax(y.detach().float().cpu().numpy(), y_r) < tol
+    assert _relmax(x.grad.float().cpu().numpy(), gx_r) < tol
+    assert _relmax(mod.lora.lora_A.grad.cpu().numpy(), gA_r) < tol
+    assert _relmax(mod.lora.lora_B.grad.cpu().numpy(), gB_r) < tol
+
+
+@pytest.mark.parametrize("api", ["root", "package"])
+def test_empty_input_gives_empty_output_and_zero_grads(api):
+    """No rows at all (SAM3: a batch without geometric prompts feeds [0, B, C] to the geometry encoder)."""
+    lin = torch.nn.Linear(256, 256)
+    mod = (root_api.LoRALinear(lin, rank=8, alpha=16) if api == "root" else pkg_api.LinearWithLoRA(lin, rank=8, alpha=16))
+    mod.to(DEV)
+    torch.nn.init.normal_(mod.lora.lora_B)
+    x = torch.zeros(0, 3, 256, device=DEV, requires_grad=True)
+    y = mod(x)
+    assert y.shape == (0, 3, 256)
+    y.sum().backward()
+    assert x.grad.shape == x.shape
+    assert mod.lora.lora_A.grad is not None and not mod.lora.lora_A.grad.any() and not mod.lora.lora_B.grad.any()
+
+
+def test_odd_width_dropout_is_consistent_between_forward_and_backward():
+    """With dropout the padded path must use one mask in both directions: gA == (drop(x))^T gt for the SAME mask,
+    checked through linearity -- d(sum(y * gy))/dB contracted with B equals sum(delta * gy)."""
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(258, 256)
+    mod = root_api.LoRALinear(lin, rank=4, alpha=8, dropout=0.3).to(DEV)
+    torch.nn.init.normal_(mod.lora.lora_B)
+    mod.train()
+    x = torch.randn(64, 258, device=DEV)
+    gy = torch.randn(64, 256, device=DEV)
+    torch.manual_seed(11)
+    y = mod(x)
+    with torch.no_grad():
+        base = lin(x)
+    (y * gy).sum().backward()
+    delta_dot = ((y.detach() - base) * gy).sum().item()
+    euler_B = (mod.lora.lora_B.grad * mod.lora.lora_B.detach()).sum().item()      # delta is linear in B ...
+    euler_A = (mod.lora.lora_A.grad * mod.lora.lora_A.detach()).sum().item()      # ... and in A
+    assert abs(euler_B - delta_dot) < 2e-2 * abs(delta_dot)
+    assert abs(euler_A - delta_dot) < 2e-2 * abs(delta_dot)

@@ -35,18 +35,18 @@ class _Decoder(nn.Module):
 
     def forward(self, feat):                           # feat [B, C, h, w]
         B, C, h, w = feat.shape
-        tok = feat.flatten(2).transpose(1, 2)          # [B, hw, C]
+        tok = feat.flatten(2).transpose(1, 2).to(self.query.dtype)          # [B, hw, C]
         q = self.q_proj(self.query)[None].expand(B, -1, -1)
         att = torch.softmax(q @ tok.transpose(1, 2) / C ** 0.5, dim=-1)
         outs = []
         hs = q
         for _ in range(2):                              # two "layers": first is the aux output
             hs = hs + att @ self.v_proj(tok)
-            boxes = self.box(hs).sigmoid()
-            outs.append({"pred_logits": self.cls(hs), "pred_boxes": boxes, "pred_boxes_xyxy": box_cxcywh_to_xyxy(boxes),
-                         "presence_logit_dec": self.presence(hs.mean(1))})
+            boxes = self.box(hs).float().sigmoid()
+            outs.append({"pred_logits": self.cls(hs).float(), "pred_boxes": boxes, "pred_boxes_xyxy": box_cxcywh_to_xyxy(boxes),
+                         "presence_logit_dec": self.presence(hs.mean(1)).float()})
         final = outs[-1]
-        final["pred_masks"] = (hs @ tok.transpose(1, 2)).reshape(B, -1, h, w)
+        final["pred_masks"] = (hs @ tok.transpose(1, 2)).float().reshape(B, -1, h, w)
         final["aux_outputs"] = outs[:-1]
         return final
 
@@ -65,7 +65,7 @@ class ToySam3(nn.Module):
     def forward(self, batch: ToyBatch):
         x = batch.img_batch
         feat = self.backbone.vision_backbone.trunk(x.to(self.transformer.decoder.query.dtype))[-1]
-        return [self.transformer.decoder(feat.float())]            # one find stage
+        return [self.transformer.decoder(feat)]            # one find stage
 
     @staticmethod
     def back_convert(t):
