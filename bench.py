@@ -84,26 +84,34 @@ class Workload:
             params += [self.A1[b], self.B1[b], self.A2[b], self.B2[b]]
         self.reducer = LoRAGradReducer(params, bucket_bytes=8 << 20)
         self.params = params
-        self.tT1 = [None] * blocks
-        self.tT2 = [None] * blocks
+        self.P1 = [None] * blocks        # operand images of (A1, B1) / (A2, B2), re-packed every step
+        self.P2 = [None] * blocks
 
     def step(self):
-        from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
+        from sam3_lora_amd.functional import lora_bwd_, lora_fwd_, pack_operands
         s, L, dp = self.scaling, 0, self.dropout
+        prepack = os.environ.get("BENCH_PREPACK", "1") != "0"
         self.reducer.zero_grad()
         with torch.no_grad():
             for b in range(self.blocks):                       # forward
                 k = b & 1
-                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, drop_p=dp, seed=2 * b)
-                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, drop_p=dp, seed=2 * b + 1)
+                if prepack:     # A/B changed at the optimizer step: pack once, use for fwd, recompute and bwd
+                    self.P1[b] = pack_operands(self.A1[b], self.B1[b], L, out=self.P1[b])
+                    self.P2[b] = pack_operands(self.A2[b], self.B2[b], L, out=self.P2[b])
+                p1, p2 = (self.P1[b], self.P2[b]) if prepack else (None, None)
+                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, drop_p=dp, seed=2 * b, packed=p1)
+                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, drop_p=dp, seed=2 * b + 1, packed=p2)
             for b in reversed(range(self.blocks)):             # per-block recompute, then backward
                 k = b & 1
-                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True, drop_p=dp, seed=2 * b)
-                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True, drop_p=dp, seed=2 * b + 1)
+                p1, p2 = (self.P1[b], self.P2[b]) if prepack else (None, None)
+                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True, drop_p=dp, seed=2 * b,
+                               packed=p1)
+                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True, drop_p=dp,
+                               seed=2 * b + 1, packed=p2)
                 lora_bwd_(self.g2[k], self.h[k], t2, self.A2[b], self.B2[b], self.gh[k],
-                          self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b + 1)
+                          self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b + 1, packed=p2)
                 lora_bwd_(self.gh[k], self.x1[k], t1, self.A1[b], self.B1[b], self.g1[k],
-                          self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b)
+                          self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b, packed=p1)
                 for p in (self.A1[b], self.B1[b], self.A2[b], self.B2[b]):
                     self.reducer.notify(p)
         self.reducer.finish()
@@ -163,8 +171,10 @@ def insitu_kernels(w, steps=2):
         raise RuntimeError(_ffi.last_error())
     M, r = w.M, w.rank
     RP, e = (16 if r <= 16 else 32), 2
-    names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2", _ffi.STAGE_T3_GB: "k_t3",
-             _ffi.STAGE_T3_GA: "k_t3", _ffi.STAGE_REDUCE: "k_reduce"}
+    one_pass = r <= 16 and os.environ.get("SAM3_LORA_TWO_PASS_GY", "0") in ("", "0")
+    names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2",
+             _ffi.STAGE_T3_GB: "k_t3+gt" if one_pass else "k_t3", _ffi.STAGE_T3_GA: "k_t3",
+             _ffi.STAGE_REDUCE: "k_reduce", 64: "k_gt_reduce"}
 
     def alg_bytes(kernel, dim):
         if kernel == "k_t2":      # read + write Y[M,N]; read T[M,RP], W2t[N,RP]
@@ -173,6 +183,10 @@ def insitu_kernels(w, steps=2):
             return e * M * dim + e * RP * dim + 2 * e * M * RP
         if kernel == "k_t3":      # read X[M,N], TT[RP,M] (partials are overhead, not algorithmic)
             return e * M * dim + e * RP * M
+        if kernel == "k_t3+gt":   # one pass over gy: gB partials and gt (T, TT written by k_gt_reduce)
+            return e * M * dim + e * RP * M
+        if kernel == "k_gt_reduce":   # pure overhead of the one-pass form: fp32 gt partials back in, T and TT out
+            return -(-dim // 128) * M * 64 + 2 * e * M * RP
         if kernel == "k_reduce":  # read-modify-write fp32 gA, gB
             return 2 * 4 * r * dim
         return (4 + 2) * r * dim  # k_pack: read fp32, write bf16

@@ -46,6 +46,9 @@ extern "C" {
 
 #define SAM3_LORA_LAYOUT_ROOT 0
 #define SAM3_LORA_LAYOUT_PACKAGE 1
+/* OR-ed into `layout` of sam3_lora_fwd / sam3_lora_bwd: `A` is the blob written by sam3_lora_pack for the current
+ * values of A and B (and `B` is ignored).  The low bits still name the layout of gA_accum / gB_accum. */
+#define SAM3_LORA_PREPACKED 0x100
 
 #define SAM3_LORA_BF16 0
 #define SAM3_LORA_F32 1
@@ -67,6 +70,17 @@ size_t sam3_lora_saved_t_bytes(int64_t M, int rank);
 
 size_t sam3_lora_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype);
 size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype);
+
+/*
+ * Operand images.  Every fwd/bwd call first converts the fp32 masters into the bf16 MFMA operand images it needs
+ * (one small launch).  A and B only change at the optimizer step, while a training step calls fwd, the
+ * activation-checkpoint recompute fwd and bwd on the same values: sam3_lora_pack writes all images once into a
+ * caller-held blob (sam3_lora_packed_bytes, 256-byte aligned) that the three calls then take through
+ * `layout | SAM3_LORA_PREPACKED`.  The caller re-packs after A or B changed; results are bit-identical either way.
+ */
+size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank);
+int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, int out_features, int rank,
+                   int layout, void* stream);
 
 /*
  * Forward of the LoRA branch, fused with the residual add into the base output:
@@ -149,9 +163,10 @@ int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, con
 #define SAM3_LORA_STAGE_PACK 1u     /* k_pack   : fp32 A/B -> bf16 operand images              */
 #define SAM3_LORA_STAGE_T1 2u       /* k_t1     : t = x.A_c (fwd) / gt = gy.B_c^T (bwd)         */
 #define SAM3_LORA_STAGE_T2 4u       /* k_t2     : y += s.t.B_c (fwd) / gx += s.gt.A_c^T (bwd)   */
-#define SAM3_LORA_STAGE_T3_GB 8u    /* k_t3     : gB partials = t^T.gy                          */
+#define SAM3_LORA_STAGE_T3_GB 8u    /* k_t3     : gB partials = t^T.gy (+ gt partials, r <= 16) */
 #define SAM3_LORA_STAGE_T3_GA 16u   /* k_t3     : gA partials = gt^T.x                          */
 #define SAM3_LORA_STAGE_REDUCE 32u  /* k_reduce : fixed-order sum of the partials into gA/gB    */
+#define SAM3_LORA_STAGE_GT_REDUCE 64u /* k_gt_reduce : chunk sum of the gt partials k_t3 emitted (r <= 16)  */
 #define SAM3_LORA_STAGE_ALL 0xffffffffu
 unsigned sam3_lora_debug_set_stages(unsigned mask);
 

@@ -26,7 +26,9 @@ EXPORTS = (
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_aug_scatter", "sam3_lora_fused_workspace_bytes", "sam3_lora_fwd_fused", "sam3_lora_bwd_fused",
+    "sam3_lora_packed_bytes", "sam3_lora_pack",
 )
+PREPACKED = 0x100
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
 _lib = None
@@ -47,6 +49,10 @@ def _declare(lib):
     for f in (lib.sam3_lora_fwd_workspace_bytes, lib.sam3_lora_bwd_workspace_bytes):
         f.restype = c_size_t
         f.argtypes = [c_int64, c_int, c_int, c_int, c_int]
+    lib.sam3_lora_packed_bytes.restype = c_size_t
+    lib.sam3_lora_packed_bytes.argtypes = [c_int, c_int, c_int]
+    lib.sam3_lora_pack.restype = c_int
+    lib.sam3_lora_pack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.sam3_lora_fwd.restype = c_int
     lib.sam3_lora_fwd.argtypes = [
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,      # x, A, B, y_inout, tT_out

@@ -103,8 +103,12 @@ struct PackJob {
     int ldd;              // row pitch of dst in elements (0 => J); > J when packing into a slice of a wider buffer
 };
 
-__global__ __launch_bounds__(256) void k_pack(PackJob j0, PackJob j1) {
-    const PackJob jb = blockIdx.y == 0 ? j0 : j1;
+struct PackJobs {
+    PackJob j[4];
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
+    const PackJob jb = jobs.j[blockIdx.y];
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)jb.I * jb.J) return;
     const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
@@ -433,10 +437,16 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename XT, int RT, bool GATHER, bool DROP>
+// EMIT (r <= 16, backward over gy): the same pass also produces the row reduction gt = gy . B_c^T that k_t1 would
+// otherwise re-read gy for.  Each wave contracts its [32 rows x 128 cols] slab with the workgroup's 128 columns of
+// B_c (W1b image, held in registers) and writes the fp32 partial to GTP[column chunk][row][16]; k_gt_reduce sums the
+// chunks in fixed order.  Extra traffic: 2 x nchunks x M x 64 B (partials out and back) instead of M x N x 2 B.
+template <typename XT, int RT, bool GATHER, bool DROP, bool EMIT = false>
 __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
-                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk) {
+                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk,
+                                            const bf16_t* __restrict__ W1b = nullptr, float* __restrict__ GTP = nullptr) {
+    static_assert(!EMIT || (RT == 1 && !DROP), "gt emission: r <= 16, no dropout on the streamed tensor");
     constexpr int RP = RT * 16, CW = 128, CPR = 16;
     __shared__ uint4 xs[4][32 * CPR];      // 32 rows x 256 B per wave; reused as the reduction buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -474,6 +484,15 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 wb[EMIT ? 4 : 1];          // B operand of the gt contraction: B_c[r = n][c0 + ks*32 + g*8 .. +8]
+    if (EMIT) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cb = c0 + ks * 32 + g * 8;
+            wb[ks] = and4(*reinterpret_cast<const uint4*>(W1b + (long long)n * N + (cb < N ? cb : N - 8)),
+                          cb < N ? 0xffffffffu : 0u);
+        }
+    }
     uint4* slab = xs[wave];
     auto stage = [&](int s0, const Regs& r_) {
         const long long mb = w_begin + (long long)s0 * 32;
@@ -487,6 +506,23 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
             slab[row * CPR + (lc ^ (t3_h(row) << 1))] = v;
         }
         wave_sync();
+        if (EMIT && s0 < nst) {
+#pragma unroll
+            for (int rtile = 0; rtile < 2; ++rtile) {
+                f32x4 ga = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int row = rtile * 16 + n;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const uint4 xa = slab[row * CPR + ((ks * 4 + g) ^ (t3_h(row) << 1))];
+                    // D[i = row][n = rank idx] += sum_col gy[row][col] * B_c[rank idx][col]
+                    ga = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa),
+                                                                __builtin_bit_cast(bf16x8, wb[ks]), ga, 0, 0, 0);
+                }
+                float* gp = GTP + ((long long)blockIdx.x * Mp + mb + rtile * 16 + g * 4) * 16 + n;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) gp[jj * 16] = ga[jj];
+            }
+        }
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
             bf16x8 xf;
@@ -586,6 +622,31 @@ __global__ __launch_bounds__(256) void k_repack(const bf16_t* __restrict__ t, lo
 }
 
 // ------------------------------------------------------------------------------------------
+// gt = sum over column chunks (fixed order) of the fp32 partials k_t3<EMIT> wrote -> bf16 T[Mp, 16] row-major
+// (k_t2's operand) and TTf fragment-major (k_t3's operand), exactly the two images k_t1 would have produced.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP, int nchunks, bf16_t* __restrict__ T,
+                                                   bf16_t* __restrict__ TTf, long long Mp) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 4 consecutive rank entries
+    if (idx >= Mp * 4) return;
+    const long long m = idx >> 2;
+    const int r0 = (int)(idx & 3) * 4;
+    f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunks; ++c) s4 += *reinterpret_cast<const f32x4*>(GTP + ((long long)c * Mp + m) * 16 + r0);
+    uint2 v;
+    v.x = pack2(s4[0], s4[1]);
+    v.y = pack2(s4[2], s4[3]);
+    *reinterpret_cast<uint2*>(T + m * 16 + r0) = v;
+    const long long blk = m >> 5;
+    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
+    bf16_t* tb = TTf + ((blk * 4 + gq) * 16 + r0) * 8 + jq;
+    tb[0] = (bf16_t)(v.x & 0xffffu);
+    tb[8] = (bf16_t)(v.x >> 16);
+    tb[16] = (bf16_t)(v.y & 0xffffu);
+    tb[24] = (bf16_t)(v.y >> 16);
+}
+
+// ------------------------------------------------------------------------------------------
 // second-stage, fixed-order reduction of the T3 partials into the fp32 gradient tensors
 //   dst[r*sr + n*sn] (+)= scale * sum_rs part[rs][r][n]
 // ------------------------------------------------------------------------------------------
@@ -671,6 +732,7 @@ struct T3Plan {
     int nchunks, NR, rows_per_wg, br;
 };
 bool env_flag(const char* name);
+long long env_int(const char* name, long long dflt);
 
 T3Plan plan_t3(long long Mp, int N, int RT) {
     // workgroup = 128 columns x a row group (4 waves x a quarter each, 32-row steps).  ~190 VGPRs allow
@@ -680,7 +742,7 @@ T3Plan plan_t3(long long Mp, int N, int RT) {
     p.br = 32;
     p.nchunks = (N + 127) / 128;
     const long long units = (Mp + 127) / 128;          // 128-row units (4 waves x 32 rows)
-    long long nrg = (RT == 2 ? 256 : 512) / p.nchunks;   // r > 16: ~230 VGPRs, one workgroup per CU
+    long long nrg = env_int("SAM3_LORA_T3_WGS", RT == 2 ? 256 : 512) / p.nchunks;   // r > 16: ~230 VGPRs, one workgroup per CU
     if (nrg > units) nrg = units;
     if (nrg < 1) nrg = 1;
     const long long upg = (units + nrg - 1) / nrg;     // units per row group
@@ -733,6 +795,10 @@ bool env_flag(const char* name) {
     const char* v = getenv(name);
     return v && v[0] && v[0] != '0';
 }
+long long env_int(const char* name, long long dflt) {
+    const char* v = getenv(name);
+    return (v && v[0]) ? atoll(v) : dflt;
+}
 
 // strides of the canonical views A_c[in, r], B_c[r, out] inside the caller's tensors
 struct Strides {
@@ -774,12 +840,39 @@ struct ProfScope {
     }
 };
 
+void launch_pack(const PackJob* jobs, int n, hipStream_t st) {
+    PackJobs pj;
+    long long nmax = 0;
+    int dim = 0;
+    for (int i = 0; i < 4; ++i) {
+        pj.j[i] = i < n ? jobs[i] : PackJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+        const long long ne = (long long)pj.j[i].I * pj.j[i].J;
+        nmax = ne > nmax ? ne : nmax;
+        dim = pj.j[i].J > dim ? pj.j[i].J : dim;
+    }
+    dim3 grid((unsigned)((nmax + 255) / 256), (unsigned)n);
+    ProfScope ps(SAM3_LORA_STAGE_PACK, dim, st);
+    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, pj);
+}
 void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
-    const long long na = (long long)a.I * a.J, nb = (long long)b.I * b.J;
-    const long long nmax = na > nb ? na : nb;
-    dim3 grid((unsigned)((nmax + 255) / 256), 2);
-    ProfScope ps(SAM3_LORA_STAGE_PACK, a.J > b.J ? a.J : b.J, st);
-    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, a, b);
+    const PackJob jobs[2] = {a, b};
+    launch_pack(jobs, b.dst ? 2 : 1, st);
+}
+
+// caller-held operand images (sam3_lora_pack): [ W1 = A_c^T | W2t = B_c^T | W1b = B_c | W2tb = A_c ], bf16
+struct PackedLayout {
+    size_t w1, w2t, w1b, w2tb, total;
+};
+PackedLayout packed_layout(int in_f, int out_f, int rank) {
+    const int RP = rpad(rank);
+    PackedLayout p;
+    size_t off = 0;
+    p.w1 = off; off += al256((size_t)RP * round_up(in_f, 128) * 2);
+    p.w2t = off; off += al256((size_t)out_f * RP * 2);
+    p.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * 2);
+    p.w2tb = off; off += al256((size_t)in_f * RP * 2);
+    p.total = off;
+    return p;
 }
 
 template <typename XT>
@@ -798,10 +891,11 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
                hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
-    long long want = (3072 + nchunks - 1) / nchunks;  // ~3k workgroups of 4 waves
-    long long tiles_per_wg = (ntiles + want - 1) / want;
-    if (tiles_per_wg < 4) tiles_per_wg = 4;
-    tiles_per_wg = round_up(tiles_per_wg, 4);
+    // 3 tiles per wave measured best on MI355X for both N = 4736 and N = 1024 at M = 41472 (sweep 4..48:
+    // 121 / 36 us at 12 vs 125 / 37 us at 32 / 8); fewer per workgroup only when that leaves too few workgroups.
+    long long tiles_per_wg = 12;
+    while (tiles_per_wg > 4 && nchunks * ((ntiles + tiles_per_wg - 1) / tiles_per_wg) < 1024) tiles_per_wg -= 4;
+    tiles_per_wg = env_int("SAM3_LORA_T2_TPW", tiles_per_wg);
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
 #define T2_LAUNCH(RTV, DV) \
@@ -831,6 +925,21 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
 #undef T3_LAUNCH
 }
 
+// gB partials AND gt partials from one pass over gy (r <= 16); then the fixed-order chunk sum -> GT / GTT images
+template <typename XT>
+void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N,
+                    const T3Plan& p, const bf16_t* W1b, float* GTP, bf16_t* GT, bf16_t* GTT, hipStream_t st) {
+    dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
+    {
+        ProfScope ps(SAM3_LORA_STAGE_T3_GB, N, st);
+        hipLaunchKernelGGL((k_t3<XT, 1, false, false, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N,
+                           p.rows_per_wg, DropKey{0u, 0u, 0}, W1b, GTP);
+    }
+    ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, N, st);
+    hipLaunchKernelGGL(k_gt_reduce, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, p.nchunks,
+                       GT, GTT, Mp);
+}
+
 struct FwdWs {
     size_t w1, w2t, t, tt, total;
 };
@@ -848,7 +957,7 @@ FwdWs fwd_ws(long long M, int in_f, int out_f, int rank) {
 }
 
 struct BwdWs {
-    size_t w1b, w2tb, w1a, gt, gtt, t, tt, pb, pa, total;
+    size_t w1b, w2tb, w1a, gt, gtt, t, tt, pb, pa, gtp, total;
     T3Plan pB, pA;
 };
 BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
@@ -867,6 +976,7 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
     w.tt = off; off += al256((size_t)RP * Mp * 2);
     w.pb = off; off += al256((size_t)w.pB.NR * RP * out_f * 4);
     w.pa = off; off += al256((size_t)w.pA.NR * RP * in_f * 4);
+    w.gtp = off; off += RP == 16 ? al256((size_t)w.pB.nchunks * Mp * 16 * 4) : 0;     // gt partials (r <= 16)
     w.total = off;
     return w;
 }
@@ -935,6 +1045,31 @@ size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_feature
     return bwd_ws(M, in_features, out_features, rank).total;
 }
 
+size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank) {
+    if (check_common(1, in_features, out_features, rank, 0, SAM3_LORA_BF16)) return 0;
+    return packed_layout(in_features, out_features, rank).total;
+}
+
+int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, int out_features, int rank, int layout,
+                   void* stream) {
+    g_err[0] = 0;
+    int rc;
+    if ((rc = check_common(1, in_features, out_features, rank, layout, SAM3_LORA_BF16))) return rc;
+    if (!A || !B || !packed) return fail(SAM3_LORA_EINVAL, "NULL pointer");
+    if (((uintptr_t)packed & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
+    const int RP = rpad(rank);
+    const PackedLayout pl = packed_layout(in_features, out_features, rank);
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+    char* p = (char*)packed;
+    const PackJob jobs[4] = {
+        {(const float*)A, (bf16_t*)(p + pl.w1), RP, in_features, rank, in_features, s.a_sr, s.a_si, 0},
+        {(const float*)B, (bf16_t*)(p + pl.w2t), out_features, RP, out_features, rank, s.b_so, s.b_sr, 0},
+        {(const float*)B, (bf16_t*)(p + pl.w1b), RP, out_features, rank, out_features, s.b_sr, s.b_so, 0},
+        {(const float*)A, (bf16_t*)(p + pl.w2tb), in_features, RP, in_features, rank, s.a_si, s.a_sr, 0}};
+    launch_pack(jobs, 4, (hipStream_t)stream);
+    return launch_ok("sam3_lora_pack");
+}
+
 int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
                   int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
                   float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
@@ -942,10 +1077,13 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
     if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
+    const bool pre = (layout & SAM3_LORA_PREPACKED) != 0;
+    layout &= ~SAM3_LORA_PREPACKED;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if ((rc = check_act(y_inout, ldy, out_features, dtype, "y_inout"))) return rc;
-    if (!A || !B) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
+    if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
+    if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
     float inv_keep; const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
     const FwdWs w = fwd_ws(M, in_features, out_features, rank);
     if (!workspace || workspace_bytes < w.total)
@@ -957,16 +1095,19 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
     const int RP = rpad(rank), RT = RP / 16;
     const long long Mp = round_up(M, 64);
     char* ws = (char*)workspace;
-    bf16_t* W1 = (bf16_t*)(ws + w.w1);
-    bf16_t* W2t = (bf16_t*)(ws + w.w2t);
+    const PackedLayout pl = packed_layout(in_features, out_features, rank);
+    bf16_t* W1 = pre ? (bf16_t*)((char*)A + pl.w1) : (bf16_t*)(ws + w.w1);
+    bf16_t* W2t = pre ? (bf16_t*)((char*)A + pl.w2t) : (bf16_t*)(ws + w.w2t);
     bf16_t* T = (bf16_t*)(ws + w.t);
     bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
     const Strides s = strides_of(layout, in_features, out_features, rank);
 
     // W1[RP][in] = A_c^T ; W2t[out][RP] = B_c^T
-    PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0};
-    PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0};
-    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(ja, jb, st);
+    if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
+        PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0};
+        PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0};
+        launch_pack(ja, jb, st);
+    }
     if (dtype == SAM3_LORA_BF16) {
         if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
         if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st);
@@ -984,11 +1125,14 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
+    const bool pre = (layout & SAM3_LORA_PREPACKED) != 0;
+    layout &= ~SAM3_LORA_PREPACKED;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
     if ((rc = check_act(gy, ldgy, out_features, dtype, "gy"))) return rc;
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
-    if (!A || !B) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
+    if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
+    if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
     float inv_keep; const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
     if (tT_saved && ((uintptr_t)tT_saved & 15)) return fail(SAM3_LORA_EINVAL, "tT_saved must be 16-byte aligned");
     const BwdWs w = bwd_ws(M, in_features, out_features, rank);
@@ -1000,9 +1144,10 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     const int RP = rpad(rank), RT = RP / 16;
     const long long Mp = round_up(M, 64);
     char* ws = (char*)workspace;
-    bf16_t* W1b = (bf16_t*)(ws + w.w1b);
-    bf16_t* W2tb = (bf16_t*)(ws + w.w2tb);
-    bf16_t* W1a = (bf16_t*)(ws + w.w1a);
+    const PackedLayout pl = packed_layout(in_features, out_features, rank);
+    bf16_t* W1b = pre ? (bf16_t*)((char*)A + pl.w1b) : (bf16_t*)(ws + w.w1b);
+    bf16_t* W2tb = pre ? (bf16_t*)((char*)A + pl.w2tb) : (bf16_t*)(ws + w.w2tb);
+    bf16_t* W1a = pre ? (bf16_t*)((char*)A + pl.w1) : (bf16_t*)(ws + w.w1a);
     bf16_t* GT = (bf16_t*)(ws + w.gt);
     bf16_t* GTT = (bf16_t*)(ws + w.gtt);
     bf16_t* Tscr = (bf16_t*)(ws + w.t);
@@ -1012,14 +1157,14 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     const Strides s = strides_of(layout, in_features, out_features, rank);
 
     // W1b[RP][out] = B_c ; W2tb[in][RP] = A_c
-    PackJob jb{(const float*)B, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so, 0};
-    PackJob ja{(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0};
-    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(jb, ja, st);
+    if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
+        PackJob jobs[3] = {{(const float*)B, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so, 0},
+                           {(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0},
+                           {(const float*)A, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0}};
+        launch_pack(jobs, TT ? 2 : 3, st);
+    }
     const bool bf = dtype == SAM3_LORA_BF16;
     if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
-        PackJob j1{(const float*)A, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0};
-        PackJob j2{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
-        launch_pack(j1, j2, st);
         bf16_t* TTs = (bf16_t*)(ws + w.tt);
         if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk);
         else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk);
@@ -1027,7 +1172,20 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     }
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
     const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
-    if (bf) {
+    // r <= 16 with weight gradients wanted: gy is read ONCE -- k_t3 emits the gt partials beside the gB partials
+    const bool one_pass = RT == 1 && gB_accum && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
+    float* GTP = (float*)(ws + w.gtp);
+    if (one_pass) {
+        if (bf) launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, W1b, GTP, GT, GTT, st);
+        else launch_t3_emit<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, W1b, GTP, GT, GTT, st);
+        if (bf) {
+            if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
+            if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
+        } else {
+            if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
+            if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
+        }
+    } else if (bf) {
         if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
         if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);     // gA^T = gt^T . x

@@ -21,9 +21,9 @@ import torch
 import torch.nn.functional as F
 
 from . import _ffi
-from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, LoRAKernelError
+from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
-__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
+__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
 
 _ws_lock = threading.Lock()
 _workspaces = {}  # (device index, stream handle) -> uint8 tensor
@@ -104,8 +104,45 @@ def saved_t_like(M: int, rank: int, device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+def pack_operands(A: torch.Tensor, B: torch.Tensor, layout: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 operand images of the current A/B for ``lora_fwd_/lora_bwd_(..., packed=blob)`` (sam3_lora_pack)."""
+    lib = _ffi.load()
+    _require_cuda(A, B)
+    rank = _rank_of(A, layout)
+    fin = A.shape[0] if layout == LAYOUT_ROOT else A.shape[1]
+    fout = B.shape[1] if layout == LAYOUT_ROOT else B.shape[0]
+    n = lib.sam3_lora_packed_bytes(fin, fout, rank)
+    if n == 0:
+        raise LoRAKernelError(f"sam3_lora_packed_bytes: {_ffi.last_error()}")
+    if out is None or out.numel() != n or out.device != A.device:
+        out = torch.empty(n, dtype=torch.uint8, device=A.device)
+    rc = lib.sam3_lora_pack(A.data_ptr(), B.data_ptr(), out.data_ptr(), fin, fout, rank, layout,
+                            ctypes.c_void_p(torch.cuda.current_stream(A.device).cuda_stream))
+    _ffi.check(rc, "sam3_lora_pack")
+    return out
+
+
+class PackedOperands:
+    """Per-module cache of the operand images, refreshed when A or B changed (torch version counters: the
+    optimizer step, ``load_state_dict`` and ``copy_`` all bump them; re-pointing ``.data`` changes the address).
+    The blob a step's forward used stays valid for its recompute and backward: a refresh allocates a new tensor
+    whenever the previous one may still be referenced by a saved autograd context."""
+
+    def __init__(self):
+        self.blob = None
+        self._stamp = None
+
+    def get(self, A: torch.Tensor, B: torch.Tensor, layout: int) -> torch.Tensor:
+        stamp = (A.data_ptr(), A._version, B.data_ptr(), B._version, layout, A.device)
+        if stamp != self._stamp:
+            self.blob = pack_operands(_master(A), _master(B), layout)
+            self._stamp = stamp
+        return self.blob
+
+
 def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tensor, scaling: float, layout: int,
-              save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0) -> Optional[torch.Tensor]:
+              save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
+              packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """In place: y2[M,out] += scaling * (x2[M,in] @ A_c) @ B_c.  Returns the saved-t blob if asked."""
     lib = _ffi.load()
     _require_cuda(x2, A, B, y2)
@@ -121,8 +158,9 @@ def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tens
     ws = _workspace(x2.device, nws)
     tT = saved_t_like(M, rank, x2.device) if save_t else None
     rc = lib.sam3_lora_fwd(
-        x2.data_ptr(), A.data_ptr(), B.data_ptr(), y2.data_ptr(), tT.data_ptr() if tT is not None else None,
-        M, fin, fout, rank, x2.stride(0), y2.stride(0), layout, float(scaling),
+        x2.data_ptr(), (packed if packed is not None else A).data_ptr(), B.data_ptr(), y2.data_ptr(),
+        tT.data_ptr() if tT is not None else None,
+        M, fin, fout, rank, x2.stride(0), y2.stride(0), layout | (PREPACKED if packed is not None else 0), float(scaling),
         float(drop_p), int(seed), int(offset), dt, ws.data_ptr(), ws.numel(),
         ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
     _ffi.check(rc, "sam3_lora_fwd")
@@ -131,7 +169,8 @@ def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tens
 
 def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor,
               gx2: Optional[torch.Tensor], gA: Optional[torch.Tensor], gB: Optional[torch.Tensor], scaling: float,
-              layout: int, accumulate: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0) -> None:
+              layout: int, accumulate: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
+              packed: Optional[torch.Tensor] = None) -> None:
     """In place: gx2 += lora input-grad; gA/gB (fp32, caller layout) = or += the LoRA weight grads."""
     lib = _ffi.load()
     _require_cuda(gy2, x2, A, B, gx2, gA, gB)
@@ -149,11 +188,13 @@ def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A
         raise LoRAKernelError(f"sam3_lora_bwd_workspace_bytes: {_ffi.last_error()}")
     ws = _workspace(x2.device, nws)
     rc = lib.sam3_lora_bwd(
-        gy2.data_ptr(), x2.data_ptr(), tT.data_ptr() if tT is not None else None, A.data_ptr(), B.data_ptr(),
+        gy2.data_ptr(), x2.data_ptr(), tT.data_ptr() if tT is not None else None,
+        (packed if packed is not None else A).data_ptr(), B.data_ptr(),
         gx2.data_ptr() if gx2 is not None else None,
         gA.data_ptr() if gA is not None else None, gB.data_ptr() if gB is not None else None,
         M, fin, fout, rank, gy2.stride(0), x2.stride(0), gx2.stride(0) if gx2 is not None else fin,
-        layout, float(scaling), float(drop_p), int(seed), int(offset), dt, 1 if accumulate else 0,
+        layout | (PREPACKED if packed is not None else 0), float(scaling), float(drop_p), int(seed), int(offset), dt,
+        1 if accumulate else 0,
         ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
     _ffi.check(rc, "sam3_lora_bwd")
 
@@ -175,7 +216,7 @@ class _LoRALinearFn(torch.autograd.Function):
     """Frozen linear + LoRA branch as one autograd node (saved tensors: x, t^T -- never y or delta)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_p, seed):
+    def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_p, seed, packed=None):
         _require_cuda(x, weight, A, B)
         ref = weight if weight is not None else x        # weight None: bare LoRA branch (zero base)
         cdt = ref.dtype if ref.dtype in (torch.bfloat16, torch.float32) else torch.float32
@@ -196,6 +237,7 @@ class _LoRALinearFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         fin, fout = x2.shape[1], y2.shape[1]
         ctx.pad = None
+        ctx.packed = None
         tT = None
         if x2.shape[0] == 0:
             pass                                         # no rows (e.g. no geometric prompts): y is empty, grads are zero
@@ -209,7 +251,8 @@ class _LoRALinearFn(torch.autograd.Function):
             tT = lora_fwd_(x2, Ap, Bp, delta, scaling, layout, save_t=need_w, drop_p=drop_p, seed=seed)
             y2 = y2 + delta[:, :fout]
         else:
-            tT = lora_fwd_(x2, Am, Bm, y2, scaling, layout, save_t=need_w, drop_p=drop_p, seed=seed)
+            ctx.packed = packed
+            tT = lora_fwd_(x2, Am, Bm, y2, scaling, layout, save_t=need_w, drop_p=drop_p, seed=seed, packed=packed)
         ctx.scaling, ctx.layout, ctx.drop_p, ctx.seed = scaling, layout, drop_p, seed
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         ctx.save_for_backward(x2, w, A, B, tT)
@@ -250,12 +293,12 @@ class _LoRALinearFn(torch.autograd.Function):
                 gB.copy_(gBp[:, :fout] if root else gBp[:fout])
         elif need_x or need_w:
             lora_bwd_(gy2, x2, tT, Am, Bm, gx2, gA, gB, ctx.scaling, ctx.layout,
-                      drop_p=ctx.drop_p, seed=ctx.seed)
+                      drop_p=ctx.drop_p, seed=ctx.seed, packed=ctx.packed)
         gx = gx2.view(ctx.x_shape).to(ctx.x_dtype) if need_x else None
         if need_w:
             gA = gA.to(A.dtype) if ctx.needs_input_grad[3] else None
             gB = gB.to(B.dtype) if ctx.needs_input_grad[4] else None
-        return gx, None, None, gA, gB, None, None, None, None
+        return gx, None, None, gA, gB, None, None, None, None, None
 
 
 class AugmentedWeight:
@@ -374,7 +417,8 @@ def fused_mode_enabled() -> bool:
 
 def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], A: torch.Tensor,
                 B: torch.Tensor, scaling: float, layout: int, dropout_p: float = 0.0,
-                training: bool = False, aug: Optional[AugmentedWeight] = None) -> torch.Tensor:
+                training: bool = False, aug: Optional[AugmentedWeight] = None,
+                cache: Optional[PackedOperands] = None) -> torch.Tensor:
     """``F.linear(x, weight, bias) + scaling * (dropout(x) @ A_c) @ B_c`` on the HIP path.
 
     ``layout`` selects how A/B are stored (LAYOUT_ROOT: A[in,r], B[r,out]; LAYOUT_PACKAGE:
@@ -397,4 +441,10 @@ def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[
         Waug, bias_aug, RP = aug.ensure(weight, bias, A, B, layout)
         return _LoRALinearFusedFn.apply(x, Waug, bias_aug, A, B, float(scaling), int(layout), weight.shape[1],
                                         weight.shape[0], RP)
-    return _LoRALinearFn.apply(x, weight, bias, A, B, float(scaling), int(layout), p, seed)
+    packed = None
+    if cache is not None and A.is_cuda and x.numel() > 0:
+        fin = A.shape[0] if layout == LAYOUT_ROOT else A.shape[1]
+        fout = B.shape[1] if layout == LAYOUT_ROOT else B.shape[0]
+        if fin % 8 == 0 and fout % 8 == 0:
+            packed = cache.get(A, B, int(layout))
+    return _LoRALinearFn.apply(x, weight, bias, A, B, float(scaling), int(layout), p, seed, packed)

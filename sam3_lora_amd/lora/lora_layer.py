@@ -13,7 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
-from ..functional import LAYOUT_PACKAGE, AugmentedWeight, lora_linear, merge_weight
+from ..functional import LAYOUT_PACKAGE, AugmentedWeight, PackedOperands, lora_linear, merge_weight
 
 
 class LoRALayer(nn.Module):
@@ -28,6 +28,7 @@ class LoRALayer(nn.Module):
         self.lora_A = nn.Parameter(torch.zeros(rank, in_features))
         self.lora_B = nn.Parameter(torch.zeros(out_features, rank))
         self.dropout = nn.Dropout(p=dropout) if dropout > 0.0 else nn.Identity()
+        self._packed = PackedOperands()   # bf16 operand images of A/B, re-packed when they change (not state)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -41,7 +42,7 @@ class LoRALayer(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return lora_linear(x, None, None, self.lora_A, self.lora_B, self.scaling, LAYOUT_PACKAGE,
-                           self.dropout_p, self.training)
+                           self.dropout_p, self.training, cache=self._packed)
 
     def merge_weights(self) -> torch.Tensor:
         """``(lora_B @ lora_A) * scaling`` as an [out, in] fp32 matrix."""
@@ -73,7 +74,7 @@ class LinearWithLoRA(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lo = self.lora
         return lora_linear(x, self.linear.weight, self.linear.bias, lo.lora_A, lo.lora_B, lo.scaling,
-                           LAYOUT_PACKAGE, lo.dropout_p, self.training, aug=self._aug)
+                           LAYOUT_PACKAGE, lo.dropout_p, self.training, aug=self._aug, cache=lo._packed)
 
     def merge_weights(self) -> nn.Linear:
         """A plain nn.Linear whose weight is ``W + scaling * B @ A`` (bias cloned)."""

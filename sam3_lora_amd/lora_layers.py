@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from .functional import LAYOUT_ROOT, AugmentedWeight, lora_linear
+from .functional import LAYOUT_ROOT, AugmentedWeight, PackedOperands, lora_linear
 
 __all__ = [
     "LoRALayer", "LoRALinear", "LoRAConfig", "apply_lora_to_model", "get_lora_parameters",
@@ -46,6 +46,7 @@ class LoRALayer(nn.Module):
         self.lora_A = nn.Parameter(a)
         self.lora_B = nn.Parameter(torch.zeros(rank, out_features))
         self.dropout = nn.Dropout(p=dropout) if dropout > 0 else nn.Identity()
+        self._packed = PackedOperands()   # bf16 operand images of A/B, re-packed when they change (not state)
 
     @property
     def dropout_p(self) -> float:
@@ -53,7 +54,7 @@ class LoRALayer(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return lora_linear(x, None, None, self.lora_A, self.lora_B, self.scaling, LAYOUT_ROOT,
-                           self.dropout_p, self.training)
+                           self.dropout_p, self.training, cache=self._packed)
 
 
 class LoRALinear(nn.Module):
@@ -71,7 +72,7 @@ class LoRALinear(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lo = self.lora
         return lora_linear(x, self.original_layer.weight, self.original_layer.bias, lo.lora_A, lo.lora_B,
-                           lo.scaling, LAYOUT_ROOT, lo.dropout_p, self.training, aug=self._aug)
+                           lo.scaling, LAYOUT_ROOT, lo.dropout_p, self.training, aug=self._aug, cache=lo._packed)
 
 
 class LoRAConfig:

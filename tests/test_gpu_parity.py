@@ -436,3 +436,81 @@ def test_odd_width_dropout_is_consistent_between_forward_and_backward():
     euler_A = (mod.lora.lora_A.grad * mod.lora.lora_A.detach()).sum().item()      # ... and in A
     assert abs(euler_B - delta_dot) < 2e-2 * abs(delta_dot)
     assert abs(euler_A - delta_dot) < 2e-2 * abs(delta_dot)
+
+
+@pytest.mark.parametrize("layout", [cases.LAYOUT_ROOT, cases.LAYOUT_PACKAGE])
+@pytest.mark.parametrize("rank", [4, 16, 24])
+@pytest.mark.parametrize("drop", [0.0, 0.25])
+def test_prepacked_operands_are_bit_identical(layout, rank, drop):
+    """sam3_lora_pack + layout|SAM3_LORA_PREPACKED == the per-call packing, bit for bit, in both directions and in
+    the recompute-t backward."""
+    g = torch.Generator(device=DEV).manual_seed(rank)
+    M, fin, fout = 1000, 264, 520
+    x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    a_shape, b_shape = ((fin, rank), (rank, fout)) if layout == cases.LAYOUT_ROOT else ((rank, fin), (fout, rank))
+    A = torch.randn(a_shape, device=DEV, generator=g)
+    B = torch.randn(b_shape, device=DEV, generator=g)
+    blob = Fn.pack_operands(A, B, layout)
+    outs = []
+    for packed in (None, blob):
+        y = torch.ones(M, fout, device=DEV, dtype=torch.bfloat16)
+        tT = Fn.lora_fwd_(x, A, B, y, 2.0, layout, save_t=True, drop_p=drop, seed=3, packed=packed)
+        gx = torch.ones(M, fin, device=DEV, dtype=torch.bfloat16)
+        gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+        Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, 2.0, layout, drop_p=drop, seed=3, packed=packed)
+        gA2, gB2 = torch.zeros_like(A), torch.zeros_like(B)
+        Fn.lora_bwd_(gy, x, None, A, B, None, gA2, gB2, 2.0, layout, drop_p=drop, seed=3, packed=packed)
+        outs.append((y, tT, gx, gA, gB, gA2, gB2))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+
+
+def test_module_repacks_when_parameters_change():
+    lin = torch.nn.Linear(64, 64)
+    mod = root_api.LoRALinear(lin, rank=4, alpha=8).to(DEV)
+    torch.nn.init.normal_(mod.lora.lora_B)
+    x = torch.randn(32, 64, device=DEV)
+    y0 = mod(x).detach().clone()
+    blob0 = mod.lora._packed.blob
+    assert blob0 is not None and mod(x) is not None and mod.lora._packed.blob is blob0      # cached
+    with torch.no_grad():
+        mod.lora.lora_B.mul_(2.0)                                                               # optimizer-like in-place update
+    y1 = mod(x).detach()
+    base = lin(x).detach()
+    assert mod.lora._packed.blob is not blob0
+    assert _relmax((y1 - base).cpu().numpy(), 2 * (y0 - base).cpu().numpy()) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(1000, 264, 520, 16), (4097, 1024, 4736, 16), (77, 64, 128, 3), (5184, 4736, 1024, 8)])
+def test_one_pass_backward_matches_two_pass(shape, dtype, monkeypatch):
+    """r <= 16: gt comes out of the gB pass over gy (k_t3 emitting partials + k_gt_reduce) instead of a second
+    read of gy by k_t1.  Same math, different fp32 summation order: gx / gA agree to bf16 rounding of gt, gB (which
+    does not depend on gt) bit for bit; both agree with the fp64 oracle."""
+    M, fin, fout, rank = shape
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x = torch.randn(M, fin, device=DEV, generator=g).to(td)
+    gy = torch.randn(M, fout, device=DEV, generator=g).to(td)
+    A = torch.randn(fin, rank, device=DEV, generator=g) / fin ** 0.5
+    B = torch.randn(rank, fout, device=DEV, generator=g) / fout ** 0.5
+    res = {}
+    for mode in ("one", "two"):
+        if mode == "two":
+            monkeypatch.setenv("SAM3_LORA_TWO_PASS_GY", "1")
+        y = torch.zeros(M, fout, device=DEV, dtype=td)
+        tT = Fn.lora_fwd_(x, A, B, y, 2.0, cases.LAYOUT_ROOT, save_t=True)
+        gx = torch.zeros(M, fin, device=DEV, dtype=td)
+        gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+        Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, 2.0, cases.LAYOUT_ROOT)
+        res[mode] = (gx.float().cpu().numpy(), gA.cpu().numpy(), gB.cpu().numpy())
+    assert np.array_equal(res["one"][2], res["two"][2])
+    assert _relmax(res["one"][0], res["two"][0]) < 1e-2
+    assert _relmax(res["one"][1], res["two"][1]) < 5e-3
+    if M <= 5184:
+        gx_r, gA_r, gB_r = O.adapter_backward(gy.float().cpu().numpy(), x.float().cpu().numpy(), A.cpu().numpy(),
+                                              B.cpu().numpy(), 2.0, cases.LAYOUT_ROOT, acc_dtype=np.float64)
+        assert _relmax(res["one"][0], gx_r) < 1e-2
+        assert _relmax(res["one"][1], gA_r) < 1e-2
+        assert _relmax(res["one"][2], gB_r) < 1e-2

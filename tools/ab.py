@@ -21,10 +21,12 @@ def main():
     order = [None] + flags
     for rep in range(2):
         for f in order:
-            for g in flags:
-                os.environ[g] = "0"
+            for g in flags:                      # "NAME" toggles 0/1, "NAME=VALUE" sets a value (unset = default)
+                os.environ.pop(g.split("=")[0], None)
+                if "=" not in g:
+                    os.environ[g] = "0"
             if f:
-                os.environ[f] = "1"
+                os.environ[f.split("=")[0]] = f.split("=")[1] if "=" in f else "1"
             w.step()
             torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
