@@ -437,16 +437,10 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-// EMIT (r <= 16, backward over gy): the same pass also produces the row reduction gt = gy . B_c^T that k_t1 would
-// otherwise re-read gy for.  Each wave contracts its [32 rows x 128 cols] slab with the workgroup's 128 columns of
-// B_c (W1b image, held in registers) and writes the fp32 partial to GTP[column chunk][row][16]; k_gt_reduce sums the
-// chunks in fixed order.  Extra traffic: 2 x nchunks x M x 64 B (partials out and back) instead of M x N x 2 B.
-template <typename XT, int RT, bool GATHER, bool DROP, bool EMIT = false>
+template <typename XT, int RT, bool GATHER, bool DROP>
 __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
-                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk,
-                                            const bf16_t* __restrict__ W1b = nullptr, float* __restrict__ GTP = nullptr) {
-    static_assert(!EMIT || (RT == 1 && !DROP), "gt emission: r <= 16, no dropout on the streamed tensor");
+                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk) {
     constexpr int RP = RT * 16, CW = 128, CPR = 16;
     __shared__ uint4 xs[4][32 * CPR];      // 32 rows x 256 B per wave; reused as the reduction buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -484,15 +478,6 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint4 wb[EMIT ? 4 : 1];          // B operand of the gt contraction: B_c[r = n][c0 + ks*32 + g*8 .. +8]
-    if (EMIT) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cb = c0 + ks * 32 + g * 8;
-            wb[ks] = and4(*reinterpret_cast<const uint4*>(W1b + (long long)n * N + (cb < N ? cb : N - 8)),
-                          cb < N ? 0xffffffffu : 0u);
-        }
-    }
     uint4* slab = xs[wave];
     auto stage = [&](int s0, const Regs& r_) {
         const long long mb = w_begin + (long long)s0 * 32;
@@ -506,23 +491,6 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
             slab[row * CPR + (lc ^ (t3_h(row) << 1))] = v;
         }
         wave_sync();
-        if (EMIT && s0 < nst) {
-#pragma unroll
-            for (int rtile = 0; rtile < 2; ++rtile) {
-                f32x4 ga = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const int row = rtile * 16 + n;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const uint4 xa = slab[row * CPR + ((ks * 4 + g) ^ (t3_h(row) << 1))];
-                    // D[i = row][n = rank idx] += sum_col gy[row][col] * B_c[rank idx][col]
-                    ga = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa),
-                                                                __builtin_bit_cast(bf16x8, wb[ks]), ga, 0, 0, 0);
-                }
-                float* gp = GTP + ((long long)blockIdx.x * Mp + mb + rtile * 16 + g * 4) * 16 + n;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) gp[jj * 16] = ga[jj];
-            }
-        }
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
             bf16x8 xf;
@@ -598,6 +566,150 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
 }
 
 // ------------------------------------------------------------------------------------------
+// T3E (r <= 16, backward over gy): ONE pass over gy produces both the column reduction gB = t^T . gy (as k_t3) and
+// the row reduction gt = gy . B_c^T that k_t1 would otherwise re-read gy for.  A workgroup owns TWO 128-column chunks
+// of a row group; each wave streams its rows as sub-steps (rows of step s, chunk 0), (rows of step s, chunk 1) through
+// its private slab: the distance-1 prefetch of k_t3 with the two named register sets bound to the two chunks.
+// Per sub-step: 8 tr-read MFMAs into that chunk's gB accumulators + 8 row-major MFMAs contracting the slab with the
+// chunk's 128 columns of B_c (W1b image, in registers) into the step's gt partial, written after the second chunk to
+// GTP[column pair][row][16] (fp32).  k_gt_reduce sums the pairs in fixed order.  Extra traffic: 2 x ceil(N/256) x M
+// x 64 B (partials out and back, 100 MB at N = 4736) instead of a second M x N x 2 B read (393 MB).
+// ------------------------------------------------------------------------------------------
+template <typename XT>
+__global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf,
+                                             float* __restrict__ Gpart, long long M, long long Mp, int N,
+                                             int rows_per_wg, const bf16_t* __restrict__ W1b,
+                                             float* __restrict__ GTP) {
+    constexpr int RP = 16, CPR = 16;
+    __shared__ uint4 xs[4][32 * CPR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.x * 256;
+    const int rg = (int)blockIdx.y;
+    const long long w_begin = (long long)rg * rows_per_wg + (long long)wave * (rows_per_wg / 4);
+    long long w_end = w_begin + rows_per_wg / 4;
+    if (w_end > Mp) w_end = Mp;
+    const int nst = w_end > w_begin ? (int)((w_end - w_begin) / 32) : 0;
+    const int lr = lane >> 4, lc = lane & 15;
+    int colc[2];
+    unsigned cmask[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int col = c0 + cc * 128 + lc * 8;
+        colc[cc] = col < N ? col : N - 8;
+        cmask[cc] = col < N ? 0xffffffffu : 0u;
+    }
+    // B operand of the gt contraction, per lane: B_c[r = n][c0 + cc*128 + ks*32 + g*8 .. +8]; the same for all four
+    // waves and all row steps -> staged once in LDS in fragment order (32 registers per lane otherwise)
+    __shared__ uint4 wbs[8][64];
+    if (wave < 2) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cb = c0 + wave * 128 + ks * 32 + g * 8;
+            wbs[wave * 4 + ks][lane] = and4(*reinterpret_cast<const uint4*>(W1b + (long long)n * N + (cb < N ? cb : N - 8)),
+                                            cb < N ? 0xffffffffu : 0u);
+        }
+    }
+    __syncthreads();
+    struct Regs {
+        uint4 t;
+        Raw8<XT> x[8];
+    };
+    auto gload = [&](int s0, int cc, Regs& r_) {
+        const int s = s0 < nst ? s0 : nst - 1;
+        const long long mb = w_begin + (long long)s * 32;
+        r_.t = *reinterpret_cast<const uint4*>(TTf + ((mb >> 5) * 64 + lane) * 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const long long m = mb + lr + 4 * q;
+            r_.x[q].load(X + (m < M ? m : M - 1) * ldx + colc[cc]);
+        }
+    };
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[cc][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[2];
+    uint4* slab = xs[wave];
+    auto stage = [&](int s0, int cc, const Regs& r_) {
+        const long long mb = w_begin + (long long)s0 * 32;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = lr + 4 * q;
+            slab[row * CPR + (lc ^ (t3_h(row) << 1))] = and4(r_.x[q].packed(), mb + row < M ? cmask[cc] : 0u);
+        }
+        wave_sync();
+#pragma unroll
+        for (int rtile = 0; rtile < 2; ++rtile) {
+            if (cc == 0) ga[rtile] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = rtile * 16 + n;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 xa = slab[row * CPR + ((ks * 4 + g) ^ (t3_h(row) << 1))];
+                // D[i = row][n = rank idx] += sum_col gy[row][col] * B_c[rank idx][col]
+                ga[rtile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa),
+                                                                   __builtin_bit_cast(bf16x8, wbs[cc * 4 + ks][lane]), ga[rtile], 0, 0, 0);
+            }
+            if (cc == 1) {
+                float* gp = GTP + ((long long)blockIdx.x * Mp + mb + rtile * 16 + g * 4) * 16 + n;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) gp[jj * 16] = ga[rtile][jj];
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            const int rowA = g * 8 + (n >> 2), rowB = rowA + 4;
+            const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
+            const char* base = reinterpret_cast<const char*>(slab);
+            const char* pa = base + ((rowA * CPR + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
+            const char* pb = base + ((rowB * CPR + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc[cc][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t),
+                                                                 __builtin_bit_cast(bf16x8, both), acc[cc][ct], 0, 0, 0);
+        }
+        wave_sync();
+    };
+    if (nst > 0) {
+        Regs rA, rB;               // rA <-> chunk 0, rB <-> chunk 1; one sub-step of prefetch distance
+        gload(0, 0, rA);
+        for (int s = 0; s < nst; ++s) {
+            gload(s, 1, rB);
+            stage(s, 0, rA);
+            gload(s + 1, 0, rA);   // clamped to the last step at the end (harmless re-read)
+            stage(s, 1, rB);
+        }
+    }
+    // fixed-order cross-wave sum of the gB accumulators, one chunk at a time (as k_t3 does per rank tile)
+    float* red = reinterpret_cast<float*>(&xs[0][0]);
+    float* out = Gpart + (long long)rg * RP * N;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+            *reinterpret_cast<f32x4*>(red + ((wave * 8 + ct) * 64 + lane) * 4) = acc[cc][ct];
+        __syncthreads();
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) {
+            const int ct = wave * 2 + jc;
+            f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ((0 * 8 + ct) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 8 + ct) * 64 + lane) * 4);
+            const int ocol = c0 + cc * 128 + ct * 16 + n;
+            if (ocol < N) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = s4[jj];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // repack: strided bf16 t[M, RP] (a column slice of the augmented frozen GEMM's output, row pitch ldt)
 //   -> T[Mp, RP] row-major (k_t2's operand) and TTf fragment-major (k_t3's operand); rows >= M are zero.
 // ------------------------------------------------------------------------------------------
@@ -622,7 +734,7 @@ __global__ __launch_bounds__(256) void k_repack(const bf16_t* __restrict__ t, lo
 }
 
 // ------------------------------------------------------------------------------------------
-// gt = sum over column chunks (fixed order) of the fp32 partials k_t3<EMIT> wrote -> bf16 T[Mp, 16] row-major
+// gt = sum over column pairs (fixed order) of the fp32 partials k_t3e wrote -> bf16 T[Mp, 16] row-major
 // (k_t2's operand) and TTf fragment-major (k_t3's operand), exactly the two images k_t1 would have produced.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP, int nchunks, bf16_t* __restrict__ T,
@@ -746,6 +858,21 @@ T3Plan plan_t3(long long Mp, int N, int RT) {
     if (nrg > units) nrg = units;
     if (nrg < 1) nrg = 1;
     const long long upg = (units + nrg - 1) / nrg;     // units per row group
+    p.rows_per_wg = (int)(upg * 128);
+    p.NR = (int)((units + upg - 1) / upg);
+    return p;
+}
+
+T3Plan plan_t3e(long long Mp, int N) {
+    // k_t3e: workgroup = 256 columns (two chunks) x a row group; `nchunks` counts column PAIRS here
+    T3Plan p;
+    p.br = 32;
+    p.nchunks = (N + 255) / 256;
+    const long long units = (Mp + 127) / 128;
+    long long nrg = env_int("SAM3_LORA_T3E_WGS", 512) / p.nchunks;
+    if (nrg > units) nrg = units;
+    if (nrg < 1) nrg = 1;
+    const long long upg = (units + nrg - 1) / nrg;
     p.rows_per_wg = (int)(upg * 128);
     p.NR = (int)((units + upg - 1) / upg);
     return p;
@@ -932,8 +1059,7 @@ void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part,
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
     {
         ProfScope ps(SAM3_LORA_STAGE_T3_GB, N, st);
-        hipLaunchKernelGGL((k_t3<XT, 1, false, false, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N,
-                           p.rows_per_wg, DropKey{0u, 0u, 0}, W1b, GTP);
+        hipLaunchKernelGGL((k_t3e<XT>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP);
     }
     ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, N, st);
     hipLaunchKernelGGL(k_gt_reduce, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, p.nchunks,
@@ -958,7 +1084,7 @@ FwdWs fwd_ws(long long M, int in_f, int out_f, int rank) {
 
 struct BwdWs {
     size_t w1b, w2tb, w1a, gt, gtt, t, tt, pb, pa, gtp, total;
-    T3Plan pB, pA;
+    T3Plan pB, pA, pE;      // pE: the one-pass (k_t3e) plan over gy, r <= 16
 };
 BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
     const int RP = rpad(rank);
@@ -966,6 +1092,7 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
     BwdWs w;
     w.pB = plan_t3(Mp, out_f, RP / 16);
     w.pA = plan_t3(Mp, in_f, RP / 16);
+    w.pE = plan_t3e(Mp, out_f);
     size_t off = 0;
     w.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * 2);
     w.w2tb = off; off += al256((size_t)in_f * RP * 2);
@@ -974,9 +1101,9 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
     w.gtt = off; off += al256((size_t)RP * Mp * 2);
     w.t = off; off += al256((size_t)Mp * RP * 2);
     w.tt = off; off += al256((size_t)RP * Mp * 2);
-    w.pb = off; off += al256((size_t)w.pB.NR * RP * out_f * 4);
+    w.pb = off; off += al256((size_t)(w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR) * RP * out_f * 4);
     w.pa = off; off += al256((size_t)w.pA.NR * RP * in_f * 4);
-    w.gtp = off; off += RP == 16 ? al256((size_t)w.pB.nchunks * Mp * 16 * 4) : 0;     // gt partials (r <= 16)
+    w.gtp = off; off += RP == 16 ? al256((size_t)w.pE.nchunks * Mp * 16 * 4) : 0;     // gt partials (r <= 16)
     w.total = off;
     return w;
 }
@@ -1176,8 +1303,8 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     const bool one_pass = RT == 1 && gB_accum && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
     float* GTP = (float*)(ws + w.gtp);
     if (one_pass) {
-        if (bf) launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, W1b, GTP, GT, GTT, st);
-        else launch_t3_emit<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, W1b, GTP, GT, GTT, st);
+        if (bf) launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, W1b, GTP, GT, GTT, st);
+        else launch_t3_emit<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, W1b, GTP, GT, GTT, st);
         if (bf) {
             if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
             if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
@@ -1198,7 +1325,7 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     }
     if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
         // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
-        ReduceJob rb{PB, gB_accum, w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
+        ReduceJob rb{PB, gB_accum, one_pass ? w.pE.NR : w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
         ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
         dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);

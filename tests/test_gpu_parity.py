@@ -487,7 +487,7 @@ def test_module_repacks_when_parameters_change():
 def test_one_pass_backward_matches_two_pass(shape, dtype, monkeypatch):
     """r <= 16: gt comes out of the gB pass over gy (k_t3 emitting partials + k_gt_reduce) instead of a second
     read of gy by k_t1.  Same math, different fp32 summation order: gx / gA agree to bf16 rounding of gt, gB (which
-    does not depend on gt) bit for bit; both agree with the fp64 oracle."""
+    does not depend on gt) to fp32 re-association (the row groups differ); both agree with the fp64 oracle."""
     M, fin, fout, rank = shape
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
     g = torch.Generator(device=DEV).manual_seed(M)
@@ -505,7 +505,7 @@ def test_one_pass_backward_matches_two_pass(shape, dtype, monkeypatch):
         gA, gB = torch.zeros_like(A), torch.zeros_like(B)
         Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, 2.0, cases.LAYOUT_ROOT)
         res[mode] = (gx.float().cpu().numpy(), gA.cpu().numpy(), gB.cpu().numpy())
-    assert np.array_equal(res["one"][2], res["two"][2])
+    assert _relmax(res["one"][2], res["two"][2]) < 1e-5
     assert _relmax(res["one"][0], res["two"][0]) < 1e-2
     assert _relmax(res["one"][1], res["two"][1]) < 5e-3
     if M <= 5184:
