@@ -23,6 +23,22 @@ int sam3_vit_qkv_rope_bwd(const void* gq, const void* gk, const void* gv, int64_
                           const float* cos_t, const float* sin_t, void* gqkv, int64_t B, int L, int H, int D,
                           int dtype, void* stream);
 
+/*
+ * Window-attention forms (vitdet.py:93-141 window_partition / window_unpartition, :597-613 Block.forward): the token
+ * permutation is folded into the kernels that touch the rows anyway, so no partition / unpartition copy runs.
+ *   qkv_rope_win_*: qkv / gqkv rows are in IMAGE order [B_img, Hh, Ww, 3*H*D]; q, k, v (and their gradients) are in
+ *   WINDOW order: B = B_img * (Hh/ws) * (Ww/ws) windows of L = ws*ws tokens.  ws == 0: no windows (identity).
+ *   win_residual: y = x + scale[img] * unpartition(h) in one pass (scale = stochastic-depth mask / keep, or NULL);
+ *   backward != 0 computes gh = scale[img] * partition(gy) from x := gy (the gradient of x is gy itself).
+ */
+int sam3_vit_qkv_rope_win_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* q, void* k, void* v,
+                              int64_t B, int L, int H, int D, int ws, int Hh, int Ww, int dtype, void* stream);
+int sam3_vit_qkv_rope_win_bwd(const void* gq, const void* gk, const void* gv, int64_t sb, int64_t sh, int64_t sl,
+                              const float* cos_t, const float* sin_t, void* gqkv, int64_t B, int L, int H, int D,
+                              int ws, int Hh, int Ww, int dtype, void* stream);
+int sam3_vit_win_residual(const void* x, const void* h, const float* scale, void* y, int64_t B_img, int Hh, int Ww,
+                          int C, int ws, int backward, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

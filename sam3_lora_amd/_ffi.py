@@ -29,6 +29,8 @@ EXPORTS = (
     "sam3_lora_packed_bytes", "sam3_lora_pack",
 )
 PREPACKED = 0x100
+VIT_EXPORTS = ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd", "sam3_vit_qkv_rope_win_fwd",
+               "sam3_vit_qkv_rope_win_bwd", "sam3_vit_win_residual")      # include/sam3_vit_amd.h
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
 _lib = None
@@ -92,6 +94,12 @@ def _declare(lib):
     lib.sam3_vit_qkv_rope_fwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_int, c_void_p]
     lib.sam3_vit_qkv_rope_bwd.argtypes = [c_void_p] * 3 + [c_int64] * 3 + [c_void_p] * 3 + [c_int64, c_int, c_int, c_int,
                                                                                       c_int, c_void_p]
+    for f in (lib.sam3_vit_qkv_rope_win_fwd, lib.sam3_vit_qkv_rope_win_bwd, lib.sam3_vit_win_residual):
+        f.restype = c_int
+    lib.sam3_vit_qkv_rope_win_fwd.argtypes = [c_void_p] * 6 + [c_int64] + [c_int] * 7 + [c_void_p]
+    lib.sam3_vit_qkv_rope_win_bwd.argtypes = ([c_void_p] * 3 + [c_int64] * 3 + [c_void_p] * 3 + [c_int64] + [c_int] * 7
+                                              + [c_void_p])
+    lib.sam3_vit_win_residual.argtypes = [c_void_p] * 4 + [c_int64] + [c_int] * 6 + [c_void_p]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]
@@ -115,7 +123,7 @@ def load(path: str | None = None):
             lib = ctypes.CDLL(p)
         except OSError as e:  # missing libamdhip64 etc.
             raise LoRAKernelError(f"sam3_lora_amd: cannot load {p}: {e}") from e
-        missing = [s for s in EXPORTS + ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd") if not hasattr(lib, s)]
+        missing = [s for s in EXPORTS + VIT_EXPORTS if not hasattr(lib, s)]
         if missing:
             raise LoRAKernelError(f"sam3_lora_amd: {p} lacks symbols {missing}")
         _declare(lib)

@@ -60,13 +60,31 @@ __device__ __forceinline__ F8 rot(const F8& f, const float4 c, const float4 s, f
     return o;
 }
 
+// Window attention (vitdet.py:93-141 window_partition / window_unpartition) is a permutation of token ROWS, and
+// LayerNorm / Linear act per row, so the permutation never needs its own pass: the kernels below enumerate tokens
+// in window order (window b, position l) and address the image-order tensor through img_token(); ws == 0 is the
+// identity (global-attention blocks).
+struct WinMap {
+    int ws, Hh, Ww;      // window edge, token grid of one image (Hh % ws == 0, Ww % ws == 0)
+};
+__device__ __forceinline__ long long img_token(long long tok, int L, const WinMap w) {
+    if (w.ws == 0) return tok;
+    const int nWw = w.Ww / w.ws, nW = nWw * (w.Hh / w.ws);
+    const long long bw = tok / L;
+    const int l = (int)(tok % L);
+    const long long img = bw / nW;
+    const int wi = (int)(bw % nW);
+    const int wy = wi / nWw, wx = wi % nWw, iy = l / w.ws, ix = l % w.ws;
+    return img * ((long long)w.Hh * w.Ww) + (long long)(wy * w.ws + iy) * w.Ww + (wx * w.ws + ix);
+}
+
 // one thread = 8 consecutive elements of one (token, which in {q,k,v}, head); consecutive threads walk the
 // 3*H*D row of a token, so both the read and the three writes are fully coalesced
 template <typename T>
 __global__ __launch_bounds__(256) void k_qkv_rope_fwd(const T* __restrict__ qkv, const float* __restrict__ cs,
                                                       const float* __restrict__ sn, T* __restrict__ q,
                                                       T* __restrict__ k, T* __restrict__ v, long long ntok, int L,
-                                                      int H, int D) {
+                                                      int H, int D, WinMap wm) {
     const int cpr = 3 * H * D / 8;   // 16-byte chunks per token row
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= ntok * cpr) return;
@@ -75,7 +93,7 @@ __global__ __launch_bounds__(256) void k_qkv_rope_fwd(const T* __restrict__ qkv,
     const int hd8 = H * D / 8;
     const int which = c / hd8, ch = c % hd8;     // chunk inside the [H, D] slab
     const int d0 = (ch * 8) % D;                 // first element index inside the head
-    F8 f = ld8(qkv + tok * (3LL * H * D) + (long long)c * 8);
+    F8 f = ld8(qkv + img_token(tok, L, wm) * (3LL * H * D) + (long long)c * 8);
     T* dst = (which == 0 ? q : which == 1 ? k : v) + tok * ((long long)H * D) + (long long)ch * 8;
     if (which < 2) {
         const int l = (int)(tok % L);
@@ -91,7 +109,7 @@ __global__ __launch_bounds__(256) void k_qkv_rope_bwd(const T* __restrict__ gq, 
                                                       const T* __restrict__ gv, long long sb, long long sh,
                                                       long long sl, const float* __restrict__ cs,
                                                       const float* __restrict__ sn, T* __restrict__ gqkv,
-                                                      long long ntok, int L, int H, int D) {
+                                                      long long ntok, int L, int H, int D, WinMap wm) {
     const int cpr = 3 * H * D / 8;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= ntok * cpr) return;
@@ -109,7 +127,34 @@ __global__ __launch_bounds__(256) void k_qkv_rope_bwd(const T* __restrict__ gq, 
         const float4 ss = *reinterpret_cast<const float4*>(sn + (long long)l * (D / 2) + d0 / 2);
         f = rot(f, cc, ss, -1.f);
     }
-    st8(gqkv + tok * (3LL * H * D) + (long long)c * 8, f);
+    st8(gqkv + img_token(tok, L, wm) * (3LL * H * D) + (long long)c * 8, f);
+}
+
+// y[img token] = x[img token] + scale[img] * h[window token]   (residual add fused with window_unpartition and the
+// stochastic-depth mask; scale == nullptr means 1).  backward: gh[window token] = scale[img] * gy[img token].
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void k_win_residual(const T* __restrict__ x, const T* __restrict__ h,
+                                                      const float* __restrict__ scale, T* __restrict__ out,
+                                                      long long ntok, int L, int C, WinMap wm) {
+    const int cpr = C / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ntok * cpr) return;
+    const long long tok = idx / cpr;
+    const int c = (int)(idx % cpr);
+    const long long it = img_token(tok, L, wm);
+    const float sc = scale ? scale[it / ((long long)wm.Hh * wm.Ww)] : 1.f;
+    if (BWD) {      // x = gy (image order), out = gh (window order)
+        F8 f = ld8(x + it * C + (long long)c * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f.v[i] *= sc;
+        st8(out + tok * C + (long long)c * 8, f);
+    } else {
+        const F8 a = ld8(x + it * C + (long long)c * 8), b = ld8(h + tok * C + (long long)c * 8);
+        F8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = a.v[i] + sc * b.v[i];
+        st8(out + it * C + (long long)c * 8, o);
+    }
 }
 
 }  // namespace
@@ -117,37 +162,78 @@ __global__ __launch_bounds__(256) void k_qkv_rope_bwd(const T* __restrict__ gq, 
 extern "C" {
 
 // returns 0 on success, -22 on bad arguments, -5 on a launch error (same codes as sam3_lora_amd.h)
-int sam3_vit_qkv_rope_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* q, void* k, void* v,
-                          int64_t B, int L, int H, int D, int dtype, void* stream) {
+int sam3_vit_qkv_rope_win_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* q, void* k, void* v,
+                              int64_t B, int L, int H, int D, int ws, int Hh, int Ww, int dtype, void* stream) {
     if (!qkv || !cos_t || !sin_t || !q || !k || !v || B <= 0 || L <= 0 || H <= 0 || D <= 0 || (D % 8)) return -22;
+    if (ws < 0 || (ws > 0 && (Hh <= 0 || Ww <= 0 || Hh % ws || Ww % ws || L != ws * ws || (B * L) % ((int64_t)Hh * Ww))))
+        return -22;
+    const WinMap wm{ws, Hh, Ww};
     const long long ntok = B * L, total = ntok * (3LL * H * D / 8);
     const dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == 0)
         hipLaunchKernelGGL(k_qkv_rope_fwd<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, cos_t,
-                           sin_t, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, ntok, L, H, D);
+                           sin_t, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, ntok, L, H, D, wm);
     else if (dtype == 1)
         hipLaunchKernelGGL(k_qkv_rope_fwd<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, cos_t,
-                           sin_t, (float*)q, (float*)k, (float*)v, ntok, L, H, D);
+                           sin_t, (float*)q, (float*)k, (float*)v, ntok, L, H, D, wm);
     else
         return -22;
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+int sam3_vit_qkv_rope_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* q, void* k, void* v,
+                          int64_t B, int L, int H, int D, int dtype, void* stream) {
+    return sam3_vit_qkv_rope_win_fwd(qkv, cos_t, sin_t, q, k, v, B, L, H, D, 0, 0, 0, dtype, stream);
+}
+
 // gq/gk/gv: [B, H, L, D]-shaped views with element strides (sb, sh, sl, 1), identical for the three
-int sam3_vit_qkv_rope_bwd(const void* gq, const void* gk, const void* gv, int64_t sb, int64_t sh, int64_t sl,
-                          const float* cos_t, const float* sin_t, void* gqkv, int64_t B, int L, int H, int D,
-                          int dtype, void* stream) {
+int sam3_vit_qkv_rope_win_bwd(const void* gq, const void* gk, const void* gv, int64_t sb, int64_t sh, int64_t sl,
+                              const float* cos_t, const float* sin_t, void* gqkv, int64_t B, int L, int H, int D,
+                              int ws, int Hh, int Ww, int dtype, void* stream) {
     if (!gq || !gk || !gv || !cos_t || !sin_t || !gqkv || B <= 0 || L <= 0 || H <= 0 || D <= 0 || (D % 8)) return -22;
+    if (ws < 0 || (ws > 0 && (Hh <= 0 || Ww <= 0 || Hh % ws || Ww % ws || L != ws * ws || (B * L) % ((int64_t)Hh * Ww))))
+        return -22;
+    const WinMap wm{ws, Hh, Ww};
     const long long ntok = B * L, total = ntok * (3LL * H * D / 8);
     const dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == 0)
         hipLaunchKernelGGL(k_qkv_rope_bwd<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gq,
-                           (const bf16_t*)gk, (const bf16_t*)gv, sb, sh, sl, cos_t, sin_t, (bf16_t*)gqkv, ntok, L, H, D);
+                           (const bf16_t*)gk, (const bf16_t*)gv, sb, sh, sl, cos_t, sin_t, (bf16_t*)gqkv, ntok, L, H, D, wm);
     else if (dtype == 1)
         hipLaunchKernelGGL(k_qkv_rope_bwd<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)gq,
-                           (const float*)gk, (const float*)gv, sb, sh, sl, cos_t, sin_t, (float*)gqkv, ntok, L, H, D);
+                           (const float*)gk, (const float*)gv, sb, sh, sl, cos_t, sin_t, (float*)gqkv, ntok, L, H, D, wm);
     else
         return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int sam3_vit_qkv_rope_bwd(const void* gq, const void* gk, const void* gv, int64_t sb, int64_t sh, int64_t sl,
+                          const float* cos_t, const float* sin_t, void* gqkv, int64_t B, int L, int H, int D,
+                          int dtype, void* stream) {
+    return sam3_vit_qkv_rope_win_bwd(gq, gk, gv, sb, sh, sl, cos_t, sin_t, gqkv, B, L, H, D, 0, 0, 0, dtype, stream);
+}
+
+// backward == 0: y = x + scale[img] * unpartition(h)   (x, y: [B_img, Hh, Ww, C] image order; h: window order)
+// backward != 0: x is gy (image order), y receives gh = scale[img] * partition(gy) (window order); h is unused
+int sam3_vit_win_residual(const void* x, const void* h, const float* scale, void* y, int64_t B_img, int Hh, int Ww,
+                          int C, int ws, int backward, int dtype, void* stream) {
+    if (!x || !y || (!backward && !h) || B_img <= 0 || Hh <= 0 || Ww <= 0 || C <= 0 || (C % 8) || ws <= 0 || Hh % ws ||
+        Ww % ws)
+        return -22;
+    const WinMap wm{ws, Hh, Ww};
+    const long long ntok = B_img * Hh * Ww, total = ntok * (C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    const int L = ws * ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        if (backward) hipLaunchKernelGGL((k_win_residual<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)h, scale, (bf16_t*)y, ntok, L, C, wm);
+        else hipLaunchKernelGGL((k_win_residual<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)h, scale, (bf16_t*)y, ntok, L, C, wm);
+    } else if (dtype == 1) {
+        if (backward) hipLaunchKernelGGL((k_win_residual<float, true>), grid, dim3(256), 0, st, (const float*)x, (const float*)h, scale, (float*)y, ntok, L, C, wm);
+        else hipLaunchKernelGGL((k_win_residual<float, false>), grid, dim3(256), 0, st, (const float*)x, (const float*)h, scale, (float*)y, ntok, L, C, wm);
+    } else {
+        return -22;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

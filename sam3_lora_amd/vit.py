@@ -117,6 +117,19 @@ class Attention(nn.Module):
         out = torch.stack((a * cos - b * sin, a * sin + b * cos), dim=-1).flatten(-2)
         return out.to(t.dtype)
 
+    def forward_windows(self, x: torch.Tensor, ws: int) -> torch.Tensor:
+        """x [B, H, W, C] in IMAGE order -> attention inside ws x ws windows; returns the projected output as
+        [B * nW, ws, ws, C] in WINDOW order.  qkv is a per-token Linear, so it runs on the image-order rows and the
+        partition happens inside the qkv-split/RoPE kernel's addressing (no window_partition copy)."""
+        B, H, W, C = x.shape
+        L, nW = ws * ws, (H // ws) * (W // ws)
+        qkv = self.qkv(x)
+        cos, sin = self._cos_sin(qkv.device)
+        q, k, v = _QKVRope.apply(qkv.reshape(B * H * W, 3 * C), cos, sin, B * nW, L, self.num_heads, self.head_dim,
+                                 (ws, H, W))
+        o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+        return self.proj(o.transpose(1, 2).reshape(B * nW, ws, ws, C))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, H, W, C = x.shape
         L = H * W
@@ -141,20 +154,21 @@ class _QKVRope(torch.autograd.Function):
     """qkv[B*L, 3*H*D] -> q, k (RoPE-rotated), v as [B, L, H, D]; C-ABI ``sam3_vit_qkv_rope_fwd/bwd``."""
 
     @staticmethod
-    def forward(ctx, qkv2, cos, sin, B, L, H, D):
+    def forward(ctx, qkv2, cos, sin, B, L, H, D, win=(0, 0, 0)):
+        """``win = (ws, Hh, Ww)``: qkv2 rows are image-order tokens, outputs are window-order (B windows of L)."""
         import ctypes
         from . import _ffi
         lib = _ffi.load()
         qkv2 = qkv2.contiguous()
         q, k, v = (torch.empty(B, L, H, D, device=qkv2.device, dtype=qkv2.dtype) for _ in range(3))
         dt = 0 if qkv2.dtype == torch.bfloat16 else 1
-        rc = lib.sam3_vit_qkv_rope_fwd(qkv2.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(), k.data_ptr(),
-                                       v.data_ptr(), B, L, H, D, dt,
-                                       ctypes.c_void_p(torch.cuda.current_stream(qkv2.device).cuda_stream))
+        rc = lib.sam3_vit_qkv_rope_win_fwd(qkv2.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(), k.data_ptr(),
+                                           v.data_ptr(), B, L, H, D, win[0], win[1], win[2], dt,
+                                           ctypes.c_void_p(torch.cuda.current_stream(qkv2.device).cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"sam3_vit_qkv_rope_fwd failed ({rc})")
+            raise RuntimeError(f"sam3_vit_qkv_rope_win_fwd failed ({rc})")
         ctx.save_for_backward(cos, sin)
-        ctx.dims = (B, L, H, D, dt)
+        ctx.dims = (B, L, H, D, dt, win)
         return q, k, v
 
     @staticmethod
@@ -163,7 +177,7 @@ class _QKVRope(torch.autograd.Function):
         from . import _ffi
         lib = _ffi.load()
         cos, sin = ctx.saved_tensors
-        B, L, H, D, dt = ctx.dims
+        B, L, H, D, dt, win = ctx.dims
         # grads arrive [B, L, H, D]-shaped; view them as [B, H, L, D] with explicit strides for the kernel
         def canon(g):
             g = g if g.stride(-1) == 1 else g.contiguous()
@@ -173,12 +187,53 @@ class _QKVRope(torch.autograd.Function):
             gq, gk, gv = gq.contiguous(), gk.contiguous(), gv.contiguous()
         sb, sl, sh, _ = gq.stride()
         gqkv = torch.empty(B * L, 3 * H * D, device=gq.device, dtype=gq.dtype)
-        rc = lib.sam3_vit_qkv_rope_bwd(gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), sb, sh, sl, cos.data_ptr(),
-                                       sin.data_ptr(), gqkv.data_ptr(), B, L, H, D, dt,
-                                       ctypes.c_void_p(torch.cuda.current_stream(gq.device).cuda_stream))
+        rc = lib.sam3_vit_qkv_rope_win_bwd(gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), sb, sh, sl, cos.data_ptr(),
+                                           sin.data_ptr(), gqkv.data_ptr(), B, L, H, D, win[0], win[1], win[2], dt,
+                                           ctypes.c_void_p(torch.cuda.current_stream(gq.device).cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"sam3_vit_qkv_rope_bwd failed ({rc})")
-        return gqkv, None, None, None, None, None, None
+            raise RuntimeError(f"sam3_vit_qkv_rope_win_bwd failed ({rc})")
+        return gqkv, None, None, None, None, None, None, None
+
+
+class _WinResidual(torch.autograd.Function):
+    """``x + scale[b] * window_unpartition(h)`` in one pass (``scale``: per-image stochastic-depth factor or None);
+    C-ABI ``sam3_vit_win_residual``.  The gradient of x is the incoming gradient itself (no kernel, no copy)."""
+
+    @staticmethod
+    def forward(ctx, x, h, scale, ws):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        B, H, W, C = x.shape
+        x, h = x.contiguous(), h.contiguous()
+        y = torch.empty_like(x)
+        dt = 0 if x.dtype == torch.bfloat16 else 1
+        rc = lib.sam3_vit_win_residual(x.data_ptr(), h.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                       y.data_ptr(), B, H, W, C, ws, 0, dt,
+                                       ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_vit_win_residual failed ({rc})")
+        ctx.save_for_backward(scale) if scale is not None else None
+        ctx.meta = (B, H, W, C, ws, dt, h.shape, scale is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        B, H, W, C, ws, dt, h_shape, has_scale = ctx.meta
+        scale = ctx.saved_tensors[0] if has_scale else None
+        gy = gy.contiguous()
+        gh = None
+        if ctx.needs_input_grad[1]:
+            gh = torch.empty(h_shape, device=gy.device, dtype=gy.dtype)
+            rc = lib.sam3_vit_win_residual(gy.data_ptr(), None, scale.data_ptr() if scale is not None else None,
+                                           gh.data_ptr(), B, H, W, C, ws, 1, dt,
+                                           ctypes.c_void_p(torch.cuda.current_stream(gy.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"sam3_vit_win_residual (backward) failed ({rc})")
+        return (gy if ctx.needs_input_grad[0] else None), gh, None, None
 
 
 def window_partition(x: torch.Tensor, ws: int) -> Tuple[torch.Tensor, Tuple[int, int]]:
@@ -216,7 +271,19 @@ class Block(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.window_size = window_size
 
+    def _fused_windows(self, x: torch.Tensor) -> bool:
+        ws = self.window_size
+        return (ws > 0 and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % ws == 0
+                and x.shape[2] % ws == 0 and x.shape[-1] % 8 == 0
+                and not (self.training and isinstance(self.dropout, nn.Dropout) and self.dropout.p > 0.0))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._fused_windows(x):
+            # window blocks without partition / unpartition copies: rows stay in image order through norm1 and qkv,
+            # the qkv-split/RoPE kernel gathers them into windows, and the residual add scatters them back
+            hw = self.attn.forward_windows(self.norm1(x), self.window_size)
+            x = _WinResidual.apply(x, hw, self._drop_path_scale(x), self.window_size)
+            return self._residual(x, self.mlp(self.norm2(x)))
         h = self.norm1(x)
         if self.window_size > 0:
             H, W = h.shape[1], h.shape[2]
@@ -226,6 +293,17 @@ class Block(nn.Module):
             h = window_unpartition(h, self.window_size, pad_hw, (H, W))
         x = self._residual(x, h)
         return self._residual(x, self.mlp(self.norm2(x)))
+
+    def _drop_path_scale(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """fp32 [B]: Bernoulli(keep) / keep per image while stochastic depth is active, else None."""
+        dp = self.drop_path
+        if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
+            keep = 1.0 - dp.drop_prob
+            mask = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+            if keep > 0.0 and dp.scale_by_keep:
+                mask.div_(keep)
+            return mask
+        return None
 
     def _residual(self, x: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
         """x + dropout(drop_path(h)); with stochastic depth active the mask-multiply and the add are one

@@ -198,6 +198,15 @@ def test_linear_with_lora_exposes_linear_attrs():
 
 
 # ------------------------------------------------------------------ C-ABI ----------------
+def lib_has_packed_sizes():
+    """sam3_lora_packed_bytes: four bf16 images, each 256-byte aligned; 0 (with an error text) on bad shapes."""
+    lib = _ffi.load()
+    n = lib.sam3_lora_packed_bytes(1024, 4736, 16)
+    assert n == 2 * 16 * (1024 + 4736) * 2 and n % 256 == 0
+    assert lib.sam3_lora_packed_bytes(1024, 4736, 33) == 0 and "rank" in _ffi.last_error()
+    return True
+
+
 def test_cabi_library_builds_loads_and_exports_header_symbols():
     """No compute call (no GPU here): the library exists, loads, and exports every function the
     header declares."""
@@ -206,8 +215,12 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     hdr = open(os.path.join(build.INCLUDE, "sam3_lora_amd.h")).read()
     declared = set(re.findall(r"\b(sam3_lora_[a-z_]+)\s*\(", hdr))
     assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    vit_hdr = open(os.path.join(build.INCLUDE, "sam3_vit_amd.h")).read()
+    vit_declared = set(re.findall(r"\b(sam3_vit_[a-z_]+)\s*\(", vit_hdr))
+    assert vit_declared == set(_ffi.VIT_EXPORTS), vit_declared ^ set(_ffi.VIT_EXPORTS)
+    assert lib_has_packed_sizes()
     lib = ctypes.CDLL(path)
-    for sym in declared:
+    for sym in declared | vit_declared:
         assert hasattr(lib, sym), sym
     lib2 = _ffi.load()
     assert lib2.sam3_lora_abi_version() == 1

@@ -115,3 +115,50 @@ def test_trunk_with_hip_lora_matches_reference(golden_dir, dtype):
             assert mod.lora_A.grad.dtype == torch.float32
             eA, eB = rel(mod.lora_A.grad.cpu().numpy(), g[f"gA/{n}"]), rel(mod.lora_B.grad.cpu().numpy(), g[f"gB/{n}"])
             assert eA < 5 * tol and eB < 5 * tol, (n, eA, eB)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_window_block_without_partition_copies_equals_partitioned_form(dtype, monkeypatch):
+    """Block.forward's fused window path (image-order rows, gather in the qkv/RoPE kernel, scatter in the residual
+    kernel: sam3_vit_qkv_rope_win_* / sam3_vit_win_residual) against the literal window_partition ->
+    attention -> window_unpartition -> add form (vitdet.py:597-613), forward and every gradient."""
+    torch.manual_seed(0)
+    blk = V.Block(dim=64, num_heads=2, mlp_ratio=2.0, qkv_bias=True, drop_path=0.0, window_size=4, input_size=(12, 8),
+                  rope_pt_size=(4, 4), rope_interp=False).to("cuda")
+    for p in blk.parameters():          # not Module.to(dtype): that would squash the complex RoPE buffer
+        p.data = p.data.to(dtype)
+    x = torch.randn(3, 12, 8, 64, device="cuda", dtype=dtype)
+    gy = torch.randn_like(x)
+    outs = {}
+    for mode in ("fused", "literal"):
+        if mode == "literal":
+            monkeypatch.setattr(V.Block, "_fused_windows", lambda self, t: False)
+        xi = x.clone().requires_grad_(True)
+        blk.zero_grad()
+        y = blk(xi)
+        y.backward(gy)
+        outs[mode] = [y.detach().float(), xi.grad.float()] + [p.grad.float().clone() for p in blk.parameters()]
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    for a, b in zip(outs["fused"], outs["literal"]):
+        assert (a - b).abs().max() <= tol * (b.abs().max() + 1e-6)
+
+
+@pytest.mark.gpu
+def test_window_residual_applies_stochastic_depth_per_image():
+    torch.manual_seed(1)
+    blk = V.Block(dim=32, num_heads=2, mlp_ratio=1.0, qkv_bias=True, drop_path=0.5, window_size=2, input_size=(4, 4),
+                  rope_pt_size=(2, 2), rope_interp=False).to("cuda")
+    x = torch.randn(16, 4, 4, 32, device="cuda")
+    hw = torch.randn(16 * 4, 2, 2, 32, device="cuda", requires_grad=True)
+    blk.train()
+    scale = blk._drop_path_scale(x)
+    assert set(scale.unique().tolist()) <= {0.0, 2.0} and 0 < (scale == 0).float().mean() < 1
+    y = V._WinResidual.apply(x, hw, scale, 2)
+    ref = x + scale.view(-1, 1, 1, 1) * V.window_unpartition(hw.detach(), 2, (4, 4), (4, 4))
+    assert torch.allclose(y, ref, atol=1e-6)
+    y.backward(torch.ones_like(y))
+    want = scale.repeat_interleave(4).view(-1, 1, 1, 1).expand_as(hw)
+    assert torch.allclose(hw.grad, want)
+    blk.eval()
+    assert blk._drop_path_scale(x) is None
