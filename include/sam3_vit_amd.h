@@ -39,6 +39,16 @@ int sam3_vit_qkv_rope_win_bwd(const void* gq, const void* gk, const void* gv, in
 int sam3_vit_win_residual(const void* x, const void* h, const float* scale, void* y, int64_t B_img, int Hh, int Ww,
                           int C, int ws, int backward, int dtype, void* stream);
 
+/*
+ * LayerNorm over the last dimension of x[M, C] with frozen affine parameters (vitdet.py:563-571, nn.LayerNorm eps 1e-5):
+ * one pass each way, fp32 statistics.  gamma / beta have the activation dtype; C % 8 == 0, C <= 4096.  The backward
+ * produces the input gradient only (the parameters are frozen under LoRA).
+ */
+int sam3_vit_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                           int64_t M, int C, float eps, int dtype, void* stream);
+int sam3_vit_layernorm_bwd(const void* gy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                           void* gx, int64_t M, int C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

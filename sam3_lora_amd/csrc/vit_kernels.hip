@@ -157,6 +157,121 @@ __global__ __launch_bounds__(256) void k_win_residual(const T* __restrict__ x, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm over the channel dimension with FROZEN affine parameters (the trunk's norm1 / norm2 / ln_pre; reference
+// vitdet.py:563-571 nn.LayerNorm(eps=1e-5)).  One wave per token row, the row lives in registers (CPL chunks of 8
+// elements per lane), statistics in fp32 with a two-pass variance.  HBM-bound: forward reads x and writes y once,
+// backward reads gy and x and writes gx once (no weight / bias gradients: they are frozen under LoRA).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void k_ln_fwd(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                const T* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
+                                                float* __restrict__ rstd, long long M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    F8 v[CPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            v[i] = ld8(x + row * C + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[i].v[j];
+        }
+    }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+        if ((i * 64 + lane) * 8 < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q += (v[i].v[j] - mu) * (v[i].v[j] - mu);
+        }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            const F8 g = ld8(gamma + c), b = ld8(beta + c);
+            F8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = (v[i].v[j] - mu) * rs * g.v[j] + b.v[j];
+            st8(y + row * C + c, o);
+        }
+    }
+}
+
+// gx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gy * gamma,  xhat = (x - mean) * rstd
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ gy, const T* __restrict__ x,
+                                                const T* __restrict__ gamma, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, T* __restrict__ gx, long long M, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mu = mean[row], rs = rstd[row];
+    F8 g[CPL], xh[CPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            const F8 a = ld8(gy + row * C + c), w = ld8(gamma + c), xv = ld8(x + row * C + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                g[i].v[j] = a.v[j] * w.v[j];
+                xh[i].v[j] = (xv.v[j] - mu) * rs;
+                s1 += g[i].v[j];
+                s2 += g[i].v[j] * xh[i].v[j];
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            F8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = rs * (g[i].v[j] - m1 - xh[i].v[j] * m2);
+            st8(gx + row * C + c, o);
+        }
+    }
+}
+
+template <typename T>
+int launch_ln(bool bwd, const void* a, const void* b, const void* gamma, const void* beta, void* out, float* mean,
+              float* rstd, long long M, int C, float eps, hipStream_t st) {
+    const dim3 grid((unsigned)((M + 3) / 4));
+    const int cpl = (C + 511) / 512;
+#define LN_CASE(N)                                                                                                     \
+    case N:                                                                                                            \
+        if (bwd) hipLaunchKernelGGL((k_ln_bwd<T, N>), grid, dim3(256), 0, st, (const T*)a, (const T*)b, (const T*)gamma, \
+                                    (const float*)mean, (const float*)rstd, (T*)out, M, C);                            \
+        else hipLaunchKernelGGL((k_ln_fwd<T, N>), grid, dim3(256), 0, st, (const T*)a, (const T*)gamma, (const T*)beta, \
+                                (T*)out, mean, rstd, M, C, eps);                                                       \
+        break;
+    switch (cpl) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+        default: return -22;
+    }
+#undef LN_CASE
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 }  // namespace
 
 extern "C" {
@@ -235,6 +350,26 @@ int sam3_vit_win_residual(const void* x, const void* h, const float* scale, void
         return -22;
     }
     return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+
+// y = LayerNorm(x) * gamma + beta over the last dimension of x[M, C]; also writes the fp32 row statistics the
+// backward needs.  gamma / beta have the activation dtype.  C % 8 == 0, C <= 4096.
+int sam3_vit_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                           int64_t M, int C, float eps, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || C <= 0 || (C % 8) || C > 4096) return -22;
+    if (dtype == 0) return launch_ln<bf16_t>(false, x, nullptr, gamma, beta, y, mean, rstd, M, C, eps, (hipStream_t)stream);
+    if (dtype == 1) return launch_ln<float>(false, x, nullptr, gamma, beta, y, mean, rstd, M, C, eps, (hipStream_t)stream);
+    return -22;
+}
+
+// input gradient only (gamma, beta frozen): gx from gy, x and the saved statistics
+int sam3_vit_layernorm_bwd(const void* gy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                           void* gx, int64_t M, int C, int dtype, void* stream) {
+    if (!gy || !x || !gamma || !mean || !rstd || !gx || M <= 0 || C <= 0 || (C % 8) || C > 4096) return -22;
+    if (dtype == 0) return launch_ln<bf16_t>(true, gy, x, gamma, nullptr, gx, (float*)mean, (float*)rstd, M, C, 0.f, (hipStream_t)stream);
+    if (dtype == 1) return launch_ln<float>(true, gy, x, gamma, nullptr, gx, (float*)mean, (float*)rstd, M, C, 0.f, (hipStream_t)stream);
+    return -22;
 }
 
 }  // extern "C"

@@ -236,6 +236,60 @@ class _WinResidual(torch.autograd.Function):
         return (gy if ctx.needs_input_grad[0] else None), gh, None, None
 
 
+class _FrozenLayerNorm(torch.autograd.Function):
+    """LayerNorm with frozen weight / bias: one HIP pass each way (``sam3_vit_layernorm_fwd/bwd``), saving x and
+    the fp32 row statistics; no parameter gradients are produced."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        stats = torch.empty(2, M, device=x.device, dtype=torch.float32)
+        dt = 0 if x.dtype == torch.bfloat16 else 1
+        rc = lib.sam3_vit_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                        stats[1].data_ptr(), M, C, float(eps), dt,
+                                        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_vit_layernorm_fwd failed ({rc})")
+        ctx.save_for_backward(x2, weight, stats)
+        ctx.meta = (M, C, dt, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        x2, weight, stats = ctx.saved_tensors
+        M, C, dt, shape = ctx.meta
+        gy2 = gy.reshape(M, C)
+        gy2 = gy2 if gy2.is_contiguous() else gy2.contiguous()
+        gx = torch.empty_like(x2)
+        rc = lib.sam3_vit_layernorm_bwd(gy2.data_ptr(), x2.data_ptr(), weight.data_ptr(), stats[0].data_ptr(),
+                                        stats[1].data_ptr(), gx.data_ptr(), M, C, dt,
+                                        ctypes.c_void_p(torch.cuda.current_stream(gy.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_vit_layernorm_bwd failed ({rc})")
+        return gx.view(shape), None, None, None
+
+
+def layer_norm(norm: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """``norm(x)``; an ``nn.LayerNorm`` over the last dimension whose parameters are frozen and share x's dtype runs
+    on the HIP kernels, everything else (Identity, trainable or mixed-dtype norms, CPU) on the module itself."""
+    if (isinstance(norm, nn.LayerNorm) and x.is_cuda and norm.elementwise_affine and norm.bias is not None
+            and len(norm.normalized_shape) == 1 and not norm.weight.requires_grad and not norm.bias.requires_grad
+            and x.dtype in (torch.bfloat16, torch.float32) and norm.weight.dtype == x.dtype and norm.bias.dtype == x.dtype
+            and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096 and x.numel() > 0 and not torch.is_autocast_enabled("cuda")):
+        return _FrozenLayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
 def window_partition(x: torch.Tensor, ws: int) -> Tuple[torch.Tensor, Tuple[int, int]]:
     B, H, W, C = x.shape
     ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
@@ -281,10 +335,10 @@ class Block(nn.Module):
         if self._fused_windows(x):
             # window blocks without partition / unpartition copies: rows stay in image order through norm1 and qkv,
             # the qkv-split/RoPE kernel gathers them into windows, and the residual add scatters them back
-            hw = self.attn.forward_windows(self.norm1(x), self.window_size)
+            hw = self.attn.forward_windows(layer_norm(self.norm1, x), self.window_size)
             x = _WinResidual.apply(x, hw, self._drop_path_scale(x), self.window_size)
-            return self._residual(x, self.mlp(self.norm2(x)))
-        h = self.norm1(x)
+            return self._residual(x, self.mlp(layer_norm(self.norm2, x)))
+        h = layer_norm(self.norm1, x)
         if self.window_size > 0:
             H, W = h.shape[1], h.shape[2]
             h, pad_hw = window_partition(h, self.window_size)
@@ -292,7 +346,7 @@ class Block(nn.Module):
         if self.window_size > 0:
             h = window_unpartition(h, self.window_size, pad_hw, (H, W))
         x = self._residual(x, h)
-        return self._residual(x, self.mlp(self.norm2(x)))
+        return self._residual(x, self.mlp(layer_norm(self.norm2, x)))
 
     def _drop_path_scale(self, x: torch.Tensor) -> Optional[torch.Tensor]:
         """fp32 [B]: Bernoulli(keep) / keep per image while stochastic depth is active, else None."""
@@ -379,7 +433,7 @@ class ViT(nn.Module):
         x = self.patch_embed(x)
         h, w = x.shape[1], x.shape[2]
         x = x + self.abs_pos(h, w).to(x.dtype)
-        x = self.ln_pre(x)
+        x = layer_norm(self.ln_pre, x)
         outs = []
         for i, blk in enumerate(self.blocks):
             if self.use_act_checkpoint and self.training:
@@ -387,7 +441,7 @@ class ViT(nn.Module):
             else:
                 x = blk(x)
             if i == self.full_attn_ids[-1]:
-                x = self.ln_post(x)
+                x = layer_norm(self.ln_post, x)
                 outs.append(x.permute(0, 3, 1, 2))
         return outs
 

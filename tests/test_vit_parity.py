@@ -162,3 +162,34 @@ def test_window_residual_applies_stochastic_depth_per_image():
     assert torch.allclose(hw.grad, want)
     blk.eval()
     assert blk._drop_path_scale(x) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(5, 7, 1024), (3, 64), (1000, 520), (2, 3, 4096)])
+def test_frozen_layernorm_kernel_matches_torch(dtype, shape):
+    """sam3_vit_layernorm_fwd/bwd (frozen affine) against nn.LayerNorm evaluated in fp32 on the same inputs.
+    Tolerance: fp32 5e-5 of the tensor's max; bf16 one output rounding (2^-8 relative) on top."""
+    torch.manual_seed(shape[-1])
+    C = shape[-1]
+    ln = torch.nn.LayerNorm(C, eps=1e-5).to("cuda")
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.3)
+        ln.bias.normal_(0.0, 0.3)
+    x32 = (torch.randn(*shape, device="cuda") * 2 + 0.5).to(dtype).float()
+    gy32 = torch.randn(*shape, device="cuda").to(dtype).float()
+    w32, b32 = ln.weight.detach().to(dtype).float(), ln.bias.detach().to(dtype).float()
+    xr = x32.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (C,), w32, b32, 1e-5)
+    yr.backward(gy32)
+    ln.to(dtype)
+    assert V.layer_norm(ln, x32.to(dtype)).dtype == dtype              # trainable norm: stays on the module
+    for p in ln.parameters():
+        p.requires_grad_(False)
+    x = x32.to(dtype).requires_grad_(True)
+    y = V.layer_norm(ln, x)
+    assert y.grad_fn is not None and "FrozenLayerNorm" in type(y.grad_fn).__name__
+    y.backward(gy32.to(dtype))
+    tol = 5e-5 if dtype == torch.float32 else 8e-3
+    assert (y.float() - yr).abs().max() <= tol * yr.abs().max()
+    assert (x.grad.float() - xr.grad).abs().max() <= tol * xr.grad.abs().max()
