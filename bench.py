@@ -208,17 +208,18 @@ def insitu_kernels(w, steps=2):
 
 def op_table(w, iters):
     """Whole C-ABI calls (all their kernels) against SURVEY section 8(d)'s per-unit algorithmic bytes."""
-    from sam3_lora_amd.functional import lora_bwd_, lora_fwd_
+    from sam3_lora_amd.functional import lora_bwd_, lora_fwd_, pack_operands
     M, r, s, e = w.M, w.rank, w.scaling, 2
     x1, h, y2, g2, gh, g1 = w.x1[0], w.h[0], w.y2[0], w.g2[0], w.gh[0], w.g1[0]
     A1, B1, A2, B2 = w.A1[0], w.B1[0], w.A2[0], w.B2[0]
     gA1, gB1, gA2, gB2 = (torch.zeros_like(p) for p in (A1, B1, A2, B2))
-    t1 = lora_fwd_(x1, A1, B1, h, s, 0, save_t=True)
-    t2 = lora_fwd_(h, A2, B2, y2, s, 0, save_t=True)
-    fwd1 = lambda: lora_fwd_(x1, A1, B1, h, s, 0)
-    fwd2 = lambda: lora_fwd_(h, A2, B2, y2, s, 0)
-    bwd2 = lambda: lora_bwd_(g2, h, t2, A2, B2, gh, gA2, gB2, s, 0, accumulate=True)
-    bwd1 = lambda: lora_bwd_(gh, x1, t1, A1, B1, g1, gA1, gB1, s, 0, accumulate=True)
+    p1, p2 = pack_operands(A1, B1, 0), pack_operands(A2, B2, 0)     # as the step calls them: operands pre-packed
+    t1 = lora_fwd_(x1, A1, B1, h, s, 0, save_t=True, packed=p1)
+    t2 = lora_fwd_(h, A2, B2, y2, s, 0, save_t=True, packed=p2)
+    fwd1 = lambda: lora_fwd_(x1, A1, B1, h, s, 0, packed=p1)
+    fwd2 = lambda: lora_fwd_(h, A2, B2, y2, s, 0, packed=p2)
+    bwd2 = lambda: lora_bwd_(g2, h, t2, A2, B2, gh, gA2, gB2, s, 0, accumulate=True, packed=p2)
+    bwd1 = lambda: lora_bwd_(gh, x1, t1, A1, B1, g1, gA1, gB1, s, 0, accumulate=True, packed=p1)
     D, H = D_MODEL, D_HID
     fwd_b = lambda i, o: e * M * (i + 2 * o) + e * r * (i + o)
     bwd_b = lambda i, o: e * M * (o + i + 2 * i) + 4 * r * (i + o) * 2
