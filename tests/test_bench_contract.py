@@ -1,0 +1,53 @@
+"""
+bench.py's output contract (one JSON line with the driver's keys + `roofline` + `cpu_baseline`) on a reduced
+workload, and the N = 2 launch exactly as the driver issues it (torch.distributed.run, one process per rank) with
+both ranks sharing the one GPU of the test box over gloo -- the path where a rank-0-only collective once deadlocked.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _last_json(out: str):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_has_the_contract_keys():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--blocks", "2", "--batch", "1",
+           "--kernel-iters", "2", "--no-trunk"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = _last_json(p.stdout)
+    assert KEYS <= set(r), KEYS - set(r)
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["unit"] == "images/s" and r["value"] > 0 and r["dtype"] == "bf16" and r["vs_baseline"] is None
+    assert "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000 and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_launched_like_the_driver_complete():
+    port = 29600 + os.getpid() % 1000
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--blocks", "2", "--batch", "1", "--kernel-iters", "2", "--no-trunk", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    r = _last_json(p.stdout)
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert sum(1 for l in p.stdout.splitlines() if l.startswith("{")) == 1      # rank 0 only
