@@ -124,6 +124,31 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Activation fused into the rank-r update (the MLP of a transformer block: fc1 -> GELU -> fc2; SURVEY section 8f-1
+ * "fuse GELU too").  The in-place update already streams the [M, out] tensor once; these variants make that pass also do
+ * the elementwise work that would otherwise be its own read+write of the same tensor:
+ *   sam3_lora_fwd_act: as sam3_lora_fwd, and act_out[M, out] (row pitch ldact) = act(y_inout after the update).
+ *   sam3_lora_bwd_act: as sam3_lora_bwd, then gx_inout *= act'(pre_act[M, in]) -- for the layer that CONSUMES the
+ *                      activation (fc2): gx_inout leaves as the gradient of the producing layer's pre-activation.
+ * act: SAM3_LORA_ACT_GELU = exact (erf) GELU, torch.nn.GELU()'s default, evaluated in fp32 on the rounded tensor.
+ */
+#define SAM3_LORA_ACT_NONE 0
+#define SAM3_LORA_ACT_GELU 1
+int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout, void* tT_out,
+                      int64_t M, int in_features, int out_features, int rank,
+                      int64_t ldx, int64_t ldy, int layout, float scaling,
+                      float drop_p, uint64_t seed, uint64_t offset, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream,
+                      int act, void* act_out, int64_t ldact);
+int sam3_lora_bwd_act(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B,
+                      void* gx_inout, float* gA_accum, float* gB_accum,
+                      int64_t M, int in_features, int out_features, int rank,
+                      int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling,
+                      float drop_p, uint64_t seed, uint64_t offset, int dtype, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream,
+                      int act, const void* pre_act, int64_t ldpre);
+
+/*
  * Merge for adapter-free inference: Wm[out, in] = W[out, in] + scaling * (A_c @ B_c)^T, fp32.
  * Replaces sam3_lora/lora/lora_layer.py:81-88 (merge_weights) and :160-178.
  */

@@ -26,8 +26,9 @@ EXPORTS = (
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_aug_scatter", "sam3_lora_fused_workspace_bytes", "sam3_lora_fwd_fused", "sam3_lora_bwd_fused",
-    "sam3_lora_packed_bytes", "sam3_lora_pack",
+    "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
 )
+ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
 VIT_EXPORTS = ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd", "sam3_vit_qkv_rope_win_fwd",
                "sam3_vit_qkv_rope_win_bwd", "sam3_vit_win_residual", "sam3_vit_layernorm_fwd",
@@ -73,6 +74,10 @@ def _declare(lib):
         c_float, c_uint64, c_uint64, c_int, c_int,             # drop_p, seed, offset, dtype, accumulate
         c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
     ]
+    lib.sam3_lora_fwd_act.restype = c_int
+    lib.sam3_lora_fwd_act.argtypes = list(lib.sam3_lora_fwd.argtypes) + [c_int, c_void_p, c_int64]
+    lib.sam3_lora_bwd_act.restype = c_int
+    lib.sam3_lora_bwd_act.argtypes = list(lib.sam3_lora_bwd.argtypes) + [c_int, c_void_p, c_int64]
     lib.sam3_lora_debug_set_stages.restype = ctypes.c_uint
     lib.sam3_lora_debug_set_stages.argtypes = [ctypes.c_uint]
     lib.sam3_lora_prof_start.restype = c_int

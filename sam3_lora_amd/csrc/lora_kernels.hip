@@ -272,6 +272,26 @@ __device__ __forceinline__ void mask8(f32x4& a, f32x4& b, unsigned keep) {
     }
 }
 
+// exact (erf) GELU, nn.GELU()'s default, and its derivative -- evaluated in fp32 on the ROUNDED pre-activation, as the
+// unfused elementwise kernels would see it
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+// ACT: 0 = none; 1 = forward, also write act(y_new) to AUX; 2 = backward, y_new *= act'(AUX) (AUX = pre-activation)
+__device__ __forceinline__ uint4 act8(uint4 y, uint4 h, int act) {
+    float v[8] = {bf_lo(y.x), bf_hi(y.x), bf_lo(y.y), bf_hi(y.y), bf_lo(y.z), bf_hi(y.z), bf_lo(y.w), bf_hi(y.w)};
+    if (act == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+    } else {
+        const float hv[8] = {bf_lo(h.x), bf_hi(h.x), bf_lo(h.y), bf_hi(h.y), bf_lo(h.z), bf_hi(h.z), bf_lo(h.w), bf_hi(h.w)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(hv[i]);
+    }
+    return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
 template <typename YT>
 struct YTile;  // 16 rows x 128 cols, lane L owns rows p*4 + (L>>4), cols (L&15)*8 .. +8
 
@@ -288,10 +308,10 @@ struct YTile<bf16_t> {
             else v[p] = (m < M && col < N) ? *reinterpret_cast<const uint4*>(Y + m * ldy + col) : zero4();
         }
     }
-    template <bool FAST, bool DROP>
+    template <bool FAST, bool DROP, int ACT>
     __device__ __forceinline__ void add_store(bf16_t* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
-                                              const DropKey& dk) {
+                                              const DropKey& dk, bf16_t* AUX, long long ldaux, const YTile<bf16_t>& haux) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
@@ -304,7 +324,10 @@ struct YTile<bf16_t> {
             o.y = pack2(bf_lo(v[p].y) + scale * a[2], bf_hi(v[p].y) + scale * a[3]);
             o.z = pack2(bf_lo(v[p].z) + scale * b[0], bf_hi(v[p].z) + scale * b[1]);
             o.w = pack2(bf_lo(v[p].w) + scale * b[2], bf_hi(v[p].w) + scale * b[3]);
-            if (FAST || (m < M && col < N)) *reinterpret_cast<uint4*>(Y + m * ldy + col) = o;
+            const bool ok = FAST || (m < M && col < N);
+            if (ACT == 2) o = act8(o, haux.v[p], 2);
+            if (ok) *reinterpret_cast<uint4*>(Y + m * ldy + col) = o;
+            if (ACT == 1 && ok) *reinterpret_cast<uint4*>(AUX + m * ldaux + col) = act8(o, o, 1);
         }
     }
 };
@@ -323,10 +346,10 @@ struct YTile<float> {
             v[p][1] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    template <bool FAST, bool DROP>
+    template <bool FAST, bool DROP, int ACT>
     __device__ __forceinline__ void add_store(float* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
-                                              const DropKey& dk) {
+                                              const DropKey& dk, float* AUX, long long ldaux, const YTile<float>& haux) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
@@ -335,17 +358,35 @@ struct YTile<float> {
             f32x4 b = *reinterpret_cast<const f32x4*>(slab + rl * ldw + (lane & 15) * 8 + 4);
             if (DROP) mask8(a, b, keep8((unsigned long long)m * dk.width + col, dk));
             if (FAST || (m < M && col < N)) {
-                *reinterpret_cast<f32x4*>(Y + m * ldy + col) = v[p][0] + scale * a;
-                *reinterpret_cast<f32x4*>(Y + m * ldy + col + 4) = v[p][1] + scale * b;
+                f32x4 o0 = v[p][0] + scale * a, o1 = v[p][1] + scale * b;
+                if (ACT == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o0[j] *= gelu_grad_f(haux.v[p][0][j]);
+                        o1[j] *= gelu_grad_f(haux.v[p][1][j]);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(Y + m * ldy + col) = o0;
+                *reinterpret_cast<f32x4*>(Y + m * ldy + col + 4) = o1;
+                if (ACT == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o0[j] = gelu_f(o0[j]);
+                        o1[j] = gelu_f(o1[j]);
+                    }
+                    *reinterpret_cast<f32x4*>(AUX + m * ldaux + col) = o0;
+                    *reinterpret_cast<f32x4*>(AUX + m * ldaux + col + 4) = o1;
+                }
             }
         }
     }
 };
 
-template <typename YT, int RT, bool DROP>
+template <typename YT, int RT, bool DROP, int ACT = 0>
 __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
-                                            int tiles_per_wg, DropKey dk) {
+                                            int tiles_per_wg, DropKey dk, YT* __restrict__ AUX = nullptr,
+                                            long long ldaux = 0) {
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
     __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,31 +439,35 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
     long long t = t_begin;
     if (t < t_fast_end) {
         // branch-free stream: tile t+4 (and its t fragment, issued first) is in flight while tile t is updated
-        YTile<YT> cur, nxt;
+        YTile<YT> cur, nxt, hcur, hnxt;      // hcur/hnxt: the pre-activation tile (ACT == 2 only)
         uint2 tlo, thi, nlo, nhi;
         load_t(t, nlo, nhi);
         nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
+        if (ACT == 2) hnxt.template load<true>(AUX, ldaux, t * 16, col, lane, M, N);
         for (; t < t_fast_end; t += 4) {
             cur = nxt;
+            if (ACT == 2) hcur = hnxt;
             tlo = nlo;
             thi = nhi;
             const long long tn = t + 4 < t_fast_end ? t + 4 : t;   // last iteration re-reads its own tile (L2 hit)
             load_t(tn, nlo, nhi);
             nxt.template load<true>(Y, ldy, tn * 16, col, lane, M, N);
+            if (ACT == 2) hnxt.template load<true>(AUX, ldaux, tn * 16, col, lane, M, N);
             delta_to_slab(tlo, thi);
             wave_sync();
-            cur.template add_store<true, DROP>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk);
+            cur.template add_store<true, DROP, ACT>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur);
             wave_sync();
         }
     }
     for (; t < t_end; t += 4) {   // ragged tiles (last rows / last column chunk): predicated path
-        YTile<YT> cur;
+        YTile<YT> cur, hcur;
         uint2 tlo, thi;
         load_t(t, tlo, thi);
         cur.template load<false>(Y, ldy, t * 16, col, lane, M, N);
+        if (ACT == 2) hcur.template load<false>(AUX, ldaux, t * 16, col, lane, M, N);
         delta_to_slab(tlo, thi);
         wave_sync();
-        cur.template add_store<false, DROP>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk);
+        cur.template add_store<false, DROP, ACT>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur);
         wave_sync();
     }
 }
@@ -1015,7 +1060,7 @@ if (RT == 1)
 
 template <typename YT>
 void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT,
-               hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
+               hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
     // 3 tiles per wave measured best on MI355X for both N = 4736 and N = 1024 at M = 41472 (sweep 4..48:
@@ -1025,13 +1070,17 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     tiles_per_wg = env_int("SAM3_LORA_T2_TPW", tiles_per_wg);
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
-#define T2_LAUNCH(RTV, DV) \
-    hipLaunchKernelGGL((k_t2<YT, RTV, DV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk)
-    if (RT == 1) {
-        if (dk.thr) T2_LAUNCH(1, true); else T2_LAUNCH(1, false);
-    } else {
-        if (dk.thr) T2_LAUNCH(2, true); else T2_LAUNCH(2, false);
-    }
+#define T2_LAUNCH(RTV, DV, AV) \
+    hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
+                       (YT*)aux, ldaux)
+#define T2_RT(RTV)                                                                     \
+    do {                                                                               \
+        if (act == 1) T2_LAUNCH(RTV, false, 1);            /* forward: no mask on y */   \
+        else if (act == 2) { if (dk.thr) T2_LAUNCH(RTV, true, 2); else T2_LAUNCH(RTV, false, 2); } \
+        else { if (dk.thr) T2_LAUNCH(RTV, true, 0); else T2_LAUNCH(RTV, false, 0); }    \
+    } while (0)
+    if (RT == 1) T2_RT(1); else T2_RT(2);
+#undef T2_RT
 #undef T2_LAUNCH
 }
 
@@ -1197,10 +1246,10 @@ int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, 
     return launch_ok("sam3_lora_pack");
 }
 
-int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
-                  int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
-                  float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
-                  void* stream) {
+static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
+                    int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
+                    float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
+                    void* stream, int act, void* act_out, int64_t ldact) {
     if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
@@ -1217,6 +1266,8 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
     if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
     if (tT_out && ((uintptr_t)tT_out & 15)) return fail(SAM3_LORA_EINVAL, "tT_out must be 16-byte aligned");
+    if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
+    if (act && (rc = check_act(act_out, ldact, out_features, dtype, "act_out"))) return rc;
 
     hipStream_t st = (hipStream_t)stream;
     const int RP = rpad(rank), RT = RP / 16;
@@ -1237,18 +1288,39 @@ int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, vo
     }
     if (dtype == SAM3_LORA_BF16) {
         if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
-        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T2))
+            launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
+                              act_out, ldact);
     } else {
         if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
-        if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st);
+        if (stage_on(SAM3_LORA_STAGE_T2))
+            launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
+                             act_out, ldact);
     }
     return launch_ok("sam3_lora_fwd");
 }
 
-int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
-                  float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
-                  int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
-                  uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+int sam3_lora_fwd(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
+                  int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
+                  float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    return fwd_impl(x, A, B, y_inout, tT_out, M, in_features, out_features, rank, ldx, ldy, layout, scaling, drop_p, seed,
+                    offset, dtype, workspace, workspace_bytes, stream, SAM3_LORA_ACT_NONE, nullptr, 0);
+}
+
+int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
+                      int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
+                      float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
+                      void* stream, int act, void* act_out, int64_t ldact) {
+    return fwd_impl(x, A, B, y_inout, tT_out, M, in_features, out_features, rank, ldx, ldy, layout, scaling, drop_p, seed,
+                    offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact);
+}
+
+static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
+                    float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
+                    int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
+                    uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
+                    int act, const void* pre_act, int64_t ldpre) {
     if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
@@ -1262,6 +1334,11 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
     float inv_keep; const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
     if (tT_saved && ((uintptr_t)tT_saved & 15)) return fail(SAM3_LORA_EINVAL, "tT_saved must be 16-byte aligned");
+    if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
+    if (act && !gx_inout) return fail(SAM3_LORA_EINVAL, "an activation derivative needs gx_inout");
+    if (act && (rc = check_act(pre_act, ldpre, in_features, dtype, "pre_act"))) return rc;
+    const int a2 = act ? 2 : 0;
+    void* hpre = const_cast<void*>(pre_act);
     const BwdWs w = bwd_ws(M, in_features, out_features, rank);
     if (!workspace || workspace_bytes < w.total)
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
@@ -1307,21 +1384,21 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
         else launch_t3_emit<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, W1b, GTP, GT, GTT, st);
         if (bf) {
             if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
-            if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
+            if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
         } else {
             if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
-            if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
+            if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
         }
     } else if (bf) {
         if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
         if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);     // gA^T = gt^T . x
-        if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
+        if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
     } else {
         if (s1) launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);
         if (gB_accum && s3b) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);
         if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
-        if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk);
+        if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
     }
     if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
         // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
@@ -1333,6 +1410,25 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
         hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling * inv_keep, accumulate);
     }
     return launch_ok("sam3_lora_bwd");
+}
+
+int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
+                  float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
+                  int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
+                  uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return bwd_impl(gy, x, tT_saved, A, B, gx_inout, gA_accum, gB_accum, M, in_features, out_features, rank, ldgy, ldx, ldgx,
+                    layout, scaling, drop_p, seed, offset, dtype, accumulate, workspace, workspace_bytes, stream,
+                    SAM3_LORA_ACT_NONE, nullptr, 0);
+}
+
+int sam3_lora_bwd_act(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
+                      float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
+                      int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
+                      uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
+                      int act, const void* pre_act, int64_t ldpre) {
+    return bwd_impl(gy, x, tT_saved, A, B, gx_inout, gA_accum, gB_accum, M, in_features, out_features, rank, ldgy, ldx, ldgx,
+                    layout, scaling, drop_p, seed, offset, dtype, accumulate, workspace, workspace_bytes, stream, act, pre_act,
+                    ldpre);
 }
 
 // ---- "augmented frozen GEMM" mode --------------------------------------------------------------------

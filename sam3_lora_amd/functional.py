@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import _ffi
 from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
-__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
+__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
 
 _ws_lock = threading.Lock()
 _workspaces = {}  # (device index, stream handle) -> uint8 tensor
@@ -142,8 +142,9 @@ class PackedOperands:
 
 def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tensor, scaling: float, layout: int,
               save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
-              packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """In place: y2[M,out] += scaling * (x2[M,in] @ A_c) @ B_c.  Returns the saved-t blob if asked."""
+              packed: Optional[torch.Tensor] = None, gelu_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """In place: y2[M,out] += scaling * (x2[M,in] @ A_c) @ B_c.  Returns the saved-t blob if asked.
+    ``gelu_out`` ([M,out], same dtype): additionally receives GELU(y2) from the same pass (sam3_lora_fwd_act)."""
     lib = _ffi.load()
     _require_cuda(x2, A, B, y2)
     M, fin = x2.shape
@@ -157,21 +158,27 @@ def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tens
         raise LoRAKernelError(f"sam3_lora_fwd_workspace_bytes: {_ffi.last_error()}")
     ws = _workspace(x2.device, nws)
     tT = saved_t_like(M, rank, x2.device) if save_t else None
-    rc = lib.sam3_lora_fwd(
-        x2.data_ptr(), (packed if packed is not None else A).data_ptr(), B.data_ptr(), y2.data_ptr(),
-        tT.data_ptr() if tT is not None else None,
-        M, fin, fout, rank, x2.stride(0), y2.stride(0), layout | (PREPACKED if packed is not None else 0), float(scaling),
-        float(drop_p), int(seed), int(offset), dt, ws.data_ptr(), ws.numel(),
-        ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
-    _ffi.check(rc, "sam3_lora_fwd")
+    args = (x2.data_ptr(), (packed if packed is not None else A).data_ptr(), B.data_ptr(), y2.data_ptr(),
+            tT.data_ptr() if tT is not None else None,
+            M, fin, fout, rank, x2.stride(0), y2.stride(0), layout | (PREPACKED if packed is not None else 0), float(scaling),
+            float(drop_p), int(seed), int(offset), dt, ws.data_ptr(), ws.numel(),
+            ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
+    if gelu_out is None:
+        _ffi.check(lib.sam3_lora_fwd(*args), "sam3_lora_fwd")
+    else:
+        if gelu_out.dtype != y2.dtype or gelu_out.shape != y2.shape or gelu_out.stride(1) != 1:
+            raise LoRAKernelError("sam3_lora_amd: gelu_out must match y in shape and dtype")
+        _ffi.check(lib.sam3_lora_fwd_act(*args, _ffi.ACT_GELU, gelu_out.data_ptr(), gelu_out.stride(0)), "sam3_lora_fwd_act")
     return tT
 
 
 def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor,
               gx2: Optional[torch.Tensor], gA: Optional[torch.Tensor], gB: Optional[torch.Tensor], scaling: float,
               layout: int, accumulate: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
-              packed: Optional[torch.Tensor] = None) -> None:
-    """In place: gx2 += lora input-grad; gA/gB (fp32, caller layout) = or += the LoRA weight grads."""
+              packed: Optional[torch.Tensor] = None, gelu_pre: Optional[torch.Tensor] = None) -> None:
+    """In place: gx2 += lora input-grad; gA/gB (fp32, caller layout) = or += the LoRA weight grads.
+    ``gelu_pre`` ([M,in]): the pre-activation whose GELU produced x; gx2 leaves multiplied by GELU'(gelu_pre)
+    (sam3_lora_bwd_act)."""
     lib = _ffi.load()
     _require_cuda(gy2, x2, A, B, gx2, gA, gB)
     M, fin = x2.shape
@@ -187,16 +194,20 @@ def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A
     if nws == 0:
         raise LoRAKernelError(f"sam3_lora_bwd_workspace_bytes: {_ffi.last_error()}")
     ws = _workspace(x2.device, nws)
-    rc = lib.sam3_lora_bwd(
-        gy2.data_ptr(), x2.data_ptr(), tT.data_ptr() if tT is not None else None,
-        (packed if packed is not None else A).data_ptr(), B.data_ptr(),
-        gx2.data_ptr() if gx2 is not None else None,
-        gA.data_ptr() if gA is not None else None, gB.data_ptr() if gB is not None else None,
-        M, fin, fout, rank, gy2.stride(0), x2.stride(0), gx2.stride(0) if gx2 is not None else fin,
-        layout | (PREPACKED if packed is not None else 0), float(scaling), float(drop_p), int(seed), int(offset), dt,
-        1 if accumulate else 0,
-        ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
-    _ffi.check(rc, "sam3_lora_bwd")
+    args = (gy2.data_ptr(), x2.data_ptr(), tT.data_ptr() if tT is not None else None,
+            (packed if packed is not None else A).data_ptr(), B.data_ptr(),
+            gx2.data_ptr() if gx2 is not None else None,
+            gA.data_ptr() if gA is not None else None, gB.data_ptr() if gB is not None else None,
+            M, fin, fout, rank, gy2.stride(0), x2.stride(0), gx2.stride(0) if gx2 is not None else fin,
+            layout | (PREPACKED if packed is not None else 0), float(scaling), float(drop_p), int(seed), int(offset), dt,
+            1 if accumulate else 0,
+            ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
+    if gelu_pre is None:
+        _ffi.check(lib.sam3_lora_bwd(*args), "sam3_lora_bwd")
+    else:
+        if gx2 is None or gelu_pre.dtype != x2.dtype or gelu_pre.shape != x2.shape or gelu_pre.stride(1) != 1:
+            raise LoRAKernelError("sam3_lora_amd: gelu_pre must match x in shape and dtype, and gx is required")
+        _ffi.check(lib.sam3_lora_bwd_act(*args, _ffi.ACT_GELU, gelu_pre.data_ptr(), gelu_pre.stride(0)), "sam3_lora_bwd_act")
 
 
 def merge_weight(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float, layout: int) -> torch.Tensor:
@@ -299,6 +310,78 @@ class _LoRALinearFn(torch.autograd.Function):
             gA = gA.to(A.dtype) if ctx.needs_input_grad[3] else None
             gB = gB.to(B.dtype) if ctx.needs_input_grad[4] else None
         return gx, None, None, gA, gB, None, None, None, None, None
+
+
+class _LoRAMlpFn(torch.autograd.Function):
+    """``fc2(GELU(fc1(x)))`` with both Linears LoRA-adapted, as ONE autograd node: the GELU and its derivative ride
+    on the adapters' in-place passes over the [M, hidden] tensor (``sam3_lora_fwd_act`` / ``sam3_lora_bwd_act``)
+    instead of being elementwise kernels of their own.  Saved: x, the pre-activation h, a = GELU(h), the two t^T."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, A1, B1, s1, W2, b2, A2, B2, s2, layout, drop_p, seed1, seed2, pk1, pk2):
+        _require_cuda(x, W1, W2, A1, B1, A2, B2)
+        cdt = W1.dtype
+        x2 = _rows(x if x.dtype == cdt else x.to(cdt))
+        need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
+        with torch.autocast("cuda", enabled=False):
+            h = F.linear(x2, W1, b1)
+        a = torch.empty_like(h)
+        t1 = lora_fwd_(x2, _master(A1), _master(B1), h, s1, layout, save_t=need_w, drop_p=drop_p, seed=seed1, packed=pk1,
+                       gelu_out=a)
+        with torch.autocast("cuda", enabled=False):
+            y = F.linear(a, W2, b2)
+        t2 = lora_fwd_(a, _master(A2), _master(B2), y, s2, layout, save_t=need_w, drop_p=drop_p, seed=seed2, packed=pk2)
+        ctx.meta = (s1, s2, layout, drop_p, seed1, seed2, x.shape, x.dtype)
+        ctx.pk = (pk1, pk2)
+        ctx.save_for_backward(x2, h, a, W1, W2, A1, B1, A2, B2, t1, t2)
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, h, a, W1, W2, A1, B1, A2, B2, t1, t2 = ctx.saved_tensors
+        s1, s2, layout, drop_p, seed1, seed2, x_shape, x_dtype = ctx.meta
+        pk1, pk2 = ctx.pk
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
+        gy2 = _rows(gy if gy.dtype == x2.dtype else gy.to(x2.dtype))
+        A1m, B1m, A2m, B2m = _master(A1), _master(B1), _master(A2), _master(B2)
+        gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
+        with torch.autocast("cuda", enabled=False):
+            ga = gy2 @ W2                                            # frozen GEMM
+        # fc2's adapter backward; its in-place pass over ga also applies GELU'(h): ga leaves as gh
+        lora_bwd_(gy2, a, t2, A2m, B2m, ga, gA2, gB2, s2, layout, drop_p=drop_p, seed=seed2, packed=pk2, gelu_pre=h)
+        gx2 = None
+        if need_x:
+            with torch.autocast("cuda", enabled=False):
+                gx2 = ga @ W1                                        # frozen GEMM
+        if need_x or need_w:
+            lora_bwd_(ga, x2, t1, A1m, B1m, gx2, gA1, gB1, s1, layout, drop_p=drop_p, seed=seed1, packed=pk1)
+        gx = gx2.view(x_shape).to(x_dtype) if need_x else None
+        g = lambda t, p, i: (t.to(p.dtype) if (t is not None and ctx.needs_input_grad[i]) else None)
+        return (gx, None, None, g(gA1, A1, 3), g(gB1, B1, 4), None, None, None, g(gA2, A2, 8), g(gB2, B2, 9), None, None,
+                None, None, None, None, None)
+
+
+def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool) -> Optional[torch.Tensor]:
+    """``fc2(GELU(fc1(x)))`` for two LoRA-wrapped Linears through :class:`_LoRAMlpFn`, or None when the fused form does
+    not apply (then the caller evaluates the three modules one by one).  ``fc1`` / ``fc2`` are
+    ``(weight, bias, lora_layer)`` triples; the lora layers carry ``lora_A, lora_B, scaling, dropout_p, _packed``."""
+    (W1, b1, l1), (W2, b2, l2) = fc1, fc2
+    ok = (x.is_cuda and x.numel() > 0 and W1.dtype in (torch.bfloat16, torch.float32) and W2.dtype == W1.dtype
+          and not W1.requires_grad and not W2.requires_grad and not torch.is_autocast_enabled("cuda")
+          and x.dtype == W1.dtype and all(d % 8 == 0 for d in (*W1.shape, *W2.shape))
+          and (b1 is None or b1.dtype == W1.dtype) and (b2 is None or b2.dtype == W1.dtype)
+          and l1.dropout_p == l2.dropout_p and max(_rank_of(l1.lora_A, layout), _rank_of(l2.lora_A, layout)) <= 32)
+    if not ok:
+        return None
+    p, seed1, seed2 = 0.0, 0, 0
+    if training and l1.dropout_p > 0.0:
+        p = float(l1.dropout_p)
+        seed1, seed2 = (int(v) for v in torch.randint(0, 2 ** 62, (2,)).tolist())
+    pk1 = l1._packed.get(l1.lora_A, l1.lora_B, int(layout))
+    pk2 = l2._packed.get(l2.lora_A, l2.lora_B, int(layout))
+    return _LoRAMlpFn.apply(x, W1, b1, l1.lora_A, l1.lora_B, float(l1.scaling), W2, b2, l2.lora_A, l2.lora_B,
+                            float(l2.scaling), int(layout), p, seed1, seed2, pk1, pk2)
 
 
 class AugmentedWeight:

@@ -60,7 +60,30 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, in_features)
         self.drop2 = nn.Dropout(0.0)
 
+    def _adapted(self):
+        """(layout, fc1 triple, fc2 triple) when both Linears carry a HIP LoRA adapter of the same family, else None."""
+        from . import lora_layers as root_api
+        from .functional import LAYOUT_PACKAGE, LAYOUT_ROOT
+        from .lora import lora_layer as pkg_api
+        f1, f2 = self.fc1, self.fc2
+        if isinstance(f1, root_api.LoRALinear) and isinstance(f2, root_api.LoRALinear):
+            return LAYOUT_ROOT, (f1.original_layer.weight, f1.original_layer.bias, f1.lora), \
+                (f2.original_layer.weight, f2.original_layer.bias, f2.lora)
+        if isinstance(f1, pkg_api.LinearWithLoRA) and isinstance(f2, pkg_api.LinearWithLoRA):
+            return LAYOUT_PACKAGE, (f1.linear.weight, f1.linear.bias, f1.lora), (f2.linear.weight, f2.linear.bias, f2.lora)
+        return None
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # both Linears adapted, exact GELU, no activation dropout: one fused node -- the GELU and its derivative ride on
+        # the adapters' in-place passes over [M, hidden] (functional.lora_mlp_gelu); otherwise module by module
+        if (x.is_cuda and isinstance(self.act, nn.GELU) and self.act.approximate == "none"
+                and isinstance(self.norm, nn.Identity) and not (self.training and (self.drop1.p > 0 or self.drop2.p > 0))):
+            ad = self._adapted()
+            if ad is not None:
+                from .functional import lora_mlp_gelu
+                y = lora_mlp_gelu(x, ad[1], ad[2], ad[0], self.training)
+                if y is not None:
+                    return y
         return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
 
 

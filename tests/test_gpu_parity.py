@@ -514,3 +514,91 @@ def test_one_pass_backward_matches_two_pass(shape, dtype, monkeypatch):
         assert _relmax(res["one"][0], gx_r) < 1e-2
         assert _relmax(res["one"][1], gA_r) < 1e-2
         assert _relmax(res["one"][2], gB_r) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("rank,drop", [(16, 0.0), (16, 0.2), (24, 0.0)])
+def test_activation_fused_entry_points(dtype, rank, drop):
+    """sam3_lora_fwd_act / sam3_lora_bwd_act: the update itself is bit-identical to the plain entry points; the extra
+    output is GELU of the (rounded) updated tensor, the backward's gx is the plain gx times GELU'(pre-activation) --
+    both against torch's own exact GELU evaluated in fp32, to one rounding of the activation dtype."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(rank)
+    M, fin, fout = 777, 264, 520          # ragged rows and a ragged last column chunk
+    x = torch.randn(M, fin, device=DEV, generator=g).to(td)
+    base = torch.randn(M, fout, device=DEV, generator=g).to(td)
+    A = torch.randn(fin, rank, device=DEV, generator=g) / fin ** 0.5
+    B = torch.randn(rank, fout, device=DEV, generator=g) / rank ** 0.5
+    y_plain, y_act = base.clone(), base.clone()
+    act = torch.empty_like(base)
+    Fn.lora_fwd_(x, A, B, y_plain, 2.0, cases.LAYOUT_ROOT)
+    Fn.lora_fwd_(x, A, B, y_act, 2.0, cases.LAYOUT_ROOT, gelu_out=act)
+    assert torch.equal(y_plain, y_act)
+    want = torch.nn.functional.gelu(y_plain.float())
+    tol = 2 ** -8 if dtype == "bf16" else 1e-6
+    assert (act.float() - want).abs().max() <= tol * want.abs().max() + 1e-6
+    # backward: layer [M, fout] -> [M, fin'] consuming GELU(h); here h := a random pre-activation of x's shape
+    gy = torch.randn(M, fout, device=DEV, generator=g).to(td)
+    h = torch.randn(M, fin, device=DEV, generator=g).to(td)
+    gbase = torch.randn(M, fin, device=DEV, generator=g).to(td)
+    res = {}
+    for mode in ("plain", "act"):
+        gx = gbase.clone()
+        gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+        Fn.lora_bwd_(gy, x, None, A, B, gx, gA, gB, 2.0, cases.LAYOUT_ROOT, drop_p=drop, seed=9,
+                     gelu_pre=h if mode == "act" else None)
+        res[mode] = (gx, gA, gB)
+    assert torch.equal(res["plain"][1], res["act"][1]) and torch.equal(res["plain"][2], res["act"][2])
+    hf = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hf).sum().backward()
+    want = res["plain"][0].float() * hf.grad
+    assert (res["act"][0].float() - want).abs().max() <= tol * want.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("api", ["root", "package"])
+@pytest.mark.parametrize("dtype,drop", [("f32", 0.0), ("bf16", 0.0), ("bf16", 0.1)])
+def test_fused_lora_mlp_equals_module_by_module(api, dtype, drop, monkeypatch):
+    """vit.Mlp with both Linears adapted: the fused node (GELU inside the adapters' passes) against fc1 -> GELU -> fc2
+    evaluated module by module on the same HIP adapters; with dropout the two forms consume the seed stream
+    differently, so only eval-mode equality and training-mode finiteness / mask statistics are checked there."""
+    from sam3_lora_amd import vit as V
+    from sam3_lora_amd import functional as F_
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    torch.manual_seed(3)
+    mlp = V.Mlp(64, 264)
+    if api == "root":
+        mlp.fc1, mlp.fc2 = (root_api.LoRALinear(l, rank=8, alpha=16, dropout=drop) for l in (mlp.fc1, mlp.fc2))
+    else:
+        mlp.fc1, mlp.fc2 = (pkg_api.LinearWithLoRA(l, rank=8, alpha=16, dropout=drop) for l in (mlp.fc1, mlp.fc2))
+    for p in mlp.parameters():
+        p.requires_grad_("lora_" in "".join(n for n, q in mlp.named_parameters() if q is p))
+    mlp.to(DEV)
+    for n, p in mlp.named_parameters():
+        if "lora_" in n:
+            torch.nn.init.normal_(p, std=0.3)
+        else:
+            p.data = p.data.to(td)
+    x = torch.randn(5, 37, 64, device=DEV).to(td)
+    gy = torch.randn(5, 37, 64, device=DEV).to(td)
+    mlp.train(drop == 0.0)          # with dropout: compare in eval mode (no mask), see docstring
+    outs = {}
+    for mode in ("fused", "modules"):
+        if mode == "modules":
+            monkeypatch.setattr(F_, "lora_mlp_gelu", lambda *a, **k: None)
+        xi = x.clone().requires_grad_(True)
+        mlp.zero_grad()
+        y = mlp(xi)
+        y.backward(gy)
+        outs[mode] = [y.detach().float(), xi.grad.float()] + [p.grad.clone() for n, p in mlp.named_parameters() if "lora_" in n]
+    assert type(mlp(x.clone().requires_grad_(True)).grad_fn).__name__ != "_LoRAMlpFnBackward"      # patched: module path
+    tol = 2e-3 if dtype == "f32" else 3e-2
+    for a, b in zip(outs["fused"], outs["modules"]):
+        assert (a - b).abs().max() <= tol * (b.abs().max() + 1e-6)
+    monkeypatch.undo()
+    y = mlp(x.clone().requires_grad_(True))
+    assert type(y.grad_fn).__name__ == "_LoRAMlpFnBackward"
+    if drop > 0.0:
+        mlp.train()
+        y = mlp(x.clone().requires_grad_(True))
+        y.backward(gy)
+        assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for n, p in mlp.named_parameters() if "lora_" in n)
