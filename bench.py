@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (weak scaling)")
     ap.add_argument("--blocks", type=int, default=N_BLOCKS)
     ap.add_argument("--dropout", type=float, default=0.0, help="LoRA dropout p (literal full_lora_config.yaml: 0.1)")
+    ap.add_argument("--act-dtype", choices=["bf16", "f32"], default="bf16",
+                    help="activation dtype (f32 = the reference's un-autocast precision; contracted as bf16 on the MFMAs)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -55,7 +57,7 @@ def parse():
 class Workload:
     """Synthetic, HBM-resident state of the adapter path of one ViT trunk."""
 
-    def __init__(self, dev, batch, rank, blocks, seed, dropout=0.0):
+    def __init__(self, dev, batch, rank, blocks, seed, dropout=0.0, act_dtype=torch.bfloat16):
         from sam3_lora_amd.ddp import LoRAGradReducer
         self.dev, self.rank, self.blocks = dev, rank, blocks
         self.M = batch * TOKENS
@@ -65,7 +67,7 @@ class Workload:
         M = self.M
 
         def act(cols):
-            return torch.randn(M, cols, device=dev, generator=g, dtype=torch.float32).bfloat16()
+            return torch.randn(M, cols, device=dev, generator=g, dtype=torch.float32).to(act_dtype)
 
         # two rotating activation sets so consecutive blocks never reuse the same lines
         self.x1 = [act(D_MODEL) for _ in range(2)]
@@ -84,10 +86,14 @@ class Workload:
             params += [self.A1[b], self.B1[b], self.A2[b], self.B2[b]]
         self.reducer = LoRAGradReducer(params, bucket_bytes=8 << 20)
         self.params = params
+        self.tT1 = [None] * blocks       # t^T saved by the forward (no-recompute schedule)
+        self.tT2 = [None] * blocks
         self.P1 = [None] * blocks        # operand images of (A1, B1) / (A2, B2), re-packed every step
         self.P2 = [None] * blocks
 
-    def step(self):
+    def step(self, recompute=True):
+        """recompute=True: the reference's schedule (every block re-evaluated in backward under activation
+        checkpointing).  recompute=False: the schedule 288 GB of HBM allow -- t saved by the one forward."""
         from sam3_lora_amd.functional import lora_bwd_, lora_fwd_, pack_operands
         s, L, dp = self.scaling, 0, self.dropout
         prepack = os.environ.get("BENCH_PREPACK", "1") != "0"
@@ -99,15 +105,21 @@ class Workload:
                     self.P1[b] = pack_operands(self.A1[b], self.B1[b], L, out=self.P1[b])
                     self.P2[b] = pack_operands(self.A2[b], self.B2[b], L, out=self.P2[b])
                 p1, p2 = (self.P1[b], self.P2[b]) if prepack else (None, None)
-                lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, drop_p=dp, seed=2 * b, packed=p1)
-                lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, drop_p=dp, seed=2 * b + 1, packed=p2)
+                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=not recompute, drop_p=dp,
+                               seed=2 * b, packed=p1)
+                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=not recompute, drop_p=dp,
+                               seed=2 * b + 1, packed=p2)
+                self.tT1[b], self.tT2[b] = t1, t2
             for b in reversed(range(self.blocks)):             # per-block recompute, then backward
                 k = b & 1
                 p1, p2 = (self.P1[b], self.P2[b]) if prepack else (None, None)
-                t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True, drop_p=dp, seed=2 * b,
-                               packed=p1)
-                t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True, drop_p=dp,
-                               seed=2 * b + 1, packed=p2)
+                if recompute:
+                    t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=True, drop_p=dp, seed=2 * b,
+                                   packed=p1)
+                    t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=True, drop_p=dp,
+                                   seed=2 * b + 1, packed=p2)
+                else:
+                    t1, t2 = self.tT1[b], self.tT2[b]
                 lora_bwd_(self.g2[k], self.h[k], t2, self.A2[b], self.B2[b], self.gh[k],
                           self.A2[b].grad, self.B2[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b + 1, packed=p2)
                 lora_bwd_(self.gh[k], self.x1[k], t1, self.A1[b], self.B1[b], self.g1[k],
@@ -170,7 +182,7 @@ def insitu_kernels(w, steps=2):
     if n < 0:
         raise RuntimeError(_ffi.last_error())
     M, r = w.M, w.rank
-    RP, e = (16 if r <= 16 else 32), 2
+    RP, e = (16 if r <= 16 else 32), w.x1[0].element_size()
     one_pass = r <= 16 and os.environ.get("SAM3_LORA_TWO_PASS_GY", "0") in ("", "0")
     names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2",
              _ffi.STAGE_T3_GB: "k_t3+gt" if one_pass else "k_t3", _ffi.STAGE_T3_GA: "k_t3",
@@ -209,7 +221,7 @@ def insitu_kernels(w, steps=2):
 def op_table(w, iters):
     """Whole C-ABI calls (all their kernels) against SURVEY section 8(d)'s per-unit algorithmic bytes."""
     from sam3_lora_amd.functional import lora_bwd_, lora_fwd_, pack_operands
-    M, r, s, e = w.M, w.rank, w.scaling, 2
+    M, r, s, e = w.M, w.rank, w.scaling, w.x1[0].element_size()
     x1, h, y2, g2, gh, g1 = w.x1[0], w.h[0], w.y2[0], w.g2[0], w.gh[0], w.g1[0]
     A1, B1, A2, B2 = w.A1[0], w.B1[0], w.A2[0], w.B2[0]
     gA1, gB1, gA2, gB2 = (torch.zeros_like(p) for p in (A1, B1, A2, B2))
@@ -238,7 +250,7 @@ def op_table(w, iters):
     return ops
 
 
-def trunk_step_bench(dev, batch, rank, steps, world):
+def trunk_step_bench(dev, batch, rank, steps, world, checkpoint=True):
     """The adapters in their real host: the SAM3 ViT-Det trunk (sam3_lora_amd/vit.py, 32 blocks, 1008^2 input,
     random init, frozen weights bf16) with root-API LoRA on fc1/fc2, one training step = forward with per-block
     activation checkpointing + backward + flat-buffer gradient exchange + AdamW on A/B.  Frozen GEMMs, SDPA,
@@ -251,7 +263,7 @@ def trunk_step_bench(dev, batch, rank, steps, world):
     from sam3_lora_amd.ddp import LoRAGradReducer
     torch.manual_seed(0)
     with torch.device(dev):
-        model = V.sam3_vit()
+        model = V.sam3_vit(use_act_checkpoint=checkpoint)
     with contextlib.redirect_stdout(io.StringIO()):
         L.apply_lora_to_model(model, L.LoRAConfig(rank=rank, alpha=2 * rank, dropout=0.0, target_modules=["fc1", "fc2"],
                                                   apply_to_text_encoder=False, apply_to_detr_encoder=False,
@@ -304,7 +316,8 @@ def trunk_step_bench(dev, batch, rank, steps, world):
                loss_finite=bool(torch.isfinite(loss).item()), trainable_parameters=n_lora,
                peak_mem_gb=round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                workload=f"SAM3 ViT-Det trunk only (32 blocks, 1024-d, 72x72 tokens), batch {batch}/GPU @ 1008^2, bf16 frozen "
-                        f"weights, LoRA r={rank} on 64 MLP Linears, per-block activation checkpointing, synthetic feature loss, "
+                        f"weights, LoRA r={rank} on 64 MLP Linears, "
+                        f"{'per-block activation checkpointing' if checkpoint else 'NO activation checkpointing'}, synthetic feature loss, "
                         f"AdamW on A/B, flat-buffer all-reduce")
     del model, opt, red, img, tgt
     torch.cuda.empty_cache()
@@ -378,7 +391,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank, dropout=args.dropout)
+    w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank, dropout=args.dropout,
+                 act_dtype=torch.bfloat16 if args.act_dtype == "bf16" else torch.float32)
 
     def barrier():
         if world > 1:
@@ -408,7 +422,7 @@ def main():
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": args.act_dtype, "data": "synthetic",
             "config": {"workload": "full_lora_config.yaml @ r=%d alpha=%d (configs[1]): batch %d/GPU @ 1024^2 -> 1008^2 "
                                    "(M=%d rows), %d ViT blocks x {fc1 1024->4736, fc2 4736->1024}, bf16 activations, "
                                    "fp32 A/B + fp32 grad accumulation; frozen GEMMs/attention/DETR/loss excluded"
@@ -416,6 +430,23 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": w.reducer.nbytes, "finite": bool(finite)},
         }
+    # the same path without the checkpoint recompute (t saved by the forward; 2.6 MB per layer): what a trunk that
+    # keeps its activations in 288 GB of HBM needs from the adapters.  Reported beside `value`, never instead of it.
+    for _ in range(2):
+        w.step(recompute=False)
+    barrier()
+    t0 = time.perf_counter()
+    nr_steps = max(2, min(args.steps, 5))
+    for _ in range(nr_steps):
+        w.step(recompute=False)
+    barrier()
+    tnr = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tnr, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out["no_recompute"] = {"value": round(world * args.batch * nr_steps / float(tnr.item()), 2), "unit": "images/s",
+                               "ms_per_step": round(float(tnr.item()) / nr_steps * 1e3, 3), "steps": nr_steps,
+                               "schedule": "64 x sam3_lora_pack + 64 x sam3_lora_fwd (saving t) + 64 x sam3_lora_bwd"}
     rows = None
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the gradient all-reduce: a rank-0-only run would
@@ -440,8 +471,10 @@ def main():
         del w
         torch.cuda.empty_cache()
         tr = trunk_step_bench(dev, args.batch, args.rank, args.trunk_steps, world)
+        tr2 = trunk_step_bench(dev, args.batch, args.rank, args.trunk_steps, world, checkpoint=False)
         if rank == 0:
             out["trunk_step"] = tr
+            out["trunk_step_no_checkpoint"] = tr2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.rank)
     if rank == 0:

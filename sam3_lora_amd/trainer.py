@@ -128,7 +128,7 @@ def match_all_steps(matcher, stage_outputs: Sequence, stage_targets: Sequence[Di
 
 class SAM3TrainerNative:
     def __init__(self, config_path: str, model_builder: Optional[Callable] = None,
-                 data_builder: Optional[Callable] = None, bf16_frozen: bool = False):
+                 data_builder: Optional[Callable] = None, bf16_frozen: bool = False, act_checkpoint: str = "keep"):
         self.config_path = config_path
         self.config = load_config(config_path)
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,6 +155,11 @@ class SAM3TrainerNative:
         if bf16_frozen:         # MI355X layout: frozen tensors bf16, A/B fp32 masters (not a reference behaviour)
             from .vit import to_training_layout
             to_training_layout(self.model)
+        if act_checkpoint != "keep":   # "auto" | "on" | "off" for this library's ViT trunk (vit.set_activation_checkpointing)
+            from .vit import set_activation_checkpointing
+            mode = {"on": True, "off": False}.get(act_checkpoint, "auto")
+            used = set_activation_checkpointing(self.model, mode, batch=int(self.config["training"]["batch_size"]))
+            self._say(f"Activation checkpointing of the ViT trunk: {'on' if used else 'off'} ({act_checkpoint})")
 
         trainable = [p for p in self.model.parameters() if p.requires_grad]
         self.optimizer = AdamW(trainable, lr=float(self.config["training"]["learning_rate"]),
@@ -257,10 +262,12 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     parser.add_argument("--model-builder", type=str, default=None, help="module:function -> nn.Module (see trainer.py)")
     parser.add_argument("--data-builder", type=str, default=None, help="module:function -> batches for a split")
     parser.add_argument("--bf16-frozen", action="store_true", help="keep frozen tensors in bf16 (A/B stay fp32)")
+    parser.add_argument("--act-checkpoint", choices=["keep", "auto", "on", "off"], default="keep",
+                        help="per-block recompute of this library's ViT trunk; auto = off when the activations fit in HBM")
     args = parser.parse_args(argv)
     trainer = SAM3TrainerNative(
         args.config,
         model_builder=resolve_builder(args.model_builder, "SAM3_LORA_MODEL_BUILDER", "model"),
         data_builder=resolve_builder(args.data_builder, "SAM3_LORA_DATA_BUILDER", "data"),
-        bf16_frozen=args.bf16_frozen)
+        bf16_frozen=args.bf16_frozen, act_checkpoint=args.act_checkpoint)
     trainer.train()

@@ -134,7 +134,9 @@ def test_no_validation_split_copies_last_to_best(tmp_path):
     sys.path.insert(0, HERE)
     import toy_sam3
     path, cfg = _write(tmp_path, toy_no_valid=True)
-    tr = T.SAM3TrainerNative(path, model_builder=toy_sam3.model_builder, data_builder=toy_sam3.data_builder, bf16_frozen=True)
+    tr = T.SAM3TrainerNative(path, model_builder=toy_sam3.model_builder, data_builder=toy_sam3.data_builder, bf16_frozen=True,
+                             act_checkpoint="auto")
+    assert tr.model.backbone.vision_backbone.trunk.use_act_checkpoint is False      # a toy trunk always fits
     res = tr.train()
     out = tmp_path / "out"
     assert res["best_val_loss"] is None and not (out / "val_stats.json").exists()

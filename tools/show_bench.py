@@ -12,5 +12,10 @@ for k in d.get("ops", []):
 if "trunk_step" in d:
     t = d["trunk_step"]
     print("trunk_step", t["images_per_s"], "img/s", t["ms_per_step"], "ms/step, peak", t["peak_mem_gb"], "GB, finite", t["loss_finite"])
+if "trunk_step_no_checkpoint" in d:
+    t = d["trunk_step_no_checkpoint"]
+    print("trunk_step (no activation checkpointing)", t["images_per_s"], "img/s", t["ms_per_step"], "ms/step, peak", t["peak_mem_gb"], "GB")
+if "no_recompute" in d:
+    print("adapter path without recompute", d["no_recompute"]["value"], "img/s", d["no_recompute"]["ms_per_step"], "ms/step")
 if "cpu_baseline" in d:
     print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
