@@ -44,11 +44,44 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// Streamed-once activation reads (k_t1, k_t3, k_t3e, the pre-activation tile of k_t2<ACT=2>, the gt partials) are
+// issued NON-TEMPORAL (`global_load ... nt`): they are consumed exactly once, and keeping them out of L2 / Infinity
+// Cache measured -10 % on the whole adapter step on MI355X (same-box A/B, profiles/r01e_nt_loads.txt: k_t3 96.7 -> 70.9
+// us, k_t1 85.5 -> 77.6 us, k_t3e 107.9 -> 87.3 us at 4736 columns).  The read half of k_t2's in-place update must NOT
+// be non-temporal (122 -> 145 us), and non-temporal stores change nothing -- both stay compile-time switches.
+#ifndef SAM3_NT_LOADS
+#define SAM3_NT_LOADS 1
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ uint4 ldg16(const void* p) {
+#if SAM3_NT_LOADS
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(t[0], t[1], t[2], t[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ uint4 ldg16_rmw(const void* p) {     // the read half of an in-place update
+#if defined(SAM3_NT_RMW) && SAM3_NT_RMW
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(t[0], t[1], t[2], t[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ void stg16(void* p, uint4 v) {       // streamed-out result
+#if defined(SAM3_NT_STORES) && SAM3_NT_STORES
+    const u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
 // 8 consecutive activation elements -> packed bf16x8 (as uint4)
-__device__ __forceinline__ uint4 load8(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 load8(const bf16_t* p) { return ldg16(p); }
 __device__ __forceinline__ uint4 load8(const float* p) {
-    const float4 a = *reinterpret_cast<const float4*>(p);
-    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    const float4 a = __builtin_bit_cast(float4, ldg16(p));
+    const float4 b = __builtin_bit_cast(float4, ldg16(p + 4));
     return make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
 }
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
@@ -136,15 +169,15 @@ struct Raw8;  // 8 consecutive activation elements exactly as loaded (conversion
 template <>
 struct Raw8<bf16_t> {
     uint4 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void load(const bf16_t* p) { v = ldg16(p); }
     __device__ __forceinline__ uint4 packed() const { return v; }
 };
 template <>
 struct Raw8<float> {
     float4 a, b;
     __device__ __forceinline__ void load(const float* p) {
-        a = *reinterpret_cast<const float4*>(p);
-        b = *reinterpret_cast<const float4*>(p + 4);
+        a = __builtin_bit_cast(float4, ldg16(p));
+        b = __builtin_bit_cast(float4, ldg16(p + 4));
     }
     __device__ __forceinline__ uint4 packed() const {
         return make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
@@ -298,14 +331,15 @@ struct YTile;  // 16 rows x 128 cols, lane L owns rows p*4 + (L>>4), cols (L&15)
 template <>
 struct YTile<bf16_t> {
     uint4 v[4];
-    template <bool FAST>
+    template <bool FAST, bool STREAM = false>     // STREAM: read once and not written back (the pre-activation tile)
     __device__ __forceinline__ void load(const bf16_t* Y, long long ldy, long long m0, int col, int lane,
                                          long long M, int N) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const long long m = m0 + p * 4 + (lane >> 4);
-            if (FAST) v[p] = *reinterpret_cast<const uint4*>(Y + m * ldy + col);
-            else v[p] = (m < M && col < N) ? *reinterpret_cast<const uint4*>(Y + m * ldy + col) : zero4();
+            const bf16_t* src = Y + m * ldy + col;
+            if (FAST) v[p] = STREAM ? ldg16(src) : ldg16_rmw(src);
+            else v[p] = (m < M && col < N) ? (STREAM ? ldg16(src) : ldg16_rmw(src)) : zero4();
         }
     }
     template <bool FAST, bool DROP, int ACT>
@@ -326,8 +360,8 @@ struct YTile<bf16_t> {
             o.w = pack2(bf_lo(v[p].w) + scale * b[2], bf_hi(v[p].w) + scale * b[3]);
             const bool ok = FAST || (m < M && col < N);
             if (ACT == 2) o = act8(o, haux.v[p], 2);
-            if (ok) *reinterpret_cast<uint4*>(Y + m * ldy + col) = o;
-            if (ACT == 1 && ok) *reinterpret_cast<uint4*>(AUX + m * ldaux + col) = act8(o, o, 1);
+            if (ok) stg16(Y + m * ldy + col, o);
+            if (ACT == 1 && ok) stg16(AUX + m * ldaux + col, act8(o, o, 1));
         }
     }
 };
@@ -335,7 +369,7 @@ struct YTile<bf16_t> {
 template <>
 struct YTile<float> {
     f32x4 v[4][2];
-    template <bool FAST>
+    template <bool FAST, bool STREAM = false>
     __device__ __forceinline__ void load(const float* Y, long long ldy, long long m0, int col, int lane,
                                          long long M, int N) {
 #pragma unroll
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
         uint2 tlo, thi, nlo, nhi;
         load_t(t, nlo, nhi);
         nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
-        if (ACT == 2) hnxt.template load<true>(AUX, ldaux, t * 16, col, lane, M, N);
+        if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, t * 16, col, lane, M, N);
         for (; t < t_fast_end; t += 4) {
             cur = nxt;
             if (ACT == 2) hcur = hnxt;
@@ -452,7 +486,7 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
             const long long tn = t + 4 < t_fast_end ? t + 4 : t;   // last iteration re-reads its own tile (L2 hit)
             load_t(tn, nlo, nhi);
             nxt.template load<true>(Y, ldy, tn * 16, col, lane, M, N);
-            if (ACT == 2) hnxt.template load<true>(AUX, ldaux, tn * 16, col, lane, M, N);
+            if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, tn * 16, col, lane, M, N);
             delta_to_slab(tlo, thi);
             wave_sync();
             cur.template add_store<true, DROP, ACT>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur);
@@ -464,7 +498,7 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
         uint2 tlo, thi;
         load_t(t, tlo, thi);
         cur.template load<false>(Y, ldy, t * 16, col, lane, M, N);
-        if (ACT == 2) hcur.template load<false>(AUX, ldaux, t * 16, col, lane, M, N);
+        if (ACT == 2) hcur.template load<false, true>(AUX, ldaux, t * 16, col, lane, M, N);
         delta_to_slab(tlo, thi);
         wave_sync();
         cur.template add_store<false, DROP, ACT>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur);
@@ -789,7 +823,8 @@ __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP
     const long long m = idx >> 2;
     const int r0 = (int)(idx & 3) * 4;
     f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nchunks; ++c) s4 += *reinterpret_cast<const f32x4*>(GTP + ((long long)c * Mp + m) * 16 + r0);
+    for (int c = 0; c < nchunks; ++c)
+        s4 += __builtin_bit_cast(f32x4, ldg16(GTP + ((long long)c * Mp + m) * 16 + r0));
     uint2 v;
     v.x = pack2(s4[0], s4[1]);
     v.y = pack2(s4[2], s4[3]);

@@ -39,6 +39,27 @@ __device__ __forceinline__ F8 ld8(const float* p) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     return F8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
 }
+// read-once streams (the fused qkv activation, SDPA's gradients, the window-order branch output) bypass the caches
+typedef __attribute__((ext_vector_type(4))) unsigned vu32x4;
+typedef __attribute__((ext_vector_type(4))) float vf32x4;
+#ifndef SAM3_NT_LOADS
+#define SAM3_NT_LOADS 1
+#endif
+__device__ __forceinline__ F8 ld8_nt(const bf16_t* p) {
+#if !SAM3_NT_LOADS
+    return ld8(p);
+#endif
+    const vu32x4 u = __builtin_nontemporal_load(reinterpret_cast<const vu32x4*>(p));
+    return F8{{vlo(u[0]), vhi(u[0]), vlo(u[1]), vhi(u[1]), vlo(u[2]), vhi(u[2]), vlo(u[3]), vhi(u[3])}};
+}
+__device__ __forceinline__ F8 ld8_nt(const float* p) {
+#if !SAM3_NT_LOADS
+    return ld8(p);
+#endif
+    const vf32x4 a = __builtin_nontemporal_load(reinterpret_cast<const vf32x4*>(p));
+    const vf32x4 b = __builtin_nontemporal_load(reinterpret_cast<const vf32x4*>(p + 4));
+    return F8{{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}};
+}
 __device__ __forceinline__ void st8(bf16_t* p, const F8& f) {
     *reinterpret_cast<uint4*>(p) =
         make_uint4(vpack2(f.v[0], f.v[1]), vpack2(f.v[2], f.v[3]), vpack2(f.v[4], f.v[5]), vpack2(f.v[6], f.v[7]));
@@ -93,7 +114,7 @@ __global__ __launch_bounds__(256) void k_qkv_rope_fwd(const T* __restrict__ qkv,
     const int hd8 = H * D / 8;
     const int which = c / hd8, ch = c % hd8;     // chunk inside the [H, D] slab
     const int d0 = (ch * 8) % D;                 // first element index inside the head
-    F8 f = ld8(qkv + img_token(tok, L, wm) * (3LL * H * D) + (long long)c * 8);
+    F8 f = ld8_nt(qkv + img_token(tok, L, wm) * (3LL * H * D) + (long long)c * 8);
     T* dst = (which == 0 ? q : which == 1 ? k : v) + tok * ((long long)H * D) + (long long)ch * 8;
     if (which < 2) {
         const int l = (int)(tok % L);
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(256) void k_qkv_rope_bwd(const T* __restrict__ gq, 
     const long long b = tok / L;
     const int l = (int)(tok % L);
     const T* src = (which == 0 ? gq : which == 1 ? gk : gv) + b * sb + (long long)h * sh + (long long)l * sl + d0;
-    F8 f = ld8(src);
+    F8 f = ld8_nt(src);
     if (which < 2) {
         const float4 cc = *reinterpret_cast<const float4*>(cs + (long long)l * (D / 2) + d0 / 2);
         const float4 ss = *reinterpret_cast<const float4*>(sn + (long long)l * (D / 2) + d0 / 2);
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(256) void k_win_residual(const T* __restrict__ x, c
         for (int i = 0; i < 8; ++i) f.v[i] *= sc;
         st8(out + tok * C + (long long)c * 8, f);
     } else {
-        const F8 a = ld8(x + it * C + (long long)c * 8), b = ld8(h + tok * C + (long long)c * 8);
+        const F8 a = ld8(x + it * C + (long long)c * 8), b = ld8_nt(h + tok * C + (long long)c * 8);
         F8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o.v[i] = a.v[i] + sc * b.v[i];
