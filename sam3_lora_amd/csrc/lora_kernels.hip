@@ -9,6 +9,11 @@
 //   T2  k_t2   Y[M,N]   += s * T[M,r] . W2[r,N]    rank-r update  (y += s.t.B ; gx += s.gt.A^T)
 //   T3  k_t3   G[r,N]    = T^T[r,M] . X[M,N]       column reduction over M (gB ; gA), split over
 //                                                  row ranges, fixed-order second-stage sum
+//   T3E k_t3e  T3 over gy AND gt = gy.B^T from the same pass (r <= 16): the backward reads gy once;
+//              k_gt_reduce sums the per-column-pair partials of gt in fixed order
+//   T2 also carries the MLP's activation: ACT=1 writes GELU(y) beside y, ACT=2 multiplies by GELU'(h)
+//
+// Read-once activation streams are loaded non-temporal; the read half of T2's in-place update is not.
 //
 // MFMA operand roles are chosen so that no result ever needs a cross-lane shuffle:
 //   * T1 computes t^T (A-operand = LoRA weight, B-operand = activation rows): the C/D layout
