@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import _ffi
 from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
-__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
+__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
 
 _ws_lock = threading.Lock()
 _workspaces = {}  # (device index, stream handle) -> uint8 tensor
@@ -140,6 +140,55 @@ class PackedOperands:
         return self.blob
 
 
+class TransposedCopy:
+    """``W^T`` (contiguous) of a FROZEN weight, kept beside it so that the input-gradient GEMM runs as
+    ``F.linear(gy, W^T)`` (hipBLASLt's TN form) instead of ``gy @ W`` (NN): measured on MI355X at M = 41,472
+    (tools/nn_vs_tn_probe.py) 349 vs 446 us for fc2, 296 vs 338 us for fc1, 77 vs 90 us for proj, 190 vs 225 us for qkv.
+    Costs one extra copy of the frozen weights in HBM (0.9 GB for the SAM3 trunk in bf16)."""
+
+    def __init__(self):
+        self.t = None
+        self._stamp = None
+
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        stamp = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
+        if stamp != self._stamp:
+            self.t = w.detach().t().contiguous()
+            self._stamp = stamp
+        return self.t
+
+
+def _dx(gy2: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor]) -> torch.Tensor:
+    """Input gradient of a frozen linear: ``gy2 @ w``, through the transposed copy when one of gy2's dtype is at hand."""
+    if wt is not None and wt.dtype == gy2.dtype and wt.shape == (w.shape[1], w.shape[0]):
+        return F.linear(gy2, wt)
+    return gy2 @ w
+
+
+class _FrozenLinearFn(torch.autograd.Function):
+    """``F.linear`` with a frozen weight whose backward uses the transposed copy (no weight / bias gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wt):
+        ctx.save_for_backward(weight, wt)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, wt = ctx.saved_tensors
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        return _dx(gy2, weight, wt).view(*gy.shape[:-1], weight.shape[1]), None, None, None
+
+
+def frozen_linear(x: torch.Tensor, lin: torch.nn.Linear, cache: TransposedCopy) -> torch.Tensor:
+    """``lin(x)``; a CUDA Linear with frozen parameters (and no autocast) gets the TN-form backward."""
+    w = lin.weight
+    if (x.is_cuda and not w.requires_grad and (lin.bias is None or not lin.bias.requires_grad) and x.dtype == w.dtype
+            and x.requires_grad and torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda")):
+        return _FrozenLinearFn.apply(x, w, lin.bias, cache.get(w))
+    return lin(x)
+
+
 def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tensor, scaling: float, layout: int,
               save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
               packed: Optional[torch.Tensor] = None, gelu_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -227,8 +276,9 @@ class _LoRALinearFn(torch.autograd.Function):
     """Frozen linear + LoRA branch as one autograd node (saved tensors: x, t^T -- never y or delta)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_p, seed, packed=None):
+    def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_p, seed, packed=None, wt=None):
         _require_cuda(x, weight, A, B)
+        ctx.wt = wt
         ref = weight if weight is not None else x        # weight None: bare LoRA branch (zero base)
         cdt = ref.dtype if ref.dtype in (torch.bfloat16, torch.float32) else torch.float32
         if torch.is_autocast_enabled("cuda"):
@@ -282,7 +332,7 @@ class _LoRALinearFn(torch.autograd.Function):
                 gx2 = gy2.new_zeros(gy2.shape[0], ctx.x_shape[-1])
             else:
                 with torch.autocast("cuda", enabled=False):
-                    gx2 = gy2 @ w                        # frozen GEMM
+                    gx2 = _dx(gy2, w, ctx.wt)            # frozen GEMM (TN form when W^T is at hand)
         gA = torch.empty_like(Am) if need_w else None
         gB = torch.empty_like(Bm) if need_w else None
         if gy2.shape[0] == 0:
@@ -309,7 +359,7 @@ class _LoRALinearFn(torch.autograd.Function):
         if need_w:
             gA = gA.to(A.dtype) if ctx.needs_input_grad[3] else None
             gB = gB.to(B.dtype) if ctx.needs_input_grad[4] else None
-        return gx, None, None, gA, gB, None, None, None, None, None
+        return gx, None, None, gA, gB, None, None, None, None, None, None
 
 
 class _LoRAMlpFn(torch.autograd.Function):
@@ -318,7 +368,7 @@ class _LoRAMlpFn(torch.autograd.Function):
     instead of being elementwise kernels of their own.  Saved: x, the pre-activation h, a = GELU(h), the two t^T."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, A1, B1, s1, W2, b2, A2, B2, s2, layout, drop_p, seed1, seed2, pk1, pk2):
+    def forward(ctx, x, W1, b1, A1, B1, s1, W2, b2, A2, B2, s2, layout, drop_p, seed1, seed2, pk1, pk2, Wt1=None, Wt2=None):
         _require_cuda(x, W1, W2, A1, B1, A2, B2)
         cdt = W1.dtype
         x2 = _rows(x if x.dtype == cdt else x.to(cdt))
@@ -333,6 +383,7 @@ class _LoRAMlpFn(torch.autograd.Function):
         t2 = lora_fwd_(a, _master(A2), _master(B2), y, s2, layout, save_t=need_w, drop_p=drop_p, seed=seed2, packed=pk2)
         ctx.meta = (s1, s2, layout, drop_p, seed1, seed2, x.shape, x.dtype)
         ctx.pk = (pk1, pk2)
+        ctx.wt = (Wt1, Wt2)
         ctx.save_for_backward(x2, h, a, W1, W2, A1, B1, A2, B2, t1, t2)
         return y.view(*x.shape[:-1], y.shape[-1])
 
@@ -347,22 +398,22 @@ class _LoRAMlpFn(torch.autograd.Function):
         A1m, B1m, A2m, B2m = _master(A1), _master(B1), _master(A2), _master(B2)
         gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
         with torch.autocast("cuda", enabled=False):
-            ga = gy2 @ W2                                            # frozen GEMM
+            ga = _dx(gy2, W2, ctx.wt[1])                             # frozen GEMM
         # fc2's adapter backward; its in-place pass over ga also applies GELU'(h): ga leaves as gh
         lora_bwd_(gy2, a, t2, A2m, B2m, ga, gA2, gB2, s2, layout, drop_p=drop_p, seed=seed2, packed=pk2, gelu_pre=h)
         gx2 = None
         if need_x:
             with torch.autocast("cuda", enabled=False):
-                gx2 = ga @ W1                                        # frozen GEMM
+                gx2 = _dx(ga, W1, ctx.wt[0])                         # frozen GEMM
         if need_x or need_w:
             lora_bwd_(ga, x2, t1, A1m, B1m, gx2, gA1, gB1, s1, layout, drop_p=drop_p, seed=seed1, packed=pk1)
         gx = gx2.view(x_shape).to(x_dtype) if need_x else None
         g = lambda t, p, i: (t.to(p.dtype) if (t is not None and ctx.needs_input_grad[i]) else None)
         return (gx, None, None, g(gA1, A1, 3), g(gB1, B1, 4), None, None, None, g(gA2, A2, 8), g(gB2, B2, 9), None, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
-def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool) -> Optional[torch.Tensor]:
+def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool, wt_caches=None) -> Optional[torch.Tensor]:
     """``fc2(GELU(fc1(x)))`` for two LoRA-wrapped Linears through :class:`_LoRAMlpFn`, or None when the fused form does
     not apply (then the caller evaluates the three modules one by one).  ``fc1`` / ``fc2`` are
     ``(weight, bias, lora_layer)`` triples; the lora layers carry ``lora_A, lora_B, scaling, dropout_p, _packed``."""
@@ -380,8 +431,10 @@ def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool) -> Opt
         seed1, seed2 = (int(v) for v in torch.randint(0, 2 ** 62, (2,)).tolist())
     pk1 = l1._packed.get(l1.lora_A, l1.lora_B, int(layout))
     pk2 = l2._packed.get(l2.lora_A, l2.lora_B, int(layout))
+    Wt1 = wt_caches[0].get(W1) if wt_caches is not None else None
+    Wt2 = wt_caches[1].get(W2) if wt_caches is not None else None
     return _LoRAMlpFn.apply(x, W1, b1, l1.lora_A, l1.lora_B, float(l1.scaling), W2, b2, l2.lora_A, l2.lora_B,
-                            float(l2.scaling), int(layout), p, seed1, seed2, pk1, pk2)
+                            float(l2.scaling), int(layout), p, seed1, seed2, pk1, pk2, Wt1, Wt2)
 
 
 class AugmentedWeight:
@@ -501,7 +554,7 @@ def fused_mode_enabled() -> bool:
 def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], A: torch.Tensor,
                 B: torch.Tensor, scaling: float, layout: int, dropout_p: float = 0.0,
                 training: bool = False, aug: Optional[AugmentedWeight] = None,
-                cache: Optional[PackedOperands] = None) -> torch.Tensor:
+                cache: Optional[PackedOperands] = None, wt_cache: Optional[TransposedCopy] = None) -> torch.Tensor:
     """``F.linear(x, weight, bias) + scaling * (dropout(x) @ A_c) @ B_c`` on the HIP path.
 
     ``layout`` selects how A/B are stored (LAYOUT_ROOT: A[in,r], B[r,out]; LAYOUT_PACKAGE:
@@ -530,4 +583,8 @@ def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[
         fout = B.shape[1] if layout == LAYOUT_ROOT else B.shape[0]
         if fin % 8 == 0 and fout % 8 == 0:
             packed = cache.get(A, B, int(layout))
-    return _LoRALinearFn.apply(x, weight, bias, A, B, float(scaling), int(layout), p, seed, packed)
+    wt = None
+    if (wt_cache is not None and weight is not None and weight.is_cuda and not weight.requires_grad and x.requires_grad
+            and torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda") and weight.dtype == x.dtype):
+        wt = wt_cache.get(weight)
+    return _LoRALinearFn.apply(x, weight, bias, A, B, float(scaling), int(layout), p, seed, packed, wt)

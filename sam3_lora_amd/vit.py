@@ -85,7 +85,7 @@ class Mlp(nn.Module):
             ad = self._adapted()
             if ad is not None:
                 from .functional import lora_mlp_gelu
-                y = lora_mlp_gelu(x, ad[1], ad[2], ad[0], self.training)
+                y = lora_mlp_gelu(x, ad[1], ad[2], ad[0], self.training, wt_caches=(self.fc1._wt, self.fc2._wt))
                 if y is not None:
                     return y
         return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
@@ -129,6 +129,8 @@ class Attention(nn.Module):
         self.register_buffer("freqs_cis", axial_rope_table(self.head_dim, input_size[0], input_size[1],
                                                            rope_theta, scale_pos))
         self._cs = None   # (cos, sin) fp32 [L, head_dim/2], derived lazily on the right device
+        from .functional import TransposedCopy
+        self._wt_qkv, self._wt_proj = TransposedCopy(), TransposedCopy()   # W^T copies for the TN-form dX GEMMs
 
     def _cos_sin(self, device):
         if self._cs is None or self._cs[0].device != device:
@@ -150,17 +152,25 @@ class Attention(nn.Module):
         partition happens inside the qkv-split/RoPE kernel's addressing (no window_partition copy)."""
         B, H, W, C = x.shape
         L, nW = ws * ws, (H // ws) * (W // ws)
-        qkv = self.qkv(x)
+        qkv = self._lin(self.qkv, x, self._wt_qkv)
         cos, sin = self._cos_sin(qkv.device)
         q, k, v = _QKVRope.apply(qkv.reshape(B * H * W, 3 * C), cos, sin, B * nW, L, self.num_heads, self.head_dim,
                                  (ws, H, W))
         o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
-        return self.proj(o.transpose(1, 2).reshape(B * nW, ws, ws, C))
+        return self._lin(self.proj, o.transpose(1, 2).reshape(B * nW, ws, ws, C), self._wt_proj)
+
+    @staticmethod
+    def _lin(mod: nn.Module, x: torch.Tensor, cache) -> torch.Tensor:
+        """``mod(x)``; a plain frozen nn.Linear gets the transposed-copy backward (functional.frozen_linear)."""
+        if type(mod) is nn.Linear:
+            from .functional import frozen_linear
+            return frozen_linear(x, mod, cache)
+        return mod(x)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, H, W, C = x.shape
         L = H * W
-        qkv = self.qkv(x)
+        qkv = self._lin(self.qkv, x, self._wt_qkv)
         if qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float32):
             # one HIP pass: split q/k/v and rotate q, k; outputs are [B, L, heads, d] so SDPA gets
             # transposed VIEWS (no permute copies) and its output reshapes to [B, H, W, C] for free
@@ -174,7 +184,7 @@ class Attention(nn.Module):
             q, k = self._rope(q), self._rope(k)
             o = F.scaled_dot_product_attention(q, k, v)
             o = o.permute(0, 2, 1, 3).reshape(B, H, W, C)
-        return self.proj(o)
+        return self._lin(self.proj, o, self._wt_proj)
 
 
 _SDPA_ORDER = None
