@@ -193,3 +193,40 @@ def test_frozen_layernorm_kernel_matches_torch(dtype, shape):
     tol = 5e-5 if dtype == torch.float32 else 8e-3
     assert (y.float() - yr).abs().max() <= tol * yr.abs().max()
     assert (x.grad.float() - xr.grad).abs().max() <= tol * xr.grad.abs().max()
+
+
+@pytest.mark.gpu
+def test_transposed_copy_backward_equals_plain_backward():
+    """functional.frozen_linear / TransposedCopy: the TN-form input gradient is the same GEMM as ``gy @ W``."""
+    from sam3_lora_amd import functional as Fn
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 96).to("cuda").to(torch.bfloat16)
+    for p in lin.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(7, 5, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    gy = torch.randn(7, 5, 96, device="cuda", dtype=torch.bfloat16)
+    cache = Fn.TransposedCopy()
+    y = Fn.frozen_linear(x, lin, cache)
+    assert "FrozenLinearFn" in type(y.grad_fn).__name__ and cache.t.shape == (64, 96)
+    y.backward(gy)
+    x2 = x.detach().clone().requires_grad_(True)
+    lin(x2).backward(gy)
+    assert torch.equal(y.detach(), lin(x2).detach())
+    assert (x.grad.float() - x2.grad.float()).abs().max() <= 2 ** -7 * x2.grad.float().abs().max()
+    blob = cache.t
+    assert Fn.frozen_linear(x, lin, cache) is not None and cache.t is blob            # cached while W is unchanged
+    with torch.no_grad():
+        lin.weight.mul_(2)
+    Fn.frozen_linear(x, lin, cache)
+    assert cache.t is not blob
+    lin.weight.requires_grad_(True)                                                   # trainable: the module itself
+    assert "FrozenLinearFn" not in type(Fn.frozen_linear(x, lin, cache).grad_fn).__name__
+
+
+def test_activation_checkpointing_policy_switches_every_trunk():
+    m = torch.nn.Sequential(V.ViT(img_size=56, pretrain_img_size=56, embed_dim=64, depth=2, num_heads=2, window_size=2,
+                                  global_att_blocks=(1,)))
+    assert m[0].use_act_checkpoint is True
+    assert V.set_activation_checkpointing(m, False) is False and m[0].use_act_checkpoint is False
+    assert V.set_activation_checkpointing(m, True) is True and m[0].use_act_checkpoint is True
+    assert V.set_activation_checkpointing(m, "auto") is True          # CPU model: nothing to measure, keep recompute

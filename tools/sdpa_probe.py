@@ -4,7 +4,11 @@ import torch
 import torch.nn.functional as F
 from torch.nn.attention import SDPBackend, sdpa_kernel
 
+import sys
 dev = "cuda"
+if len(sys.argv) > 1:      # python tools/sdpa_probe.py ck|aotriton
+    torch.backends.cuda.preferred_rocm_fa_library(sys.argv[1])
+    print("preferred_rocm_fa_library ->", torch.backends.cuda.preferred_rocm_fa_library())
 shapes = {"window [72,16,576,64]": (72, 16, 576, 64), "global [8,16,5184,64]": (8, 16, 5184, 64)}
 for name, (B, H, L, D) in shapes.items():
     # [B, L, H, D] storage viewed as [B, H, L, D], as the trunk hands it to SDPA
