@@ -230,3 +230,55 @@ def test_activation_checkpointing_policy_switches_every_trunk():
     assert V.set_activation_checkpointing(m, False) is False and m[0].use_act_checkpoint is False
     assert V.set_activation_checkpointing(m, True) is True and m[0].use_act_checkpoint is True
     assert V.set_activation_checkpointing(m, "auto") is True          # CPU model: nothing to measure, keep recompute
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ckpt", [True, False])
+def test_loss_curve_and_adapters_after_adamw_match_reference(golden_dir, ckpt):
+    """SURVEY 8c "Model step" / north star "loss curve within 1e-3 of the CPU reference": 12 AdamW steps of the tiny
+    trunk with HIP adapters (fp32 activations, the reference's precision; contractions on bf16 MFMA) against
+    tests/golden/train_curve.npz, which the reference itself produced on CPU (make_train_curve_golden.py).
+    Tolerances: every loss within 1e-3 relative.  The trained A / B are compared through their UPDATE (final - initial):
+    Adam's first steps are sign-like, so an element whose gradient is near zero can move by lr per step in either
+    direction under bf16 contraction noise -- element-wise equality is not a meaningful bar; direction and size are:
+    cosine(update, reference update) > 0.995 and norm ratio within 1 % for every adapter tensor (measured on MI355X:
+    loss error 1.4e-4, cosine >= 0.9996, norm ratio 0.9995 .. 1.0013)."""
+    import lora_layers as L
+    g, sd = _load(golden_dir)
+    c = np.load(os.path.join(golden_dir, "train_curve.npz"))
+    m = V.ViT(**TINY, use_act_checkpoint=ckpt)
+    m.load_state_dict(sd, strict=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        L.apply_lora_to_model(m, L.LoRAConfig(rank=4, alpha=8, dropout=0.0, target_modules=["fc1", "fc2"]))
+    with torch.no_grad():
+        for n, mod in m.named_modules():
+            if isinstance(mod, L.LoRALayer):
+                mod.lora_A.copy_(torch.from_numpy(g[f"lora/{n}.lora_A"]))
+                mod.lora_B.copy_(torch.from_numpy(g[f"lora/{n}.lora_B"]))
+    m.to("cuda").train()
+    img = torch.from_numpy(g["img"]).cuda()
+    target = torch.from_numpy(c["target"]).cuda()
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=float(c["lr"]), weight_decay=float(c["wd"]))
+    losses = []
+    for _ in range(len(c["losses"])):
+        loss = ((m(img)[0] - target) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    rel = np.abs(np.array(losses) - c["losses"]) / c["losses"]
+    assert rel.max() < 1e-3, (rel, losses)
+    print("loss rel err max %.2e" % rel.max())
+    stats = []
+    for n, mod in m.named_modules():
+        if isinstance(mod, L.LoRALayer):
+            for key, p in (("A", mod.lora_A), ("B", mod.lora_B)):
+                init = g[f"lora/{n}.lora_{key}"]
+                du, dr = (p.detach().cpu().numpy() - init).ravel(), (c[f"{key}/{n}"] - init).ravel()
+                cos = float(du @ dr / (np.linalg.norm(du) * np.linalg.norm(dr)))
+                ratio = float(np.linalg.norm(du) / np.linalg.norm(dr))
+                stats.append((cos, ratio, key, n))
+    worst = min(stats)
+    assert worst[0] > 0.995, worst
+    assert all(abs(r - 1) < 0.01 for _, r, _, _ in stats), max(stats, key=lambda t: abs(t[1] - 1))
+    print("update cosine min %.4f, norm ratio range %.4f..%.4f" % (worst[0], min(s_[1] for s_ in stats), max(s_[1] for s_ in stats)))
