@@ -250,6 +250,26 @@ def op_table(w, iters):
     return ops
 
 
+def torch_unfused_block(w, iters=5):
+    """The same block (fc1 + fc2 adapters, forward + backward) written the way the reference writes it --
+    ``base + ((x @ A) @ B) * s`` under torch.autograd (lora_layers.py:49-55,87-91) -- on the same GPU in bf16: the
+    "before" of SURVEY section 8(d).  Returns microseconds per block (forward + backward, no recompute)."""
+    s = w.scaling
+    A1, B1, A2, B2 = (p.detach().to(torch.bfloat16).requires_grad_(True) for p in (w.A1[0], w.B1[0], w.A2[0], w.B2[0]))
+    x1, h, y2, g2 = w.x1[0], w.h[0], w.y2[0], w.g2[0]
+
+    def run():
+        for p in (A1, B1, A2, B2):
+            p.grad = None
+        xr = x1.detach().requires_grad_(True)
+        h_out = h + ((xr @ A1) @ B1) * s              # original_layer(x) + lora(x), base output given
+        y_out = y2 + ((h_out @ A2) @ B2) * s
+        y_out.backward(g2)
+
+    avg, _, _ = time_events(run, iters, warm=2, reps=3)
+    return avg
+
+
 def trunk_step_bench(dev, batch, rank, steps, world, checkpoint=True):
     """The adapters in their real host: the SAM3 ViT-Det trunk (sam3_lora_amd/vit.py, 32 blocks, 1008^2 input,
     random init, frozen weights bf16) with root-API LoRA on fc1/fc2, one training step = forward with per-block
@@ -465,6 +485,14 @@ def main():
                            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_us": dom["avg_us"]}
         out["kernels"] = rows
         out["ops"] = ops
+        try:
+            tu = torch_unfused_block(w)
+            ours = ops[-1]["avg_us"]
+            out["torch_unfused_block"] = {"avg_us": round(tu, 1), "this_library_avg_us": ours, "speedup": round(tu / ours, 2),
+                                          "what": "fc1+fc2 adapters fwd+bwd of one block as base + ((x@A)@B)*s under "
+                                                  "torch.autograd, bf16, same GPU"}
+        except Exception as e:      # an auxiliary comparison must never cost the bench line
+            out["torch_unfused_block"] = {"error": str(e)[:200]}
     if world > 1:
         dist.barrier()
     if not args.no_trunk:

@@ -17,5 +17,7 @@ if "trunk_step_no_checkpoint" in d:
     print("trunk_step (no activation checkpointing)", t["images_per_s"], "img/s", t["ms_per_step"], "ms/step, peak", t["peak_mem_gb"], "GB")
 if "no_recompute" in d:
     print("adapter path without recompute", d["no_recompute"]["value"], "img/s", d["no_recompute"]["ms_per_step"], "ms/step")
+if "torch_unfused_block" in d:
+    print("torch unfused block", d["torch_unfused_block"])
 if "cpu_baseline" in d:
     print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
