@@ -45,9 +45,10 @@ def test_two_ranks_launched_like_the_driver_complete():
     env = dict(os.environ, BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--blocks", "2", "--batch", "1", "--kernel-iters", "2", "--no-trunk", "--no-cpu-baseline"]
+           "--blocks", "2", "--batch", "1", "--kernel-iters", "2", "--trunk-steps", "1", "--no-cpu-baseline"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     r = _last_json(p.stdout)
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["no_recompute"]["value"] > 0 and r["trunk_step"]["loss_finite"] and r["trunk_step_no_checkpoint"]["loss_finite"]
     assert sum(1 for l in p.stdout.splitlines() if l.startswith("{")) == 1      # rank 0 only
