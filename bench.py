@@ -485,6 +485,16 @@ def main():
                            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_us": dom["avg_us"]}
         out["kernels"] = rows
         out["ops"] = ops
+        # the whole step against the same roofline: SURVEY section 8(d)'s algorithmic bytes of every call in the step
+        e_, r_, M_ = w.x1[0].element_size(), w.rank, w.M
+        fwd_b = lambda i, o: e_ * M_ * (i + 2 * o) + e_ * r_ * (i + o)
+        bwd_b = lambda i, o: e_ * M_ * (o + i + 2 * i) + 4 * r_ * (i + o) * 2
+        per_block = 2 * (fwd_b(D_MODEL, D_HID) + fwd_b(D_HID, D_MODEL)) + bwd_b(D_MODEL, D_HID) + bwd_b(D_HID, D_MODEL)
+        step_bytes = per_block * args.blocks
+        out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "ms": round(ms, 3),
+                                   "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                   "frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "what": "all 256 C-ABI calls of the timed step (fwd + recompute + bwd of 64 Linears)"}
         try:
             tu = torch_unfused_block(w)
             ours = ops[-1]["avg_us"]

@@ -5,6 +5,8 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("value", d["value"], d["unit"], "ms/step", d["ms_per_step"], "n_gpus", d["n_gpus"])
 if "roofline" in d:
     print("roofline", {k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_us", "traffic")})
+if "step" in d.get("roofline", {}):
+    print("whole step vs roofline", d["roofline"]["step"])
 for k in d.get("kernels", []):
     print(f"  {k['kernel']:9s} dim={k['dim']:5d} n={k['launches']:4d} avg={k['avg_us']:8.2f} med={k['median_us']:8.2f} min={k['min_us']:8.2f} tot={k['total_us']:9.1f} {k['GBps']:7.1f} GB/s")
 for k in d.get("ops", []):
