@@ -267,7 +267,8 @@ class _WinResidual(torch.autograd.Function):
                                        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"sam3_vit_win_residual failed ({rc})")
-        ctx.save_for_backward(scale) if scale is not None else None
+        if scale is not None:
+            ctx.save_for_backward(scale)
         ctx.meta = (B, H, W, C, ws, dt, h.shape, scale is not None)
         return y
 
@@ -536,8 +537,8 @@ def set_activation_checkpointing(model: nn.Module, mode="auto", batch: int = 8, 
             need = 0
             for v in vits:
                 C = v.patch_embed.proj.out_channels
-                grid = getattr(v, "_last_tokens_per_image", 72 * 72)
-                need += len(v.blocks) * 16 * batch * grid * C * 2
+                grid = getattr(v, "_last_tokens_per_image", 72 * 72)     # tokens per image seen by the last forward
+                need += len(v.blocks) * 16 * batch * grid * C * 2         # ~16 saved [tokens, C] tensors per block, bf16
             free, _ = torch.cuda.mem_get_info(p.device)
             use = need > headroom * free
     else:
