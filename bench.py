@@ -255,7 +255,7 @@ def torch_unfused_block(w, iters=5):
     ``base + ((x @ A) @ B) * s`` under torch.autograd (lora_layers.py:49-55,87-91) -- on the same GPU in bf16: the
     "before" of SURVEY section 8(d).  Returns microseconds per block (forward + backward, no recompute)."""
     s = w.scaling
-    A1, B1, A2, B2 = (p.detach().to(torch.bfloat16).requires_grad_(True) for p in (w.A1[0], w.B1[0], w.A2[0], w.B2[0]))
+    A1, B1, A2, B2 = (p.detach().to(w.x1[0].dtype).requires_grad_(True) for p in (w.A1[0], w.B1[0], w.A2[0], w.B2[0]))
     x1, h, y2, g2 = w.x1[0], w.h[0], w.y2[0], w.g2[0]
 
     def run():
@@ -500,7 +500,7 @@ def main():
             ours = ops[-1]["avg_us"]
             out["torch_unfused_block"] = {"avg_us": round(tu, 1), "this_library_avg_us": ours, "speedup": round(tu / ours, 2),
                                           "what": "fc1+fc2 adapters fwd+bwd of one block as base + ((x@A)@B)*s under "
-                                                  "torch.autograd, bf16, same GPU"}
+                                                  "torch.autograd, same activation dtype, same GPU"}
         except Exception as e:      # an auxiliary comparison must never cost the bench line
             out["torch_unfused_block"] = {"error": str(e)[:200]}
     if world > 1:
