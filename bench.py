@@ -476,7 +476,9 @@ def main():
         ops = op_table(w, args.kernel_iters)
         dom = rows[0]             # largest share of the step's kernel time
         dimname = {"k_t1": "K", "k_t2": "N", "k_t3": "N"}.get(dom["kernel"], "dim")
-        tr = committed_traffic(dom["kernel"], (dom["dim"] + 127) // 128 if dom["kernel"] == "k_t2" else -1)
+        # the committed PMC passes were taken at the default workload (batch 8, r = 16, bf16): only then do they apply
+        default_wl = args.batch == 8 and args.rank == 16 and args.act_dtype == "bf16" and args.blocks == N_BLOCKS
+        tr = committed_traffic(dom["kernel"], (dom["dim"] + 127) // 128 if dom["kernel"] == "k_t2" else -1) if default_wl else None
         out["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} [M={w.M},{dimname}={dom['dim']}]",
                            "launches_timed": dom["launches"],
                            "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
