@@ -1110,10 +1110,28 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
                int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)(Mp / 64));
     ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
-if (RT == 1)
-        hipLaunchKernelGGL((k_t1<XT, 1, 128>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+    // Workgroups hold 40-48 KB of LDS, so up to 4 (r <= 16) fit a CU.  When the grid needs more than one residency
+    // round, a nearly empty last round costs a whole round: cap the residency (dynamic-LDS padding) at the value whose
+    // last round is fullest.  Measured at M = 82,944 (1296 workgroups): 163 us uncapped, 138-141 us capped.
+    const int lds_static = 32768 + 2 * RT * 8192 / 2;
+    const int omax = 163840 / lds_static > 4 ? 4 : 163840 / lds_static;
+    unsigned pad = 0;
+    if ((long long)grid.x > 256LL * omax && K >= 2048) {      // short sweeps (K = 1024) measured better uncapped
+        double best = -1.0;
+        for (int o = omax; o >= 2; --o) {
+            const double r = (double)grid.x / (256.0 * o), full = r / (double)((long long)(r + 0.999999));
+            const double score = full * (o >= 4 ? 1.0 : o == 3 ? 0.97 : 0.82);
+            if (score > best + 1e-9) {
+                best = score;
+                pad = o == omax ? 0u : (unsigned)((163840 / o - lds_static - 256) & ~255);
+            }
+        }
+    }
+    pad = (unsigned)env_int("SAM3_LORA_T1_LDS_PAD", pad);
+    if (RT == 1)
+        hipLaunchKernelGGL((k_t1<XT, 1, 128>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
     else
-        hipLaunchKernelGGL((k_t1<XT, 2, 128>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+        hipLaunchKernelGGL((k_t1<XT, 2, 128>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
 }
 
 template <typename YT>
