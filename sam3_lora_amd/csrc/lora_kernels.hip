@@ -207,11 +207,15 @@ __device__ __forceinline__ void wave_sync() {   // LDS ops of one wave execute i
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename XT, int RT, int BK>
+// PART (small M, r <= 16): blockIdx.y selects a range of K chunks and the workgroup writes its fp32 partial to
+// P[split][row][16]; k_gt_reduce then adds the splits in fixed order and emits T / TTf.  With M/64 workgroups alone a
+// small batch leaves most CUs idle (M = 5184: 81 workgroups on 256 CUs).
+template <typename XT, int RT, int BK, bool PART = false>
 __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ W1, bf16_t* __restrict__ T,
                                             bf16_t* __restrict__ TTf, long long M, long long Mp, int K,
-                                            DropKey dk) {
+                                            DropKey dk, float* __restrict__ P = nullptr, int kc_per = 0) {
+    static_assert(!PART || RT == 1, "split-K partials are laid out for one rank tile");
     constexpr int RP = RT * 16, BM = 64, CPR = BK / 8;          // CPR 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;                               // tile rows covered per pass of 256 threads
     constexpr int XP = BM / RPP, WP = RP / RPP;                  // passes for the x tile / the W1 tile
@@ -260,12 +264,14 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    sstore(0, 0);
+    const int kc0 = PART ? (int)blockIdx.y * kc_per : 0;
+    const int kc1 = PART ? (kc0 + kc_per < nk ? kc0 + kc_per : nk) : nk;
+    gload(kc0);
+    sstore(0, kc0);
     __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1);
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const int buf = (kc - kc0) & 1;
+        if (kc + 1 < kc1) gload(kc + 1);
         const int row = wave * 16 + n;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -278,11 +284,15 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
                 acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[rt], 0, 0, 0);
             }
         }
-        if (kc + 1 < nk) sstore(buf ^ 1, kc + 1);
+        if (kc + 1 < kc1) sstore(buf ^ 1, kc + 1);
         __syncthreads();
     }
     // lane (n, g) holds t[row = m0 + wave*16 + n][rank idx = rt*16 + g*4 + j]
     const long long m = m0 + wave * 16 + n;
+    if (PART) {
+        *reinterpret_cast<f32x4*>(P + ((long long)blockIdx.y * Mp + m) * 16 + g * 4) = acc[0];
+        return;
+    }
     const long long blk = m >> 5;
     const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
 #pragma unroll
@@ -1107,8 +1117,27 @@ PackedLayout packed_layout(int in_f, int out_f, int rank) {
 
 template <typename XT>
 void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t* TT, long long M, long long Mp, int K,
-               int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
+               int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, float* part = nullptr) {
     dim3 grid((unsigned)(Mp / 64));
+    const int nk = (K + 127) / 128;
+    // small M: split K over workgroups so that ~640 of them exist (fp32 partials in `part`, fixed-order sum after)
+    if (RT == 1 && part && K >= 2048 && grid.x < 512 && !env_flag("SAM3_LORA_T1_NO_SPLIT")) {
+        int ks = (int)((640 + grid.x - 1) / grid.x);
+        ks = ks > 8 ? 8 : ks;
+        const int kc_per = (nk + ks - 1) / ks;
+        ks = (nk + kc_per - 1) / kc_per;
+        if (ks > 1) {
+            {
+                ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
+                hipLaunchKernelGGL((k_t1<XT, 1, 128, true>), dim3(grid.x, (unsigned)ks), dim3(256), 0, st, (const XT*)X, ldx, W1, T,
+                                   TT, M, Mp, K, dk, part, kc_per);
+            }
+            ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, K, st);
+            hipLaunchKernelGGL(k_gt_reduce, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)part, ks, T, TT,
+                               Mp);
+            return;
+        }
+    }
     ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
     // Workgroups hold 40-48 KB of LDS, so up to 4 (r <= 16) fit a CU.  When the grid needs more than one residency
     // round, a nearly empty last round costs a whole round: cap the residency (dynamic-LDS padding) at the value whose
@@ -1192,8 +1221,10 @@ void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part,
 }
 
 struct FwdWs {
-    size_t w1, w2t, t, tt, total;
+    size_t w1, w2t, t, tt, t1p, total;
 };
+// fp32 split-K partials of k_t1 (r <= 16 and fewer than 512 row tiles): up to 8 splits x Mp x 16
+inline size_t t1_part_bytes(long long Mp, int RP) { return (RP == 16 && Mp / 64 < 512) ? (size_t)8 * Mp * 64 : 0; }
 FwdWs fwd_ws(long long M, int in_f, int out_f, int rank) {
     const int RP = rpad(rank);
     const long long Mp = round_up(M, 64);
@@ -1203,6 +1234,7 @@ FwdWs fwd_ws(long long M, int in_f, int out_f, int rank) {
     w.w2t = off; off += al256((size_t)out_f * RP * 2);
     w.t = off; off += al256((size_t)Mp * RP * 2);
     w.tt = off; off += al256((size_t)RP * Mp * 2);
+    w.t1p = off; off += al256(t1_part_bytes(Mp, RP));
     w.total = off;
     return w;
 }
@@ -1228,7 +1260,10 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
     w.tt = off; off += al256((size_t)RP * Mp * 2);
     w.pb = off; off += al256((size_t)(w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR) * RP * out_f * 4);
     w.pa = off; off += al256((size_t)w.pA.NR * RP * in_f * 4);
-    w.gtp = off; off += RP == 16 ? al256((size_t)w.pE.nchunks * Mp * 16 * 4) : 0;     // gt partials (r <= 16)
+    {   // gt partials of k_t3e (r <= 16); the same region serves k_t1's split-K partials at small M
+        const size_t a = RP == 16 ? (size_t)w.pE.nchunks * Mp * 16 * 4 : 0, b = t1_part_bytes(Mp, RP);
+        w.gtp = off; off += al256(a > b ? a : b);
+    }
     w.total = off;
     return w;
 }
@@ -1363,12 +1398,12 @@ static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, 
         launch_pack(ja, jb, st);
     }
     if (dtype == SAM3_LORA_BF16) {
-        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
+        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk, RT == 1 ? (float*)(ws + w.t1p) : nullptr);
         if (stage_on(SAM3_LORA_STAGE_T2))
             launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
                               act_out, ldact);
     } else {
-        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk);
+        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk, RT == 1 ? (float*)(ws + w.t1p) : nullptr);
         if (stage_on(SAM3_LORA_STAGE_T2))
             launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
                              act_out, ldact);
@@ -1446,8 +1481,9 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
     const bool bf = dtype == SAM3_LORA_BF16;
     if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
         bf16_t* TTs = (bf16_t*)(ws + w.tt);
-        if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk);
-        else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk);
+        float* t1p = RT == 1 ? (float*)(ws + w.gtp) : nullptr;     // free until k_t3e runs (stream order)
+        if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk, t1p);
+        else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk, t1p);
         TT = TTs;
     }
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
@@ -1466,12 +1502,12 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
             if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
         }
     } else if (bf) {
-        if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);         // gt = gy . B_c^T
+        if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st, DropKey{0u, 0u, 0}, RT == 1 ? GTP : nullptr);   // gt = gy . B_c^T
         if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);     // gA^T = gt^T . x
         if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
     } else {
-        if (s1) launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st);
+        if (s1) launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st, DropKey{0u, 0u, 0}, RT == 1 ? GTP : nullptr);
         if (gB_accum && s3b) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);
         if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
         if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);

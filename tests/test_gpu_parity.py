@@ -602,3 +602,29 @@ def test_fused_lora_mlp_equals_module_by_module(api, dtype, drop, monkeypatch):
         y = mlp(x.clone().requires_grad_(True))
         y.backward(gy)
         assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for n, p in mlp.named_parameters() if "lora_" in n)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("M,K,drop", [(5184, 4736, 0.0), (1000, 2200, 0.2), (10368, 4736, 0.0)])
+def test_small_m_split_k_row_reduction(M, K, drop, dtype, monkeypatch):
+    """Few row tiles (small batch): k_t1 splits K over workgroups and k_gt_reduce adds the fp32 partials in fixed order.
+    Same numbers as the unsplit kernel up to fp32 re-association before the one bf16 rounding of t (<= 1 bf16 ulp of t,
+    i.e. 2^-8 of its magnitude on the delta), both within the oracle tolerances; bit-reproducible run to run."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    x = torch.randn(M, K, device=DEV, generator=g).to(td)
+    A = torch.randn(K, 16, device=DEV, generator=g) / K ** 0.5
+    B = torch.randn(16, 256, device=DEV, generator=g) / 4
+    outs = {}
+    for mode in ("split", "split2", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("SAM3_LORA_T1_NO_SPLIT", "1")
+        y = torch.zeros(M, 256, device=DEV, dtype=td)
+        tT = Fn.lora_fwd_(x, A, B, y, 2.0, cases.LAYOUT_ROOT, save_t=True, drop_p=drop, seed=5)
+        outs[mode] = (y.float().cpu().numpy(), tT.clone())
+    assert np.array_equal(outs["split"][0], outs["split2"][0]) and torch.equal(outs["split"][1], outs["split2"][1])
+    assert _relmax(outs["split"][0], outs["plain"][0]) < 6e-3
+    if drop == 0.0:
+        ref = O.adapter_delta(x.float().cpu().numpy(), A.cpu().numpy(), B.cpu().numpy(), 2.0, cases.LAYOUT_ROOT,
+                              acc_dtype=np.float64).reshape(M, -1)
+        assert _relmax(outs["split"][0], ref) < 1e-2
