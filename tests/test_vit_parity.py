@@ -233,6 +233,40 @@ def test_activation_checkpointing_policy_switches_every_trunk():
 
 
 @pytest.mark.gpu
+def test_loss_curve_in_the_bf16_training_layout_stays_close_to_the_fp32_reference(golden_dir):
+    """Same 12 steps with every frozen tensor and all activations in bf16 (``to_training_layout``, the MI355X layout the
+    benchmark runs): not a parity bar (the reference has no bf16 path) but the fidelity of the fast layout -- every loss
+    within 2e-3 of the reference's fp32 curve (measured 4.8e-4) and the curve decreasing."""
+    import lora_layers as L
+    g, sd = _load(golden_dir)
+    c = np.load(os.path.join(golden_dir, "train_curve.npz"))
+    m = V.ViT(**TINY)
+    m.load_state_dict(sd, strict=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        L.apply_lora_to_model(m, L.LoRAConfig(rank=4, alpha=8, dropout=0.0, target_modules=["fc1", "fc2"]))
+    with torch.no_grad():
+        for n, mod in m.named_modules():
+            if isinstance(mod, L.LoRALayer):
+                mod.lora_A.copy_(torch.from_numpy(g[f"lora/{n}.lora_A"]))
+                mod.lora_B.copy_(torch.from_numpy(g[f"lora/{n}.lora_B"]))
+    m.to("cuda").train()
+    V.to_training_layout(m)
+    img = torch.from_numpy(g["img"]).cuda().bfloat16()
+    target = torch.from_numpy(c["target"]).cuda()
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=float(c["lr"]), weight_decay=float(c["wd"]))
+    losses = []
+    for _ in range(len(c["losses"])):
+        loss = ((m(img)[0].float() - target) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    rel = np.abs(np.array(losses) - c["losses"]) / c["losses"]
+    print("bf16 layout: loss rel err max %.2e" % rel.max())
+    assert rel.max() < 2e-3 and losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ckpt", [True, False])
 def test_loss_curve_and_adapters_after_adamw_match_reference(golden_dir, ckpt):
     """SURVEY 8c "Model step" / north star "loss curve within 1e-3 of the CPU reference": 12 AdamW steps of the tiny
