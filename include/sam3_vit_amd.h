@@ -48,6 +48,10 @@ int sam3_vit_layernorm_fwd(const void* x, const void* gamma, const void* beta, v
                            int64_t M, int C, float eps, int dtype, void* stream);
 int sam3_vit_layernorm_bwd(const void* gy, const void* x, const void* gamma, const float* mean, const float* rstd,
                            void* gx, int64_t M, int C, int dtype, void* stream);
+/* the same plus the gradient that arrives on the skip path around the norm (x feeds both the norm and the residual):
+ * gx = add + LN'(gy) in one pass; add may be NULL. */
+int sam3_vit_layernorm_bwd_add(const void* gy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                               const void* add, void* gx, int64_t M, int C, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

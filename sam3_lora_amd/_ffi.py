@@ -32,7 +32,7 @@ ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
 VIT_EXPORTS = ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd", "sam3_vit_qkv_rope_win_fwd",
                "sam3_vit_qkv_rope_win_bwd", "sam3_vit_win_residual", "sam3_vit_layernorm_fwd",
-               "sam3_vit_layernorm_bwd")      # include/sam3_vit_amd.h
+               "sam3_vit_layernorm_bwd", "sam3_vit_layernorm_bwd_add")      # include/sam3_vit_amd.h
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
 _lib = None
@@ -110,6 +110,8 @@ def _declare(lib):
     lib.sam3_vit_layernorm_fwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_float, c_int, c_void_p]
     lib.sam3_vit_layernorm_bwd.restype = c_int
     lib.sam3_vit_layernorm_bwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]
+    lib.sam3_vit_layernorm_bwd_add.restype = c_int
+    lib.sam3_vit_layernorm_bwd_add.argtypes = [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]

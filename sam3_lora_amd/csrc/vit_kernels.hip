@@ -236,10 +236,13 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const T* __restrict__ x, const T
 }
 
 // gx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gy * gamma,  xhat = (x - mean) * rstd
+// `add` (nullable): the gradient arriving on the skip path around the norm -- gx = add + LN'(gy); saves the separate
+// accumulation pass autograd would run for a tensor that feeds both the norm and the residual
 template <typename T, int CPL>
 __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ gy, const T* __restrict__ x,
                                                 const T* __restrict__ gamma, const float* __restrict__ mean,
-                                                const float* __restrict__ rstd, T* __restrict__ gx, long long M, int C) {
+                                                const float* __restrict__ rstd, T* __restrict__ gx, long long M, int C,
+                                                const T* __restrict__ add) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -268,6 +271,11 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ gy, const 
             F8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o.v[j] = rs * (g[i].v[j] - m1 - xh[i].v[j] * m2);
+            if (add) {
+                const F8 a = ld8_nt(add + row * C + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.v[j] += a.v[j];
+            }
             st8(gx + row * C + c, o);
         }
     }
@@ -275,13 +283,13 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ gy, const 
 
 template <typename T>
 int launch_ln(bool bwd, const void* a, const void* b, const void* gamma, const void* beta, void* out, float* mean,
-              float* rstd, long long M, int C, float eps, hipStream_t st) {
+              float* rstd, long long M, int C, float eps, hipStream_t st, const void* add = nullptr) {
     const dim3 grid((unsigned)((M + 3) / 4));
     const int cpl = (C + 511) / 512;
 #define LN_CASE(N)                                                                                                     \
     case N:                                                                                                            \
         if (bwd) hipLaunchKernelGGL((k_ln_bwd<T, N>), grid, dim3(256), 0, st, (const T*)a, (const T*)b, (const T*)gamma, \
-                                    (const float*)mean, (const float*)rstd, (T*)out, M, C);                            \
+                                    (const float*)mean, (const float*)rstd, (T*)out, M, C, (const T*)add);             \
         else hipLaunchKernelGGL((k_ln_fwd<T, N>), grid, dim3(256), 0, st, (const T*)a, (const T*)gamma, (const T*)beta, \
                                 (T*)out, mean, rstd, M, C, eps);                                                       \
         break;
@@ -384,13 +392,19 @@ int sam3_vit_layernorm_fwd(const void* x, const void* gamma, const void* beta, v
     return -22;
 }
 
-// input gradient only (gamma, beta frozen): gx from gy, x and the saved statistics
+// input gradient only (gamma, beta frozen): gx = (add ? add : 0) + LN'(gy) from gy, x and the saved statistics;
+// `add` [M, C] is the gradient of the skip path around the norm (NULL: none)
+int sam3_vit_layernorm_bwd_add(const void* gy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                               const void* add, void* gx, int64_t M, int C, int dtype, void* stream) {
+    if (!gy || !x || !gamma || !mean || !rstd || !gx || M <= 0 || C <= 0 || (C % 8) || C > 4096) return -22;
+    if (dtype == 0) return launch_ln<bf16_t>(true, gy, x, gamma, nullptr, gx, (float*)mean, (float*)rstd, M, C, 0.f, (hipStream_t)stream, add);
+    if (dtype == 1) return launch_ln<float>(true, gy, x, gamma, nullptr, gx, (float*)mean, (float*)rstd, M, C, 0.f, (hipStream_t)stream, add);
+    return -22;
+}
+
 int sam3_vit_layernorm_bwd(const void* gy, const void* x, const void* gamma, const float* mean, const float* rstd,
                            void* gx, int64_t M, int C, int dtype, void* stream) {
-    if (!gy || !x || !gamma || !mean || !rstd || !gx || M <= 0 || C <= 0 || (C % 8) || C > 4096) return -22;
-    if (dtype == 0) return launch_ln<bf16_t>(true, gy, x, gamma, nullptr, gx, (float*)mean, (float*)rstd, M, C, 0.f, (hipStream_t)stream);
-    if (dtype == 1) return launch_ln<float>(true, gy, x, gamma, nullptr, gx, (float*)mean, (float*)rstd, M, C, 0.f, (hipStream_t)stream);
-    return -22;
+    return sam3_vit_layernorm_bwd_add(gy, x, gamma, mean, rstd, nullptr, gx, M, C, dtype, stream);
 }
 
 }  // extern "C"

@@ -334,13 +334,58 @@ class _FrozenLayerNorm(torch.autograd.Function):
         return gx.view(shape), None, None, None
 
 
+class _FrozenLayerNormSkip(torch.autograd.Function):
+    """``x -> (x, LayerNorm(x))`` for a tensor that feeds both the norm and the residual around it: the backward adds
+    the skip-path gradient inside the LayerNorm-backward pass (``sam3_vit_layernorm_bwd_add``) instead of leaving the
+    sum of the two gradients to a separate accumulation kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y = _FrozenLayerNorm.forward(ctx, x, weight, bias, eps)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, gskip, gy):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        x2, weight, stats = ctx.saved_tensors
+        M, C, dt, shape = ctx.meta
+        if gy is None:
+            return gskip, None, None, None
+        gy2 = gy.reshape(M, C)
+        gy2 = gy2 if gy2.is_contiguous() else gy2.contiguous()
+        add = None
+        if gskip is not None:
+            add = gskip.reshape(M, C)
+            add = add if add.is_contiguous() else add.contiguous()
+        gx = torch.empty_like(x2)
+        rc = lib.sam3_vit_layernorm_bwd_add(gy2.data_ptr(), x2.data_ptr(), weight.data_ptr(), stats[0].data_ptr(),
+                                            stats[1].data_ptr(), add.data_ptr() if add is not None else None, gx.data_ptr(),
+                                            M, C, dt, ctypes.c_void_p(torch.cuda.current_stream(gy.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_vit_layernorm_bwd_add failed ({rc})")
+        return gx.view(shape), None, None, None
+
+
+def _ln_fast(norm: nn.Module, x: torch.Tensor) -> bool:
+    return (isinstance(norm, nn.LayerNorm) and x.is_cuda and norm.elementwise_affine and norm.bias is not None
+            and len(norm.normalized_shape) == 1 and not norm.weight.requires_grad and not norm.bias.requires_grad
+            and x.dtype in (torch.bfloat16, torch.float32) and norm.weight.dtype == x.dtype and norm.bias.dtype == x.dtype
+            and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096 and x.numel() > 0 and not torch.is_autocast_enabled("cuda"))
+
+
+def layer_norm_skip(norm: nn.Module, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(x, norm(x))`` -- use the returned x for the residual so that both gradients meet inside one kernel."""
+    if _ln_fast(norm, x) and x.requires_grad and torch.is_grad_enabled():
+        return _FrozenLayerNormSkip.apply(x, norm.weight, norm.bias, norm.eps)
+    return x, layer_norm(norm, x)
+
+
 def layer_norm(norm: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """``norm(x)``; an ``nn.LayerNorm`` over the last dimension whose parameters are frozen and share x's dtype runs
     on the HIP kernels, everything else (Identity, trainable or mixed-dtype norms, CPU) on the module itself."""
-    if (isinstance(norm, nn.LayerNorm) and x.is_cuda and norm.elementwise_affine and norm.bias is not None
-            and len(norm.normalized_shape) == 1 and not norm.weight.requires_grad and not norm.bias.requires_grad
-            and x.dtype in (torch.bfloat16, torch.float32) and norm.weight.dtype == x.dtype and norm.bias.dtype == x.dtype
-            and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096 and x.numel() > 0 and not torch.is_autocast_enabled("cuda")):
+    if _ln_fast(norm, x):
         return _FrozenLayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
     return norm(x)
 
@@ -390,18 +435,21 @@ class Block(nn.Module):
         if self._fused_windows(x):
             # window blocks without partition / unpartition copies: rows stay in image order through norm1 and qkv,
             # the qkv-split/RoPE kernel gathers them into windows, and the residual add scatters them back
-            hw = self.attn.forward_windows(layer_norm(self.norm1, x), self.window_size)
-            x = _WinResidual.apply(x, hw, self._drop_path_scale(x), self.window_size)
-            return self._residual(x, self.mlp(layer_norm(self.norm2, x)))
-        h = layer_norm(self.norm1, x)
+            xs, h = layer_norm_skip(self.norm1, x)
+            hw = self.attn.forward_windows(h, self.window_size)
+            x = _WinResidual.apply(xs, hw, self._drop_path_scale(x), self.window_size)
+            xs, h = layer_norm_skip(self.norm2, x)
+            return self._residual(xs, self.mlp(h))
+        xs, h = layer_norm_skip(self.norm1, x)
         if self.window_size > 0:
             H, W = h.shape[1], h.shape[2]
             h, pad_hw = window_partition(h, self.window_size)
         h = self.attn(h)
         if self.window_size > 0:
             h = window_unpartition(h, self.window_size, pad_hw, (H, W))
-        x = self._residual(x, h)
-        return self._residual(x, self.mlp(layer_norm(self.norm2, x)))
+        x = self._residual(xs, h)
+        xs, h = layer_norm_skip(self.norm2, x)
+        return self._residual(xs, self.mlp(h))
 
     def _drop_path_scale(self, x: torch.Tensor) -> Optional[torch.Tensor]:
         """fp32 [B]: Bernoulli(keep) / keep per image while stochastic depth is active, else None."""
