@@ -126,6 +126,16 @@ def load(path: str | None = None):
         if _lib is not None:
             return _lib
         p = path or os.environ.get("SAM3_LORA_AMD_LIB") or LIB_PATH
+        if p == LIB_PATH:
+            # a fresh clone has no binary (git-ignored) and an edited kernel source makes it stale: build in-tree
+            # when hipcc is there; without hipcc an existing binary is used as it is, a missing one is an error
+            from . import build as _build
+            if _build.needs_build():
+                try:
+                    _build.build_library()
+                except Exception as e:
+                    if not os.path.exists(p):
+                        raise LoRAKernelError(f"sam3_lora_amd: {p} is missing and could not be built: {e}") from e
         if not os.path.exists(p):
             raise LoRAKernelError(
                 f"sam3_lora_amd: HIP library not found at {p}. Build it with "

@@ -28,7 +28,8 @@ import torch.distributed as dist
 
 class LoRAGradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
-                 bucket_bytes: int = 16 << 20, average: bool = True, overlap: bool = True):
+                 bucket_bytes: int = 16 << 20, average: bool = True, overlap: bool = True,
+                 broadcast_parameters: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("LoRAGradReducer: no trainable parameters")
@@ -72,6 +73,23 @@ class LoRAGradReducer:
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._armed = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        if broadcast_parameters:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self, src: int = 0):
+        """Every rank starts from rank ``src``'s A/B -- what torch DDP does at construction
+        (native_trainer.py:319-328).  The adapters are drawn per process from an unseeded generator
+        (``kaiming_uniform_``), so without this the replicas would train apart on averaged gradients.
+        One flat message through the gradient buffer's storage (it is all zeros at this point)."""
+        if self.world_size <= 1:
+            return
+        with torch.no_grad():
+            for p, o in zip(self.params, self._offs):
+                self.flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+            dist.broadcast(self.flat, src=src, group=self.group)
+            for p, o in zip(self.params, self._offs):
+                p.copy_(self.flat[o:o + p.numel()].view_as(p))
+            self.flat.zero_()
 
     # ------------------------------------------------------------------ step protocol ----
     def zero_grad(self):

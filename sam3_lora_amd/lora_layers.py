@@ -176,6 +176,6 @@ def save_lora_weights(model: nn.Module, save_path: str):
 
 
 def load_lora_weights(model: nn.Module, load_path: str):
-    blob = torch.load(load_path, weights_only=False)
+    blob = torch.load(load_path, map_location="cpu")    # default (safe) unpickler: the file holds tensors only
     model.load_state_dict(blob, strict=False)
     print(f"Loaded LoRA weights from {load_path}")

@@ -225,15 +225,15 @@ class BinaryOneToManyMatcher(nn.Module):
                 target_is_valid_padded=None):
         assert repeats <= 1 and repeat_batch <= 1
         bs, nq = outputs["pred_logits"].shape[:2]
-        prob = outputs["pred_logits"].sigmoid().squeeze(-1)
+        prob = outputs["pred_logits"].float().sigmoid().squeeze(-1)      # fp32: torch.quantile rejects bf16
         num_boxes = batched_targets["num_boxes"]
-        tgt = batched_targets["boxes_padded"]
+        tgt = batched_targets["boxes_padded"].float()
         assert len(tgt) == bs
         nt = tgt.shape[1]
         if nt == 0:
             e = torch.empty(0, dtype=torch.long, device=prob.device)
             return e, e.clone(), e.clone()
-        iou, _ = box_iou(box_cxcywh_to_xyxy(outputs["pred_boxes"]), box_cxcywh_to_xyxy(tgt))
+        iou, _ = box_iou(box_cxcywh_to_xyxy(outputs["pred_boxes"].float()), box_cxcywh_to_xyxy(tgt))
         C = self.alpha * prob.unsqueeze(-1) + (1 - self.alpha) * iou
         if out_is_valid is not None:
             C = torch.where(out_is_valid[:, :, None], C, -1e9)
@@ -305,11 +305,18 @@ class Sam3LossWrapper(nn.Module):
         losses[CORE_LOSS_KEY] = total
         return losses
 
-    def forward(self, stage_outputs: Sequence[Dict], stage_targets: Sequence[Dict]) -> Dict[str, torch.Tensor]:
-        """One dict of outputs and one dict of targets per find stage (the native CLI has exactly one)."""
-        assert len(stage_outputs) == len(stage_targets)
+    def forward(self, find_stages, find_targets: Sequence[Dict]) -> Dict[str, torch.Tensor]:
+        """``find_stages``: one entry per find stage -- an output dict, or the list of that stage's interactive steps
+        (a ``SAM3Output`` is iterated in its all-steps-per-stage view).  Every step of every stage contributes
+        (sam3_loss.py:166-203); ``loss_stages`` on the container selects the targets as it does there."""
+        stages = getattr(find_stages, "output", find_stages)
+        loss_stages = getattr(find_stages, "loss_stages", None)
+        if loss_stages is not None:
+            find_targets = [find_targets[i] for i in loss_stages]
+        assert len(stages) == len(find_targets)
         total: Dict[str, torch.Tensor] = {}
-        for out, tgt in zip(stage_outputs, stage_targets):
-            for k, v in self.compute_loss(out, tgt).items():
-                total[k] = v if k not in total else total[k] + v
+        for stage, tgt in zip(stages, find_targets):
+            for out in ([stage] if isinstance(stage, dict) else list(stage)):
+                for k, v in self.compute_loss(out, tgt).items():
+                    total[k] = v if k not in total else total[k] + v
         return total

@@ -102,11 +102,13 @@ class BinaryHungarianMatcherV2(nn.Module):
                 repeat_batch: int = 1, out_is_valid: Optional[torch.Tensor] = None,
                 target_is_valid_padded: Optional[torch.Tensor] = None):
         num_queries = outputs["pred_logits"].shape[1]
-        score = outputs["pred_logits"].squeeze(-1)
-        boxes = outputs["pred_boxes"]
+        # the cost is an fp32 expression whatever the model's output dtype (bf16 heads in the MI355X layout);
+        # numpy has no bfloat16 and the assignment must not depend on the activation dtype
+        score = outputs["pred_logits"].squeeze(-1).float()
+        boxes = outputs["pred_boxes"].float()
         device = score.device
         num_boxes = batched_targets["num_boxes"].cpu()
-        tgt = batched_targets["boxes_padded"]
+        tgt = batched_targets["boxes_padded"].float()
         keep = None
         if self.remove_samples_with_0_gt:
             keep = num_boxes > 0

@@ -179,7 +179,7 @@ class SAM3TrainerNative:
         targets = [self.model.back_convert(t) for t in input_batch.find_targets]
         targets = [move_to_device(t, self.device) for t in targets]
         match_all_steps(self.matcher, outputs, targets)
-        return self.loss_wrapper([_steps(s)[-1] for s in outputs], targets)[CORE_LOSS_KEY]
+        return self.loss_wrapper(outputs, targets)[CORE_LOSS_KEY]
 
     def train_step(self, batch) -> float:
         loss = self._loss(batch)

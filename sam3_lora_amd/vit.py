@@ -259,6 +259,8 @@ class _WinResidual(torch.autograd.Function):
         from . import _ffi
         lib = _ffi.load()
         B, H, W, C = x.shape
+        if h.dtype != x.dtype:          # the kernel reads both buffers with x's element type
+            h = h.to(x.dtype)
         x, h = x.contiguous(), h.contiguous()
         y = torch.empty_like(x)
         dt = 0 if x.dtype == torch.bfloat16 else 1
@@ -427,7 +429,10 @@ class Block(nn.Module):
 
     def _fused_windows(self, x: torch.Tensor) -> bool:
         ws = self.window_size
+        # not under autocast: norm1 would stay fp32 while qkv / SDPA / proj turn bf16, and the residual kernel takes
+        # ONE dtype for both of its inputs
         return (ws > 0 and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % ws == 0
+                and not torch.is_autocast_enabled("cuda")
                 and x.shape[2] % ws == 0 and x.shape[-1] % 8 == 0
                 and not (self.training and isinstance(self.dropout, nn.Dropout) and self.dropout.p > 0.0))
 

@@ -22,10 +22,18 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sam3_lora_amd.ddp import LoRAGradReducer, allreduce_scalar_sum
-        torch.manual_seed(0)  # identical parameters on every rank (replicas)
+        torch.manual_seed(1000 + rank)  # every rank draws DIFFERENT adapters (the unseeded-builder case) ...
         params = [torch.nn.Parameter(torch.randn(s)) for s in [(64, 4), (4, 96), (96, 4), (4, 64), (10, 3), (3, 7)]]
         unused = torch.nn.Parameter(torch.randn(5, 5))      # never receives a gradient
         red = LoRAGradReducer(params + [unused], bucket_bytes=2048, average=True)
+        # ... and the reducer's construction-time broadcast makes them rank 0's (what torch DDP does)
+        mine = torch.cat([p.detach().flatten() for p in params + [unused]])
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        assert all(torch.equal(everyone[0], e) for e in everyone), "parameters not synchronised at construction"
+        g0 = torch.Generator().manual_seed(1000)
+        assert torch.equal(params[0].detach(), torch.randn(64, 4, generator=g0)), "broadcast source is not rank 0"
+        assert bool((red.flat == 0).all())
         assert len(red.buckets) >= 2
         for p in params:
             assert p.grad.data_ptr() >= red.flat.data_ptr()
