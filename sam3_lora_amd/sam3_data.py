@@ -1,0 +1,352 @@
+"""
+Batch layout of the SAM3 image-training step and the synthetic benchmark data (SURVEY section 2 "data layout",
+section 8(d) "synthetic inputs").
+
+Restates, for rows a14 / f-4:
+  * the per-sample records of ``sam3/train/data/sam3_image_dataset.py:30-132`` (``InferenceMetadata``, ``FindQueryLoaded``,
+    ``Object``, ``Image``, ``Datapoint``);
+  * the batched records of ``sam3/model/data_misc.py:46-166`` (``FindStage``, ``BatchedFindTarget``,
+    ``BatchedInferenceMetadata``, ``BatchedDatapoint``) -- same field names, dtypes and stacking axes;
+  * ``collate_fn_api`` (``sam3/train/data/collator.py:136-360``) for the image case: one stage per
+    ``query_processing_order``, texts de-duplicated in first-seen order, packed + padded target boxes, box / point
+    prompts padded to the longest with True in the masks;
+  * the synthetic sample of SURVEY section 8(d): a seeded uniform-noise RGB image resized and normalised as
+    ``COCOSegmentDataset.__getitem__`` does (``train_sam3_lora_native.py:101-108``: bilinear resize to 1008 x 1008,
+    scale to [0, 1], mean = std = 0.5), two rectangular objects stored as normalised xyxy (the reference's box-format
+    quirk, ``:131-142``) with matching boolean masks, query text "crack".
+
+Pure host-side Python / torch; nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, fields
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+__all__ = ["InferenceMetadata", "FindQueryLoaded", "Object", "Image", "Datapoint", "FindStage", "BatchedFindTarget",
+           "BatchedInferenceMetadata", "BatchedDatapoint", "collate_fn_api", "SyntheticSegmentDataset",
+           "synthetic_datapoint", "shard_indices", "ShardedLoader"]
+
+
+# ------------------------------------------------------------------------------------------ per-sample records --
+@dataclass
+class InferenceMetadata:
+    coco_image_id: int
+    original_image_id: int
+    original_category_id: int
+    original_size: Tuple[int, int]
+    object_id: int
+    frame_index: int
+    is_conditioning_only: Optional[bool] = False
+
+
+@dataclass
+class FindQueryLoaded:
+    query_text: str
+    image_id: int
+    object_ids_output: List[int]
+    is_exhaustive: bool
+    query_processing_order: int = 0
+    input_bbox: Optional[torch.Tensor] = None
+    input_bbox_label: Optional[torch.Tensor] = None
+    input_points: Optional[torch.Tensor] = None
+    semantic_target: Optional[torch.Tensor] = None
+    is_pixel_exhaustive: Optional[bool] = None
+    inference_metadata: Optional[InferenceMetadata] = None
+
+
+@dataclass
+class Object:
+    bbox: torch.Tensor
+    area: float
+    object_id: Optional[int] = -1
+    frame_index: Optional[int] = -1
+    segment: Optional[Union[torch.Tensor, dict]] = None
+    is_crowd: bool = False
+    source: Optional[str] = None
+
+
+@dataclass
+class Image:
+    data: Any
+    objects: List[Object]
+    size: Tuple[int, int]
+    blurring_mask: Optional[Dict[str, Any]] = None
+
+
+@dataclass
+class Datapoint:
+    find_queries: List[FindQueryLoaded]
+    images: List[Image]
+    raw_images: Optional[List[Any]] = None
+
+
+# --------------------------------------------------------------------------------------------- batched records --
+# (field -> (dtype, stack axis)); list-valued fields not named here stay Python lists
+_FIND_STAGE = dict(img_ids=(torch.long, 0), text_ids=(torch.long, 0), input_boxes=(torch.float, 1),
+                   input_boxes_mask=(torch.bool, 0), input_boxes_label=(torch.long, 1), input_points=(torch.float, 0),
+                   input_points_mask=(torch.bool, 0))
+_FIND_TARGET = dict(num_boxes=(torch.long, 0), boxes=(torch.float, 0), boxes_padded=(torch.float, 0),
+                    repeated_boxes=(torch.float, 0), segments=(torch.bool, 0), semantic_segments=(torch.bool, 0),
+                    is_valid_segment=(torch.bool, 0), is_exhaustive=(torch.bool, 0), object_ids=(torch.long, 0),
+                    object_ids_padded=(torch.long, 0))
+_METADATA = dict(coco_image_id=(torch.long, 0), original_image_id=(torch.long, 0), original_category_id=(torch.int, 0),
+                 original_size=(torch.long, 0), object_id=(torch.long, 0), frame_index=(torch.long, 0))
+
+
+@dataclass
+class FindStage:
+    img_ids: Any
+    text_ids: Any
+    input_boxes: Any
+    input_boxes_mask: Any
+    input_boxes_label: Any
+    input_points: Any
+    input_points_mask: Any
+    object_ids: Optional[List[List]] = None
+
+
+@dataclass
+class BatchedFindTarget:
+    num_boxes: Any
+    boxes: Any
+    boxes_padded: Any
+    repeated_boxes: Any
+    segments: Any
+    semantic_segments: Any
+    is_valid_segment: Any
+    is_exhaustive: Any
+    object_ids: Any
+    object_ids_padded: Any
+
+
+@dataclass
+class BatchedInferenceMetadata:
+    coco_image_id: Any
+    original_image_id: Any
+    original_category_id: Any
+    original_size: Any
+    object_id: Any
+    frame_index: Any
+    is_conditioning_only: List[Optional[bool]]
+
+
+@dataclass
+class BatchedDatapoint:
+    img_batch: torch.Tensor
+    find_text_batch: List[str]
+    find_inputs: List[FindStage]
+    find_targets: List[BatchedFindTarget]
+    find_metadatas: List[BatchedInferenceMetadata]
+    raw_images: Optional[List[Any]] = None
+
+
+def _tensorise(record, spec: Dict[str, Tuple[torch.dtype, int]]):
+    """Lists of tensors are stacked along the field's axis, lists of scalars become a tensor, None stays None."""
+    for name, (dtype, axis) in spec.items():
+        value = getattr(record, name)
+        if value is None:
+            continue
+        if len(value) and isinstance(value[0], torch.Tensor):
+            setattr(record, name, torch.stack(value, dim=axis).to(dtype))
+        else:
+            setattr(record, name, torch.as_tensor(value, dtype=dtype))
+    return record
+
+
+def _pad_to_longest(tensors: List[torch.Tensor], pad_val) -> List[torch.Tensor]:
+    """Right-pad along axis 0 to the longest entry."""
+    if not tensors:
+        return tensors
+    longest = max(t.shape[0] for t in tensors)
+    out = []
+    for t in tensors:
+        pad = (0, 0) * (t.dim() - 1) + (0, longest - t.shape[0])
+        out.append(torch.nn.functional.pad(t, pad, value=pad_val))
+    return out
+
+
+def _packed_to_padded(packed: torch.Tensor, counts: torch.Tensor, fill=0) -> torch.Tensor:
+    """[sum n_i, ...] -> [B, max n_i, ...]."""
+    ns = counts.tolist()
+    out = packed.new_full((len(ns), max(ns), *packed.shape[1:]), fill)
+    start = 0
+    for i, n in enumerate(ns):
+        out[i, :n] = packed[start:start + n]
+        start += n
+    return out
+
+
+def collate_fn_api(batch: Sequence[Datapoint], dict_key, with_seg_masks: bool = False,
+                   input_points_embedding_dim: int = 257, repeats: int = 0, load_image_in_fp16: bool = False) -> Dict:
+    n_stages = max(q.query_processing_order for d in batch for q in d.find_queries) + 1
+    stages = [FindStage([], [], [], [], [], [], [], object_ids=[]) for _ in range(n_stages)]
+    targets = [BatchedFindTarget([], [], [], [], [], [], [], [], [], []) for _ in range(n_stages)]
+    metas = [BatchedInferenceMetadata([], [], [], [], [], [], []) for _ in range(n_stages)]
+    images: List[torch.Tensor] = []
+    texts: List[str] = []
+    raw_images = None
+    first_image = 0
+    for d in batch:
+        images.extend(img.data for img in d.images)
+        if d.raw_images is not None:
+            raw_images = (raw_images or []) + list(d.raw_images)
+        for q in d.find_queries:
+            st, tg, md = stages[q.query_processing_order], targets[q.query_processing_order], metas[q.query_processing_order]
+            st.img_ids.append(q.image_id + first_image)
+            if q.query_text not in texts:
+                texts.append(q.query_text)
+            st.text_ids.append(texts.index(q.query_text))
+            assert q.inference_metadata is not None, "inference_metadata must be provided when FindQueryLoaded is created."
+            for f in fields(q.inference_metadata):
+                getattr(md, f.name).append(getattr(q.inference_metadata, f.name))
+            if q.input_bbox is not None:
+                nb = q.input_bbox.numel() // 4
+                assert q.input_bbox.numel() % 4 == 0 and q.input_bbox_label is not None and len(q.input_bbox_label) == nb
+                st.input_boxes.append(q.input_bbox.view(nb, 4))
+                st.input_boxes_label.append(q.input_bbox_label.view(nb))
+                st.input_boxes_mask.append(torch.zeros(nb, dtype=torch.bool))
+            else:
+                st.input_boxes.append(torch.zeros(0, 4))
+                st.input_boxes_label.append(torch.zeros(0, dtype=torch.bool))
+                st.input_boxes_mask.append(torch.ones(0, dtype=torch.bool))
+            if q.input_points is not None:
+                st.input_points.append(q.input_points.squeeze(0))
+                st.input_points_mask.append(torch.zeros(q.input_points.shape[1]))
+            else:
+                st.input_points.append(torch.empty(0, input_points_embedding_dim))
+                st.input_points_mask.append(torch.empty(0))
+            st.object_ids.append(q.object_ids_output)
+            objects = [d.images[q.image_id].objects[i] for i in q.object_ids_output]
+            boxes = [o.bbox for o in objects]
+            tg.boxes.extend(boxes)
+            tg.object_ids.extend(q.object_ids_output)
+            for _ in range(repeats):
+                tg.repeated_boxes.extend(boxes)
+            tg.num_boxes.append(len(boxes))
+            tg.is_exhaustive.append(q.is_exhaustive)
+            if with_seg_masks:
+                for o in objects:
+                    if o.segment is not None:
+                        tg.segments.append(o.segment)
+                        tg.is_valid_segment.append(1)
+                    else:
+                        tg.segments.append(torch.zeros(d.images[q.image_id].data.shape[-2:], dtype=torch.bool))
+                        tg.is_valid_segment.append(0)
+            else:
+                tg.segments = tg.is_valid_segment = None
+            if q.semantic_target is not None:
+                tg.semantic_segments.append(q.semantic_target)
+        first_image += len(d.images)
+
+    for i in range(n_stages):
+        st, tg = stages[i], targets[i]
+        st.input_points = _pad_to_longest(st.input_points, 0)
+        st.input_points_mask = _pad_to_longest(st.input_points_mask, 1)
+        st.input_boxes = _pad_to_longest(st.input_boxes, 0)
+        st.input_boxes_label = _pad_to_longest(st.input_boxes_label, 0)
+        st.input_boxes_mask = _pad_to_longest(st.input_boxes_mask, 1)
+        _tensorise(st, _FIND_STAGE)
+        _tensorise(tg, _FIND_TARGET)
+        _tensorise(metas[i], _METADATA)
+        tg.boxes_padded = _packed_to_padded(tg.boxes.view(-1, 4), tg.num_boxes)
+        tg.object_ids_padded = _packed_to_padded(tg.object_ids, tg.num_boxes, fill=-1)
+    for img in images[1:]:
+        assert img.shape == images[0].shape, "All images must have the same size"
+    img_batch = torch.stack(images)
+    if load_image_in_fp16:
+        img_batch = img_batch.half()
+    return {dict_key: BatchedDatapoint(img_batch=img_batch, find_text_batch=texts, find_inputs=stages,
+                                       find_targets=targets, find_metadatas=metas, raw_images=raw_images)}
+
+
+# ------------------------------------------------------------------------------------------------ synthetic data --
+def synthetic_datapoint(idx: int, resolution: int = 1008, source: int = 1024, n_objects: int = 2,
+                        text: str = "crack", seed: int = 1234) -> Datapoint:
+    """One sample of SURVEY section 8(d).  Deterministic in (seed, idx)."""
+    g = torch.Generator().manual_seed(seed + idx)
+    raw = torch.rand(3, source, source, generator=g)
+    if source != resolution:                    # PIL's BILINEAR resize is an antialiased triangle filter when shrinking
+        raw = torch.nn.functional.interpolate(raw[None], size=(resolution, resolution), mode="bilinear",
+                                              align_corners=False, antialias=True)[0]
+    image = ((raw * 255.0).round().clamp(0, 255) / 255.0 - 0.5) / 0.5          # uint8 quantisation of the PIL path
+    xy = torch.rand(n_objects, 2, generator=g) * 0.5
+    wh = torch.rand(n_objects, 2, generator=g) * 0.3 + 0.1
+    objects = []
+    for i in range(n_objects):
+        x1, y1 = xy[i].tolist()
+        x2, y2 = min(x1 + wh[i, 0].item(), 1.0), min(y1 + wh[i, 1].item(), 1.0)
+        box = torch.tensor([x1, y1, x2, y2], dtype=torch.float32)               # normalised xyxy, as the reference stores
+        mask = torch.zeros(resolution, resolution, dtype=torch.bool)
+        px = (box * resolution).round().long().tolist()
+        mask[px[1]:max(px[3], px[1] + 1), px[0]:max(px[2], px[0] + 1)] = True
+        objects.append(Object(bbox=box, area=(box[2] - box[0]) * (box[3] - box[1]), object_id=i, segment=mask))
+    query = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(n_objects)), is_exhaustive=True,
+                            query_processing_order=0,
+                            inference_metadata=InferenceMetadata(coco_image_id=idx, original_image_id=idx,
+                                                                 original_category_id=0, original_size=(source, source),
+                                                                 object_id=-1, frame_index=-1))
+    return Datapoint(find_queries=[query], images=[Image(data=image, objects=objects, size=(resolution, resolution))])
+
+
+class SyntheticSegmentDataset(torch.utils.data.Dataset):
+    """``len`` samples of :func:`synthetic_datapoint` -- what ``training.data_dir: synthetic[:N]`` selects."""
+
+    def __init__(self, length: int = 64, split: str = "train", resolution: int = 1008, source: int = 1024,
+                 n_objects: int = 2, text: str = "crack", seed: int = 1234):
+        self.length, self.resolution, self.source = length, resolution, source
+        self.n_objects, self.text = n_objects, text
+        self.seed = seed + (0 if split == "train" else 1_000_003)
+
+    def __len__(self) -> int:
+        return self.length
+
+    def __getitem__(self, idx: int) -> Datapoint:
+        return synthetic_datapoint(idx, self.resolution, self.source, self.n_objects, self.text, self.seed)
+
+
+# ----------------------------------------------------------------------------------------- rank-sharded loading --
+def shard_indices(n: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0,
+                  drop_last: bool = False) -> List[int]:
+    """``torch.utils.data.DistributedSampler`` semantics (the reference's DDP trainer shards with it,
+    ``sam3/train/data/torch_dataset.py:30-37``): a permutation seeded by ``seed + epoch`` shared by all ranks, padded
+    by wrapping to a multiple of ``world`` (or truncated with ``drop_last``), rank ``r`` takes ``r, r + world, ...`` --
+    so the shards are disjoint, equally long, and their union is the dataset."""
+    if shuffle:
+        order = torch.randperm(n, generator=torch.Generator().manual_seed(seed + epoch)).tolist()
+    else:
+        order = list(range(n))
+    if drop_last:
+        order = order[:n // world * world]
+    else:
+        total = (n + world - 1) // world * world
+        while len(order) < total:
+            order += order[:total - len(order)]
+    return order[rank::world]
+
+
+class ShardedLoader:
+    """Batches of a map-style dataset for one rank: ``shard_indices`` per epoch, ``collate_fn`` per batch.  A thin
+    stand-in for ``DataLoader(dataset, batch_size, sampler=DistributedSampler(...), num_workers=0)`` that keeps the
+    sampler's ``set_epoch`` protocol and works identically with world size 1 (then it is the reference's
+    ``DataLoader(shuffle=...)``)."""
+
+    def __init__(self, dataset, batch_size: int, collate_fn, shuffle: bool, rank: int = 0, world: int = 1, seed: int = 0):
+        self.dataset, self.batch_size, self.collate_fn = dataset, int(batch_size), collate_fn
+        self.shuffle, self.rank, self.world, self.seed, self.epoch = shuffle, rank, world, seed, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def indices(self) -> List[int]:
+        return shard_indices(len(self.dataset), self.rank, self.world, self.epoch, self.shuffle, self.seed)
+
+    def __len__(self) -> int:
+        per_rank = (len(self.dataset) + self.world - 1) // self.world
+        return (per_rank + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        idx = self.indices()
+        for i in range(0, len(idx), self.batch_size):
+            yield self.collate_fn([self.dataset[j] for j in idx[i:i + self.batch_size]])

@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""
+End-to-end golden step (SURVEY section 7-1(iv), section 8c "Model step"): the REFERENCE's own parametric classes --
+ViT, Sam3DualViTDetNeck, VETextEncoder, TransformerEncoderFusion, TransformerDecoder, SequenceGeometryEncoder,
+UniversalSegmentationHead, Sam3Image, collate_fn_api, BinaryHungarianMatcherV2, Sam3LossWrapper, the root LoRA
+injector -- imported from /root/reference and assembled exactly as ``sam3/model_builder.py:58-324,478-512`` assembles
+them, at the tiny widths of e2e_case_defs.TINY, dropout / DropPath 0, CPU fp32.  Build container only.
+
+    python tests/golden/make_e2e_golden.py   ->  e2e_tiny.npz
+
+Stores: the state dict, the collated batch, the training-mode forward (every output tensor, aux outputs, matcher
+indices), the eval-mode forward, and -- with root LoRA injected and B seeded non-zero -- the loss dictionary, A/B
+gradients, A/B after one AdamW step and the loss curve of LR/WD/STEPS in e2e_case_defs (the loop of
+``train_sam3_lora_native.py:887-943`` re-enacted around the imported classes).
+"""
+import contextlib
+import functools
+import io
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+REF = "/root/reference"
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.abspath(os.path.join(HERE, "..", ".."))]
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import sam3_manifest
+import e2e_case_defs as D
+from loss_case_defs import CLI_LOSS_CFG
+
+
+def build_reference_tiny():
+    from sam3.model.decoder import TransformerDecoder, TransformerDecoderLayer
+    from sam3.model.encoder import TransformerEncoderFusion, TransformerEncoderLayer
+    from sam3.model.geometry_encoders import SequenceGeometryEncoder
+    from sam3.model.maskformer_segmentation import PixelDecoder, UniversalSegmentationHead
+    from sam3.model.model_misc import DotProductScoring, MLP, MultiheadAttentionWrapper as MHA, TransformerWrapper
+    from sam3.model.necks import Sam3DualViTDetNeck
+    from sam3.model.position_encoding import PositionEmbeddingSine
+    from sam3.model.sam3_image import Sam3Image
+    from sam3.model.text_encoder_ve import VETextEncoder
+    from sam3.model.vitdet import ViT
+    from sam3.model.vl_combiner import SAM3VLBackbone
+    from sam3.train.matcher import BinaryHungarianMatcherV2
+    c = D.TINY
+    d, h, ffn, p = c["d_model"], c["heads"], c["ffn"], c["dropout"]
+    vit = ViT(norm_layer="LayerNorm", qkv_bias=True, use_abs_pos=True, tile_abs_pos=True, rel_pos_blocks=(),
+              use_rope=True, use_interp_rope=True, pretrain_use_cls_token=True, retain_cls_token=False, ln_pre=True,
+              ln_post=False, return_interm_layers=False, bias_patch_embed=False, compile_mode=None, **c["vit"])
+    pe = lambda: PositionEmbeddingSine(num_pos_feats=d, normalize=True, scale=None, temperature=10000)
+    neck = Sam3DualViTDetNeck(position_encoding=pe(), d_model=d, scale_factors=[4.0, 2.0, 1.0, 0.5], trunk=vit,
+                              add_sam2_neck=False)
+    text = VETextEncoder(tokenizer=D.toy_tokenizer, d_model=d, **c["text"])
+    backbone = SAM3VLBackbone(visual=neck, text=text, scalp=1)
+    enc_layer = TransformerEncoderLayer(activation="relu", d_model=d, dim_feedforward=ffn, dropout=p,
+                                        pos_enc_at_attn=True, pos_enc_at_cross_attn_keys=False,
+                                        pos_enc_at_cross_attn_queries=False, pre_norm=True,
+                                        self_attention=MHA(num_heads=h, dropout=p, embed_dim=d, batch_first=True),
+                                        cross_attention=MHA(num_heads=h, dropout=p, embed_dim=d, batch_first=True))
+    encoder = TransformerEncoderFusion(layer=enc_layer, num_layers=c["enc_layers"], d_model=d, num_feature_levels=1,
+                                       frozen=False, use_act_checkpoint=True, add_pooled_text_to_img_feat=False,
+                                       pool_text_with_mask=True)
+    dec_layer = TransformerDecoderLayer(activation="relu", d_model=d, dim_feedforward=ffn, dropout=p,
+                                        cross_attention=MHA(num_heads=h, dropout=p, embed_dim=d), n_heads=h,
+                                        use_text_cross_attention=True)
+    decoder = TransformerDecoder(layer=dec_layer, num_layers=c["dec_layers"], num_queries=c["num_queries"],
+                                 return_intermediate=True, box_refine=True, num_o2m_queries=0, dac=True, boxRPB="log",
+                                 d_model=d, frozen=False, interaction_layer=None, dac_use_selfatt_ln=True,
+                                 resolution=c["vit"]["img_size"], stride=c["vit"]["patch_size"], use_act_checkpoint=True,
+                                 presence_token=True)
+    transformer = TransformerWrapper(encoder=encoder, decoder=decoder, d_model=d)
+    scoring = DotProductScoring(d_model=d, d_proj=d, prompt_mlp=MLP(input_dim=d, hidden_dim=c["scoring_hidden"],
+                                                                    output_dim=d, num_layers=2, dropout=p,
+                                                                    residual=True, out_norm=nn.LayerNorm(d)))
+    seg = UniversalSegmentationHead(hidden_dim=d, upsampling_stages=3, aux_masks=False, presence_head=False,
+                                    dot_product_scorer=None, act_ckpt=True,
+                                    cross_attend_prompt=MHA(num_heads=h, dropout=0, embed_dim=d),
+                                    pixel_decoder=PixelDecoder(num_upsampling_stages=3, interpolation_mode="nearest",
+                                                               hidden_dim=d, compile_mode=None))
+    geo_layer = TransformerEncoderLayer(activation="relu", d_model=d, dim_feedforward=ffn, dropout=p,
+                                        pos_enc_at_attn=False, pre_norm=True,
+                                        self_attention=MHA(num_heads=h, dropout=p, embed_dim=d, batch_first=False),
+                                        pos_enc_at_cross_attn_queries=False, pos_enc_at_cross_attn_keys=True,
+                                        cross_attention=MHA(num_heads=h, dropout=p, embed_dim=d, batch_first=False))
+    geometry = SequenceGeometryEncoder(pos_enc=pe(), encode_boxes_as_points=False, points_direct_project=True,
+                                       points_pool=True, points_pos_enc=True, boxes_direct_project=True, boxes_pool=True,
+                                       boxes_pos_enc=True, d_model=d, num_layers=c["geo_layers"], layer=geo_layer,
+                                       use_act_ckpt=True, add_cls=True, add_post_encode_proj=True, roi_size=c["roi_size"])
+    matcher = BinaryHungarianMatcherV2(focal=True, cost_class=2.0, cost_bbox=5.0, cost_giou=2.0, alpha=0.25, gamma=2,
+                                       stable=False)
+    return Sam3Image(backbone=backbone, transformer=transformer, input_geometry_encoder=geometry,
+                     segmentation_head=seg, num_feature_levels=1, o2m_mask_predict=True, dot_prod_scoring=scoring,
+                     use_instance_query=False, multimask_output=True, inst_interactive_predictor=None, matcher=matcher)
+
+
+def reference_batch():
+    from sam3.train.data.collator import collate_fn_api
+    from sam3.train.data.sam3_image_dataset import Datapoint, FindQueryLoaded, Image, InferenceMetadata, Object
+    imgs = D.make_images()
+    dps = []
+    for i, ((text, boxes), img) in enumerate(zip(D.SAMPLES, imgs)):
+        objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask(b))
+                for j, b in enumerate(boxes)]
+        q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
+                            query_processing_order=0,
+                            inference_metadata=InferenceMetadata(coco_image_id=i, original_image_id=i,
+                                                                 original_category_id=0, original_size=(D.RES, D.RES),
+                                                                 object_id=-1, frame_index=-1))
+        dps.append(Datapoint(find_queries=[q], images=[Image(data=img, objects=objs, size=(D.RES, D.RES))]))
+    return collate_fn_api(dps, dict_key="input", with_seg_masks=True)["input"]
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()
+
+
+OUT_KEYS = ["pred_logits", "pred_boxes", "pred_boxes_xyxy", "pred_masks", "presence_logit_dec", "pred_logits_o2m",
+            "pred_boxes_o2m", "pred_boxes_xyxy_o2m", "pred_masks_o2m", "semantic_seg", "queries", "encoder_hidden_states"]
+AUX_KEYS = ["pred_logits", "pred_boxes", "pred_boxes_xyxy", "presence_logit_dec", "pred_logits_o2m", "pred_boxes_o2m",
+            "pred_boxes_xyxy_o2m"]
+
+
+def dump_outputs(res, tag, out):
+    for k in OUT_KEYS:
+        if k in out and out[k] is not None:
+            res[f"{tag}/{k}"] = np_(out[k])
+    for i, aux in enumerate(out.get("aux_outputs", [])):
+        for k in AUX_KEYS:
+            if k in aux:
+                res[f"{tag}/aux{i}/{k}"] = np_(aux[k])
+        if "indices" in aux:
+            res[f"{tag}/aux{i}/indices"] = np.stack([np_(aux["indices"][0]), np_(aux["indices"][1])])
+    if "indices" in out:
+        res[f"{tag}/indices"] = np.stack([np_(out["indices"][0]), np_(out["indices"][1])])
+
+
+def main():
+    sam3_manifest._install_stubs()
+    sam3_manifest._patch_cuda_literals()
+    sys.modules["timm.layers"].trunc_normal_ = torch.nn.init.trunc_normal_
+    import types
+    tm = types.ModuleType("torchmetrics.functional")
+    tm.f1_score = lambda *a, **k: torch.tensor(0.0)
+    sys.modules["torchmetrics.functional"] = tm
+    import torchmetrics
+    torchmetrics.functional = tm
+    tv_ops = sys.modules["torchvision.ops"]
+    tv_ops.roi_align = lambda feats, boxes, size: feats.new_zeros((sum(len(b) for b in boxes), feats.shape[1], size, size))
+    import torchvision
+    torchvision.ops = tv_ops
+    from sam3.model.model_misc import SAM3Output
+    from sam3.train.loss import loss_fns as LF
+    from sam3.train.loss.sam3_loss import Sam3LossWrapper
+    from sam3.train.matcher import BinaryHungarianMatcherV2, BinaryOneToManyMatcher
+    import lora_layers as ref_root
+    assert ref_root.__file__.startswith(REF)
+    LF.sigmoid_focal_loss = functools.partial(LF.sigmoid_focal_loss, triton=False)
+
+    torch.manual_seed(0)
+    model = build_reference_tiny()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        te = model.backbone.language_backbone.encoder
+        te.positional_embedding.copy_(torch.randn(te.positional_embedding.shape, generator=g) * 0.01)
+        te.text_projection.copy_(torch.randn(te.text_projection.shape, generator=g) * te.width ** -0.5)
+        for n, p in model.named_parameters():      # non-trivial norms / biases; non-zero final box-head layer
+            if p.ndim == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+        model.transformer.decoder.bbox_embed.layers[-1].weight.copy_(
+            torch.randn(model.transformer.decoder.bbox_embed.layers[-1].weight.shape, generator=g) * 0.05)
+    res = {}
+    for k, v in model.state_dict().items():
+        if v.is_complex():
+            res[f"sd/{k}.re"], res[f"sd/{k}.im"] = np_(v.real), np_(v.imag)
+        else:
+            res[f"sd/{k}"] = np_(v)
+    res["sd_keys"] = np.array(list(model.state_dict().keys()))
+
+    batch = reference_batch()
+    fi, ft = batch.find_inputs[0], batch.find_targets[0]
+    res["batch/img_batch"] = np_(batch.img_batch)
+    res["batch/texts"] = np.array(batch.find_text_batch)
+    for k in ("img_ids", "text_ids", "input_boxes", "input_boxes_mask", "input_boxes_label", "input_points",
+              "input_points_mask"):
+        res[f"batch/find_input/{k}"] = np_(getattr(fi, k))
+    for k in ("num_boxes", "boxes", "boxes_padded", "repeated_boxes", "segments", "semantic_segments",
+              "is_valid_segment", "is_exhaustive", "object_ids", "object_ids_padded"):
+        res[f"batch/find_target/{k}"] = np_(getattr(ft, k))
+
+    # eval-mode forward (no DAC, no aux bookkeeping)
+    model.eval()
+    with torch.no_grad():
+        out = model(batch)[0]
+    dump_outputs(res, "eval", out)
+
+    # training-mode forward of the un-adapted model (matching inside forward)
+    model.train()
+    out = model(batch)[0]
+    dump_outputs(res, "train", out)
+
+    # LoRA + the native CLI's loss stack and loop
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref_root.apply_lora_to_model(model, ref_root.LoRAConfig(**D.LORA))
+    names = [n for n, m in model.named_modules() if isinstance(m, ref_root.LoRALinear)]
+    gb = torch.Generator().manual_seed(D.LORA_B_SEED)
+    with torch.no_grad():
+        for n, m in model.named_modules():
+            if isinstance(m, ref_root.LoRALayer):
+                m.lora_B.copy_(torch.randn(m.lora_B.shape, generator=gb) * D.LORA_B_STD)
+                res[f"lora/{n}.lora_A"], res[f"lora/{n}.lora_B"] = np_(m.lora_A), np_(m.lora_B)
+    res["lora_module_names"] = np.array(names)
+    cfg = CLI_LOSS_CFG
+    matcher = BinaryHungarianMatcherV2(**cfg["matcher"])
+    wrapper = Sam3LossWrapper(loss_fns_find=[LF.Boxes(**cfg["boxes"]), LF.IABCEMdetr(**cfg["ce"]), LF.Masks(**cfg["masks"])],
+                              matcher=matcher, o2m_matcher=BinaryOneToManyMatcher(**cfg["o2m"]), **cfg["wrapper"])
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.LR, weight_decay=D.WD)
+    losses = []
+    for step in range(D.STEPS):
+        outputs = model(batch)
+        targets = [model.back_convert(t) for t in batch.find_targets]
+        with SAM3Output.iteration_mode(outputs, iter_mode=SAM3Output.IterMode.ALL_STEPS_PER_STAGE) as it:
+            for stage_out, tg in zip(it, targets):
+                for o in stage_out:
+                    o["indices"] = matcher(o, tg)
+                    for a in o.get("aux_outputs", []):
+                        a["indices"] = matcher(a, tg)
+        loss_dict = wrapper(outputs, targets)
+        total = loss_dict["core_loss"]
+        opt.zero_grad()
+        total.backward()
+        if step == 0:
+            dump_outputs(res, "lora", outputs[0][0] if isinstance(outputs[0], list) else outputs[0])
+            for k, v in loss_dict.items():
+                res[f"loss/{k}"] = np.float64(float(v))
+            for n, m in model.named_modules():
+                if isinstance(m, ref_root.LoRALayer):
+                    res[f"gA/{n}"], res[f"gB/{n}"] = np_(m.lora_A.grad), np_(m.lora_B.grad)
+        opt.step()
+        if step == 0:
+            for n, m in model.named_modules():
+                if isinstance(m, ref_root.LoRALayer):
+                    res[f"A1/{n}"], res[f"B1/{n}"] = np_(m.lora_A), np_(m.lora_B)
+        losses.append(total.item())
+    res["losses"] = np.array(losses, np.float64)
+    np.savez_compressed(os.path.join(HERE, "e2e_tiny.npz"), **res)
+    print("adapted:", len(names), "modules; losses:", " ".join(f"{l:.6f}" for l in losses))
+    print("arrays:", len(res), "; bytes:", os.path.getsize(os.path.join(HERE, "e2e_tiny.npz")))
+
+
+if __name__ == "__main__":
+    main()
