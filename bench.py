@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
 """
-bench.py -- throughput of the LoRA adapter hot path on MI355X, at BASELINE.json's config.
+bench.py -- SAM3-LoRA training throughput on MI355X at BASELINE.json's configuration, and the HBM roofline of the
+hand-written adapter kernels inside it.
 
-One STEP = one pass of the hot path over one batch of synthetic input, i.e. everything the
-LoRA adapters of the SAM3 ViT trunk do in one training step of `full_lora_config.yaml` at r=16
-(configs[1]: batch 8 @ 1024^2 source -> 1008^2 model input -> 72x72 = 5184 tokens/image,
-M = 41472 rows; 32 blocks x {fc1 1024->4736, fc2 4736->1024} = 64 adapted Linears, bf16):
+One STEP = one training step of `full_lora_config.yaml` at r=16 (BASELINE configs[1]: batch 8 per GPU of synthetic
+1024^2 images -> 1008^2 model input, bf16) on the whole SAM3 image model (this library's restatement, 840.5M
+parameters, random seeded init -- there is no network for the checkpoint): forward, Hungarian matching of the final and
+the five auxiliary decoder outputs, Sam3LossWrapper, backward, all-reduce of the A/B gradients (N > 1), AdamW on A/B
+(train_sam3_lora_native.py:887-943).  `value` = global images per second of that step; inputs are resident in HBM
+before the timed region; nothing is skipped inside it.
 
-    forward            64 x sam3_lora_fwd                      (no-grad pass of activation checkpointing)
-    recompute+backward 64 x sam3_lora_fwd (saving t) + 64 x sam3_lora_bwd, block 31 -> 0
-                       (the reference ViT recomputes every block in backward, vitdet.py:837-838)
-    gradient exchange  all-reduce of the flat fp32 A/B-grad buffer (N > 1 only), bucketed on a side stream
-
-The frozen GEMMs / attention / DETR / loss are PyTorch-ROCm plumbing outside this path and are NOT in
-the timed region (and not claimed): `value` is images/s THROUGH THE ADAPTER PATH, the quantity
-the hand-written kernels determine.  Inputs are resident in HBM before the timed region.
-
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed),
-"kernels"/"ops" (every kernel and every C-ABI op at this config), "cpu_baseline" (numpy oracle).
+Beside it, on the same JSON line:
+  "adapter_path"  the LoRA adapter path on its own (64 adapted ViT-MLP Linears: pack + forward + checkpoint recompute +
+                  backward through the C-ABI) -- the quantity the HIP kernels determine, with its CPU port;
+  "roofline"      dominant adapter kernel, timed in situ with HIP events inside the library, against 8 TB/s;
+                  "roofline.step" = the whole adapter path against SURVEY 8(d)'s algorithmic bytes;
+  "kernels"/"ops" every kernel x shape and every C-ABI call of the adapter path;
+  "mfma_bound"    the whole step against the ~140 images/s MFMA bound of SURVEY 8(d);
+  "phases_ms"     forward / matching / loss / backward / exchange+optimizer of one synchronised step;
+  "cpu_baseline"  the reference's CPU training step (configs[0]) re-enacted on the host cores, bounded sample;
+  "distributed"   backend, RCCL version, device id of every rank;  "exchange_overlap" (N > 1).
 """
 import argparse
 import json
@@ -32,6 +34,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BOUND_IPS = 140.0       # ~18 TFLOP per image and step at 2.5 PFLOP/s dense bf16
 D_MODEL, D_HID, TOKENS, N_BLOCKS = 1024, 4736, 5184, 32
 
 
@@ -49,8 +52,15 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-trunk", action="store_true", help="skip the whole-ViT-trunk training-step measurement")
+    ap.add_argument("--trunk", action="store_true", help="also time the ViT trunk alone (with / without recompute)")
     ap.add_argument("--trunk-steps", type=int, default=3)
+    ap.add_argument("--adapter-only", action="store_true", help="skip the whole-model step; the line is the adapter path")
+    ap.add_argument("--act-checkpoint", choices=["auto", "on", "off"], default="auto",
+                    help="activation checkpointing of the whole-model step (auto: off when the activations fit in HBM)")
+    ap.add_argument("--match-twice", action="store_true", help="also match inside the model's forward, as the reference does")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the exchange-overlap measurement (N > 1)")
+    ap.add_argument("--model", choices=["sam3", "tiny"], default="sam3",
+                    help="tiny: the parity fixture's widths at 112^2 (contract tests only; the line says so)")
     return ap.parse_args()
 
 
@@ -344,9 +354,9 @@ def trunk_step_bench(dev, batch, rank, steps, world, checkpoint=True):
     return out
 
 
-def cpu_baseline(rank, seconds_budget=25.0):
-    """numpy oracle (kind 'port') on a bounded sample: 1 image through the same 64-Linear
-    fwd + recompute + bwd schedule, fp32 (the reference CLI's dtype)."""
+def adapter_cpu_port(rank, seconds_budget=10.0):
+    """numpy oracle of the adapter arithmetic alone (kind 'port') on a bounded sample: 1 image through the 64-Linear
+    fwd + recompute + bwd schedule, fp32 -- the CPU counterpart of `adapter_path`."""
     import numpy as np
     from oracle import lora_oracle as O
     M, r, s = TOKENS, rank, 2.0
@@ -380,14 +390,202 @@ def cpu_baseline(rank, seconds_budget=25.0):
         n += 1
     dt = time.perf_counter() - t0
     per_img_s = dt / n * N_BLOCKS
+    return dict(value=round(1.0 / per_img_s, 4), unit="images/s", kind="port",
+                sample=f"numpy fp32 oracle of the adapter arithmetic, 1 image (M={M}), {n}/{N_BLOCKS} ViT blocks timed, "
+                       f"extrapolated to 32 blocks; {dt:.1f}s of CPU work")
+
+
+def host_cores():
+    """(threads torch uses, physical cores of the host)."""
+    phys = None
     try:
-        import threadpoolctl
-        threads = max((p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()), default=os.cpu_count())
+        import psutil
+        phys = psutil.cpu_count(logical=False)
     except Exception:
-        threads = os.cpu_count()
-    return dict(value=round(1.0 / per_img_s, 4), unit="images/s", cores=int(threads), kind="port",
-                sample=f"numpy fp32 oracle, 1 image (M={M}), {n}/{N_BLOCKS} ViT blocks timed "
-                       f"(fc1+fc2 adapter fwd, recompute fwd, bwd), extrapolated to 32 blocks; {dt:.1f}s of CPU work")
+        pass
+    return torch.get_num_threads(), int(phys or os.cpu_count() or 1)
+
+
+def model_setup(kind):
+    """(config, resolution, source size) of the whole-step workload."""
+    from sam3_lora_amd.sam3_image import SAM3_CONFIG, TINY_CONFIG
+    if kind == "tiny":
+        cfg = dict(TINY_CONFIG, text=dict(TINY_CONFIG["text"], vocab_size=49408, context_length=32))
+        return cfg, 112, 128
+    return dict(SAM3_CONFIG), 1008, 1024
+
+
+def cpu_baseline(kind="sam3", seconds_budget=45.0):
+    """SURVEY section 8(d) "CPU baseline beside it": the reference's own training step -- configs[0]: minimal LoRA
+    (rank 4 on the ViT MLPs, vision encoder only), fp32, CPU -- re-enacted by the oracle-side restatement: this
+    library's PyTorch host model (sam3_image) with the adapters written as the reference writes them
+    (oracle/lora_torch_cpu.py: base + ((x @ A) @ B) * s, torch autograd), matcher, loss wrapper, AdamW.
+    Bounded sample: a probe step on a depth-reduced trunk predicts the cost of the whole step; the whole step (1 image)
+    is timed when it fits the budget, otherwise the figure is the extrapolation from the probe -- `sample` says which."""
+    from oracle.lora_torch_cpu import apply_reference_form_lora
+    from sam3_lora_amd.sam3_data import SyntheticSegmentDataset, collate_fn_api
+    from sam3_lora_amd.sam3_image import build_sam3_image_model
+    from sam3_lora_amd.trainer import build_criterion, match_all_steps
+    threads, phys = host_cores()
+    torch.set_num_threads(phys)
+    SAM3_CONFIG, res, src = model_setup(kind)
+    ds = SyntheticSegmentDataset(2, resolution=res, source=src)
+    batch = collate_fn_api([ds[0]], dict_key="input", with_seg_masks=True)["input"]
+
+    torch.manual_seed(0)
+    model = build_sam3_image_model(device="cpu", eval_mode=False, config=SAM3_CONFIG, match_in_forward=True)
+    n_adapted = apply_reference_form_lora(model, rank=4, alpha=8, targets=("fc1", "fc2"), only_under="vision_backbone")
+    model.train()
+    matcher, wrapper = build_criterion("local")
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01)
+    trunk = model.backbone.vision_backbone.trunk
+    all_blocks, all_global = list(trunk.blocks), list(trunk.full_attn_ids)
+    windowed = [i for i in range(len(all_blocks)) if i not in all_global]
+
+    def one_step(block_ids):
+        """The whole step with the trunk reduced to ``block_ids`` (None = all blocks)."""
+        ids = list(range(len(all_blocks))) if block_ids is None else list(block_ids)
+        trunk.blocks = torch.nn.ModuleList([all_blocks[i] for i in ids])
+        trunk.full_attn_ids = [len(ids) - 1]            # the feature map leaves after the last kept block
+        t0 = time.perf_counter()
+        out = model(batch)
+        targets = [model.back_convert(t) for t in batch.find_targets]
+        match_all_steps(matcher, out.output, targets)
+        loss = wrapper(out, targets)["core_loss"]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        trunk.blocks, trunk.full_attn_ids = torch.nn.ModuleList(all_blocks), all_global
+        return dt, loss.item()
+
+    # T(w windowed, g global blocks) = R + w Tw + g Tg from three short probes
+    w0, g0 = windowed[:3], all_global[:1]
+    t_11, _ = one_step(w0[:1] + g0)
+    t_31, _ = one_step(w0[:3] + g0)
+    t_20, _ = one_step(w0[:2])
+    Tw = max((t_31 - t_11) / 2, 1e-4)
+    R = max(t_20 - 2 * Tw, 0.0)
+    Tg = max(t_11 - R - Tw, Tw)
+    predicted = R + len(windowed) * Tw + len(all_global) * Tg
+    if predicted <= seconds_budget:
+        t_full, loss = one_step(None)
+        sample = (f"whole CPU training step timed once: 1 synthetic image @ {res}^2 (configs[0] has 2), "
+                  f"{'full 840M-parameter' if kind == 'sam3' else 'TINY-width (contract test)'} "
+                  f"model, {n_adapted} rank-4 adapters in reference form, fwd + 2x matching + loss + bwd (per-block "
+                  f"recompute) + AdamW, fp32; loss {loss:.2f}; {t_full:.1f}s of CPU work (predicted {predicted:.1f}s)")
+    else:
+        t_full = predicted
+        sample = (f"extrapolated from three probe steps of the whole model with the trunk cut to (1 windowed + 1 global), "
+                  f"(3 + 1) and (2 + 0) blocks: {t_11:.1f}s / {t_31:.1f}s / {t_20:.1f}s for 1 synthetic image @ {res}^2 -> "
+                  f"{Tw:.2f}s per windowed block, {Tg:.2f}s per global block, {R:.1f}s for everything else -> "
+                  f"{predicted:.1f}s for the {len(all_blocks)}-block step (over the {seconds_budget:.0f}s budget, not run whole); "
+                  f"{n_adapted} rank-4 adapters in reference form, fp32, fwd + 2x matching + loss + bwd (recompute) + AdamW")
+    torch.set_num_threads(threads)
+    return dict(value=round(1.0 / t_full, 5), unit="images/s", cores=phys, kind="port", s_per_step=round(t_full, 2),
+                sample=sample)
+
+
+# ============================================================================================ the full step ==
+class FullStep:
+    """One data-parallel rank of the training step of train_sam3_lora_native.py:887-943 on this library's SAM3 image
+    model: synthetic batch (resident in HBM) -> forward (ViT trunk with the HIP adapter path, neck, text tower, fusion
+    encoder, decoder, mask head) -> back_convert -> Hungarian matching of the final and every auxiliary output ->
+    Sam3LossWrapper -> backward -> flat-buffer all-reduce of the A/B gradients -> AdamW on A/B."""
+
+    def __init__(self, dev, batch, lora_rank, world, rank, dropout=0.0, act_checkpoint="auto", match_once=True,
+                 bf16=True, kind="sam3"):
+        import contextlib
+        import io
+        import lora_layers as L
+        from sam3_lora_amd import vit as V
+        from sam3_lora_amd.ddp import LoRAGradReducer
+        from sam3_lora_amd.sam3_data import SyntheticSegmentDataset, collate_fn_api
+        from sam3_lora_amd.sam3_image import build_sam3_image_model
+        from sam3_lora_amd.trainer import build_criterion, move_to_device
+        self.dev, self.batch, self.world = dev, batch, world
+        cfg, res, src = model_setup(kind)
+        self.kind, self.res = kind, res
+        self.model = build_sam3_image_model(device=str(dev), eval_mode=False, match_in_forward=not match_once, seed=0,
+                                            config=cfg)
+        with contextlib.redirect_stdout(io.StringIO()):
+            L.apply_lora_to_model(self.model, L.LoRAConfig(
+                rank=lora_rank, alpha=2 * lora_rank, dropout=dropout,
+                target_modules=["q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2"], apply_to_vision_encoder=True,
+                apply_to_text_encoder=True, apply_to_geometry_encoder=True, apply_to_detr_encoder=True,
+                apply_to_detr_decoder=True, apply_to_mask_decoder=True))
+        self.n_adapted = sum(isinstance(m, L.LoRALinear) for m in self.model.modules())
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():       # a warmed state (B != 0) so that all four gradient products are exercised
+            for m in self.model.modules():
+                if isinstance(m, L.LoRALayer):
+                    m.lora_B.copy_(torch.randn(m.lora_B.shape, generator=g) * 0.02)
+        self.model.to(dev)
+        if bf16:
+            V.to_training_layout(self.model)
+        self.model.train()
+        mode = {"on": True, "off": False}.get(act_checkpoint, "auto")
+        if mode == "auto":          # one forward so that the policy sees the real token count; then decide
+            self.ckpt = V.set_activation_checkpointing(self.model, "auto", batch=batch)
+        else:
+            self.ckpt = V.set_activation_checkpointing(self.model, mode, batch=batch)
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.reducer = LoRAGradReducer(self.params, bucket_bytes=8 << 20)
+        self.opt = torch.optim.AdamW(self.params, lr=5e-5, weight_decay=0.01)
+        self.matcher, self.wrapper = build_criterion("global" if world > 1 else "local")
+        ds = SyntheticSegmentDataset(2 * batch * world, resolution=res, source=src)
+        self.batches = []
+        for k in range(2):          # two resident batches, alternated
+            idx = [k * batch * world + rank * batch + i for i in range(batch)]
+            b = collate_fn_api([ds[i] for i in idx], dict_key="input", with_seg_masks=True)["input"]
+            b = move_to_device(b, dev)
+            if bf16:
+                b.img_batch = b.img_batch.bfloat16()
+            self.batches.append(b)
+        self.n = 0
+        self.last_loss = None
+
+    def step(self, timers=None):
+        from sam3_lora_amd.trainer import match_all_steps
+        b = self.batches[self.n & 1]
+        self.n += 1
+
+        def mark(name):
+            if timers is not None:
+                torch.cuda.synchronize()
+                timers.append((name, time.perf_counter()))
+        mark("start")
+        out = self.model(b)
+        mark("forward")
+        targets = [self.model.back_convert(t) for t in b.find_targets]
+        match_all_steps(self.matcher, out.output, targets)
+        mark("matching (host LSAP)")
+        loss = self.wrapper(out, targets)["core_loss"]
+        mark("loss")
+        self.reducer.zero_grad()
+        loss.backward()
+        mark("backward")
+        self.reducer.finish()
+        self.opt.step()
+        mark("exchange + AdamW")
+        self.last_loss = loss
+        return loss
+
+
+def rccl_info(world, dev):
+    info = {"backend": dist.get_backend() if world > 1 else None, "device": torch.cuda.get_device_name(dev)}
+    try:
+        info["rccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception as e:
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    ids = torch.tensor([dev.index if dev.index is not None else 0], device=dev)
+    if world > 1:
+        gathered = [torch.zeros_like(ids) for _ in range(world)]
+        dist.all_gather(gathered, ids)
+        info["rank_device_ids"] = [int(t.item()) for t in gathered]
+    else:
+        info["rank_device_ids"] = [int(ids.item())]
+    return info
 
 
 def main():
@@ -411,72 +609,112 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank, dropout=args.dropout,
-                 act_dtype=torch.bfloat16 if args.act_dtype == "bf16" else torch.float32)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        w.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        w.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    finite = all(torch.isfinite(p.grad).all().item() for p in w.params[:8]) and torch.isfinite(w.h[0].float()).all().item()
+    def timed(fn, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
+    act_dtype = torch.bfloat16 if args.act_dtype == "bf16" else torch.float32
     out = None
+    # ------------------------------------------------------------------ the headline: the whole training step
+    full = None
+    if not args.adapter_only:
+        full = FullStep(dev, args.batch, args.rank, world, rank, dropout=args.dropout, act_checkpoint=args.act_checkpoint,
+                        match_once=not args.match_twice, bf16=args.act_dtype == "bf16", kind=args.model)
+        for _ in range(args.warmup):
+            full.step()
+        dt = timed(full.step, args.steps)
+        finite = bool(torch.isfinite(full.last_loss).item()) and all(
+            torch.isfinite(p.grad).all().item() for p in full.params[:8])
+        info = rccl_info(world, dev)
+        if rank == 0:
+            ms = dt / args.steps * 1e3
+            ips = world * args.batch / (dt / args.steps)
+            out = {
+                "metric": "training images/sec at 1024^2, SAM3-base r=%d (whole training step)" % args.rank,
+                "value": round(ips, 2), "unit": "images/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.act_dtype, "data": "synthetic",
+                "config": {"workload": ("" if args.model == "sam3" else "[TINY-WIDTH CONTRACT-TEST MODEL, not the benchmark] ") +
+                                       "full_lora_config.yaml @ r=%d alpha=%d (BASELINE configs[1]): SAM3 image model "
+                                       "(840.5M parameters, random seeded init), batch %d/GPU of synthetic 1024^2 images -> "
+                                       "1008^2 with 2 boxes + masks each and the prompt 'crack'; forward + Hungarian "
+                                       "matching (final + 5 aux outputs) + Sam3LossWrapper (boxes, IA-BCE + presence, "
+                                       "mask focal + dice, o2m twins) + backward + A/B-gradient all-reduce + AdamW; frozen "
+                                       "tensors and activations %s, A/B fp32; LoRA on the %d ViT-MLP Linears through the "
+                                       "HIP adapter path; activation checkpointing %s; matching %s per step"
+                                       % (args.rank, 2 * args.rank, args.batch, args.act_dtype, full.n_adapted,
+                                          "on (per block / layer)" if full.ckpt else "off (activations kept in HBM)",
+                                          "twice (model + loop, as the reference)" if args.match_twice else "once"),
+                           "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                           "grad_allreduce_bytes": full.reducer.nbytes, "finite": finite,
+                           "loss": round(float(full.last_loss), 4), "adapted_modules": full.n_adapted,
+                           "trainable_parameters": sum(p.numel() for p in full.params)},
+                # ~18 TFLOP per image and step -> ~140 images/s per GPU at the 2.5 PFLOP/s dense
+                # bf16 MFMA peak; the whole step is MFMA/attention-bound, the adapter kernels HBM-bound (roofline below)
+                "mfma_bound": {"images_per_s_per_gpu_at_peak": MFMA_BOUND_IPS, "frac": round(ips / world / MFMA_BOUND_IPS, 4),
+                               "what": "whole-step images/s per GPU over the ~140 images/s MFMA bound of SURVEY 8(d)"},
+                "distributed": info,
+                "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+            }
+        # phase breakdown of one extra (synchronising) step -- all ranks run it (it contains the exchange)
+        marks = []
+        full.step(timers=marks)
+        if rank == 0:
+            out["phases_ms"] = {name: round((t - marks[i][1]) * 1e3, 2) for i, (name, t) in enumerate(marks[1:])}
+        if not args.no_overlap:
+            ov = overlap_measurement(full, world)
+            if rank == 0:
+                out["exchange_overlap"] = ov
+        del full
+        torch.cuda.empty_cache()
+    # ------------------------------------------------------------------ the adapter path on its own (HBM roofline)
+    w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank, dropout=args.dropout, act_dtype=act_dtype)
+    a_steps = args.steps if args.adapter_only else max(3, min(args.steps, 6))
+    for _ in range(2):
+        w.step()
+    dta = timed(w.step, a_steps)
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        out = {
-            "metric": "training images/sec at 1024^2 (adapter path: 64 LoRA'd ViT-MLP Linears fwd + recompute + bwd), SAM3-base r=%d" % args.rank,
-            "value": round(world * args.batch / (dt / args.steps), 2),
-            "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.act_dtype, "data": "synthetic",
-            "config": {"workload": "full_lora_config.yaml @ r=%d alpha=%d (configs[1]): batch %d/GPU @ 1024^2 -> 1008^2 "
-                                   "(M=%d rows), %d ViT blocks x {fc1 1024->4736, fc2 4736->1024}, bf16 activations, "
-                                   "fp32 A/B + fp32 grad accumulation; frozen GEMMs/attention/DETR/loss excluded"
-                                   % (args.rank, 2 * args.rank, args.batch, w.M, args.blocks),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "grad_allreduce_bytes": w.reducer.nbytes, "finite": bool(finite)},
-        }
-    # the same path without the checkpoint recompute (t saved by the forward; 2.6 MB per layer): what a trunk that
-    # keeps its activations in 288 GB of HBM needs from the adapters.  Reported beside `value`, never instead of it.
+        msa = dta / a_steps * 1e3
+        ap = {"value": round(world * args.batch / (dta / a_steps), 2), "unit": "images/s", "ms_per_step": round(msa, 3),
+              "steps": a_steps,
+              "what": "the adapter path alone: %d ViT blocks x {fc1 1024->4736, fc2 4736->1024}, M=%d rows: 64 x "
+                      "sam3_lora_pack + 64 x sam3_lora_fwd + 64 x sam3_lora_fwd (checkpoint recompute) + 64 x sam3_lora_bwd "
+                      "+ exchange; frozen GEMMs / attention / DETR / loss excluded" % (args.blocks, w.M)}
+        if out is None:     # --adapter-only: the adapter path is the line
+            out = {"metric": "images/sec through the LoRA adapter path (r=%d)" % args.rank, "value": ap["value"],
+                   "unit": "images/s", "n_gpus": world, "steps": a_steps, "warmup": 2, "ms_per_step": ap["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.act_dtype,
+                   "data": "synthetic", "config": {"workload": ap["what"], "global_batch": world * args.batch,
+                                                   "parallelism": "dp%d" % world}}
+        out["adapter_path"] = ap
     for _ in range(2):
         w.step(recompute=False)
-    barrier()
-    t0 = time.perf_counter()
-    nr_steps = max(2, min(args.steps, 5))
-    for _ in range(nr_steps):
-        w.step(recompute=False)
-    barrier()
-    tnr = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tnr, op=dist.ReduceOp.MAX)
+    nr_steps = 3
+    tnr = timed(lambda: w.step(recompute=False), nr_steps)
     if rank == 0:
-        out["no_recompute"] = {"value": round(world * args.batch * nr_steps / float(tnr.item()), 2), "unit": "images/s",
-                               "ms_per_step": round(float(tnr.item()) / nr_steps * 1e3, 3), "steps": nr_steps,
-                               "schedule": "64 x sam3_lora_pack + 64 x sam3_lora_fwd (saving t) + 64 x sam3_lora_bwd"}
+        out["adapter_path"]["no_recompute"] = {"value": round(world * args.batch * nr_steps / tnr, 2), "unit": "images/s",
+                                               "ms_per_step": round(tnr / nr_steps * 1e3, 3)}
     rows = None
     if not args.no_roofline:
-        # every rank runs the instrumented steps (they contain the gradient all-reduce: a rank-0-only run would
-        # deadlock the others); only rank 0 reports
-        rows = insitu_kernels(w)
+        rows = insitu_kernels(w)          # every rank (the instrumented steps contain the all-reduce)
     if rank == 0 and not args.no_roofline:
         ops = op_table(w, args.kernel_iters)
         dom = rows[0]             # largest share of the step's kernel time
         dimname = {"k_t1": "K", "k_t2": "N", "k_t3": "N"}.get(dom["kernel"], "dim")
-        # the committed PMC passes were taken at the default workload (batch 8, r = 16, bf16): only then do they apply
         default_wl = args.batch == 8 and args.rank == 16 and args.act_dtype == "bf16" and args.blocks == N_BLOCKS
         tr = committed_traffic(dom["kernel"], (dom["dim"] + 127) // 128 if dom["kernel"] == "k_t2" else -1) if default_wl else None
         out["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} [M={w.M},{dimname}={dom['dim']}]",
@@ -487,16 +725,16 @@ def main():
                            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_us": dom["avg_us"]}
         out["kernels"] = rows
         out["ops"] = ops
-        # the whole step against the same roofline: SURVEY section 8(d)'s algorithmic bytes of every call in the step
         e_, r_, M_ = w.x1[0].element_size(), w.rank, w.M
         fwd_b = lambda i, o: e_ * M_ * (i + 2 * o) + e_ * r_ * (i + o)
         bwd_b = lambda i, o: e_ * M_ * (o + i + 2 * i) + 4 * r_ * (i + o) * 2
         per_block = 2 * (fwd_b(D_MODEL, D_HID) + fwd_b(D_HID, D_MODEL)) + bwd_b(D_MODEL, D_HID) + bwd_b(D_HID, D_MODEL)
         step_bytes = per_block * args.blocks
-        out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "ms": round(ms, 3),
-                                   "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                   "frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                   "what": "all 256 C-ABI calls of the timed step (fwd + recompute + bwd of 64 Linears)"}
+        msa = out["adapter_path"]["ms_per_step"]
+        out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "ms": msa,
+                                   "achieved": round(step_bytes / (msa * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                   "frac": round(step_bytes / (msa * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "what": "all 256 C-ABI calls of the adapter path (fwd + recompute + bwd of 64 Linears)"}
         try:
             tu = torch_unfused_block(w)
             ours = ops[-1]["avg_us"]
@@ -507,21 +745,62 @@ def main():
             out["torch_unfused_block"] = {"error": str(e)[:200]}
     if world > 1:
         dist.barrier()
-    if not args.no_trunk:
-        del w
-        torch.cuda.empty_cache()
+    del w
+    torch.cuda.empty_cache()
+    if args.trunk:
         tr = trunk_step_bench(dev, args.batch, args.rank, args.trunk_steps, world)
         tr2 = trunk_step_bench(dev, args.batch, args.rank, args.trunk_steps, world, checkpoint=False)
         if rank == 0:
             out["trunk_step"] = tr
             out["trunk_step_no_checkpoint"] = tr2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.rank)
+        try:
+            out["cpu_baseline"] = cpu_baseline(args.model)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        out["adapter_path"]["cpu_port"] = adapter_cpu_port(args.rank)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def overlap_measurement(full, world):
+    """How much of the A/B-gradient exchange hides behind the backward: the step timed with the bucketed side-stream
+    all-reduce launched from the gradient hooks (overlapped) against the same step with one blocking all-reduce after
+    the backward (exposed), and the exchange on its own.  With one rank there is nothing to exchange: reported as such."""
+    if world == 1:
+        return {"world": 1, "note": "single rank: no exchange"}
+    red = full.reducer
+
+    def run(n):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            full.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    overlapped = run(3)
+    saved = red.overlap
+    red.overlap = False
+    exposed = run(3)
+    red.overlap = saved
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        dist.all_reduce(red.flat)
+    torch.cuda.synchronize()
+    alone = (time.perf_counter() - t0) / 10 * 1e3
+    t = torch.tensor([overlapped, exposed, alone], device=red.flat.device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    o, e, a = (float(v) for v in t.tolist())
+    return {"world": world, "step_ms_overlapped": round(o, 2), "step_ms_exposed": round(e, 2),
+            "allreduce_alone_ms": round(a, 3), "bytes": red.nbytes,
+            "hidden_ms": round(max(e - o, 0.0), 3)}
 
 
 if __name__ == "__main__":

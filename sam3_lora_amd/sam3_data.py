@@ -26,7 +26,8 @@ import torch
 
 __all__ = ["InferenceMetadata", "FindQueryLoaded", "Object", "Image", "Datapoint", "FindStage", "BatchedFindTarget",
            "BatchedInferenceMetadata", "BatchedDatapoint", "collate_fn_api", "SyntheticSegmentDataset",
-           "synthetic_datapoint", "shard_indices", "ShardedLoader"]
+           "synthetic_datapoint", "shard_indices", "ShardedLoader", "COCOSegmentDataset", "segmentation_to_mask",
+           "polygon_to_mask", "rle_decode", "rle_counts_from_string"]
 
 
 # ------------------------------------------------------------------------------------------ per-sample records --
@@ -350,3 +351,198 @@ class ShardedLoader:
         idx = self.indices()
         for i in range(0, len(idx), self.batch_size):
             yield self.collate_fn([self.dataset[j] for j in idx[i:i + self.batch_size]])
+
+
+# --------------------------------------------------------------------------------------------------- COCO data --
+def rle_counts_from_string(s: Union[str, bytes]) -> List[int]:
+    """COCO's compressed RLE string -> run lengths.  Published algorithm of ``pycocotools`` (``maskApi.c``
+    ``rleFrString``; the reference imports pycocotools >= 2.0 un-pinned, ``train_sam3_lora_native.py:40``): each count
+    is a little-endian base-32 varint offset by ASCII 48 with a continuation bit (0x20) and sign extension (0x10),
+    and from the third count on it is stored as the difference to the count two places back."""
+    if isinstance(s, bytes):
+        s = s.decode("ascii")
+    counts: List[int] = []
+    p = 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    return counts
+
+
+def rle_decode(counts: Sequence[int], h: int, w: int) -> torch.Tensor:
+    """Run lengths (column-major, starting with a run of zeros) -> bool mask [h, w]."""
+    runs = torch.as_tensor(list(counts), dtype=torch.long)
+    values = (torch.arange(len(runs)) % 2).bool()
+    flat = torch.repeat_interleave(values, runs)
+    if flat.numel() != h * w:
+        raise ValueError(f"RLE covers {flat.numel()} pixels, expected {h * w}")
+    return flat.view(w, h).t().contiguous()
+
+
+def polygon_to_mask(xy: Sequence[float], h: int, w: int) -> torch.Tensor:
+    """One polygon ``[x0, y0, x1, y1, ...]`` (pixels) -> bool mask [h, w] with ``pycocotools``' rasterisation rule
+    (``maskApi.c`` ``rleFrPoly``): vertices are scaled by 5 and rounded, every edge is walked on that fine grid,
+    the crossings of the boundary with pixel-centre columns become the run boundaries of a column-major RLE (a
+    pixel is inside when its centre lies to the right of an odd number of crossings above it).  Restated from the
+    published algorithm; pycocotools is not installed in the build image, so this function is pinned by properties
+    (exact rectangles, symmetry, area of known shapes), not by pycocotools' output: parity unpinned."""
+    import math
+    k = len(xy) // 2
+    scale = 5.0
+    px = [int(scale * xy[2 * j] + 0.5) for j in range(k)]
+    py = [int(scale * xy[2 * j + 1] + 0.5) for j in range(k)]
+    px.append(px[0])
+    py.append(py[0])
+    us: List[int] = []
+    vs: List[int] = []
+    for j in range(k):
+        xs, xe, ys, ye = px[j], px[j + 1], py[j], py[j + 1]
+        dx, dy = abs(xe - xs), abs(ys - ye)
+        flip = (dx >= dy and xs > xe) or (dx < dy and ys > ye)
+        if flip:
+            xs, xe, ys, ye = xe, xs, ye, ys
+        if dx >= dy:
+            slope = (ye - ys) / dx if dx else 0.0
+            for d in range(dx + 1):
+                t = dx - d if flip else d
+                us.append(t + xs)
+                vs.append(int(ys + slope * t + 0.5))
+        else:
+            slope = (xe - xs) / dy
+            for d in range(dy + 1):
+                t = dy - d if flip else d
+                vs.append(t + ys)
+                us.append(int(xs + slope * t + 0.5))
+    marks: List[int] = []
+    for j in range(1, len(us)):
+        if us[j] == us[j - 1]:
+            continue
+        xd = float(us[j] if us[j] < us[j - 1] else us[j] - 1)
+        xd = (xd + 0.5) / scale - 0.5
+        if math.floor(xd) != xd or xd < 0 or xd > w - 1:
+            continue
+        yd = float(vs[j] if vs[j] < vs[j - 1] else vs[j - 1])
+        yd = (yd + 0.5) / scale - 0.5
+        yd = math.ceil(min(max(yd, 0.0), float(h)))
+        marks.append(int(xd) * h + int(yd))
+    marks.append(h * w)
+    marks.sort()
+    gaps, prev = [], 0
+    for m in marks:
+        gaps.append(m - prev)
+        prev = m
+    counts = [gaps[0]]
+    j = 1
+    while j < len(gaps):                # zero-length runs merge their neighbours
+        if gaps[j] > 0:
+            counts.append(gaps[j])
+            j += 1
+        else:
+            j += 1
+            if j < len(gaps):
+                counts[-1] += gaps[j]
+                j += 1
+    return rle_decode(counts, h, w)
+
+
+def segmentation_to_mask(segmentation, h: int, w: int) -> Optional[torch.Tensor]:
+    """COCO ``segmentation`` field: RLE dict (compressed string or plain list of counts) or list of polygons (their
+    union) -- ``train_sam3_lora_native.py:151-163``."""
+    if isinstance(segmentation, dict):
+        counts = segmentation["counts"]
+        hh, ww = segmentation["size"]
+        return rle_decode(rle_counts_from_string(counts) if isinstance(counts, (str, bytes)) else counts, hh, ww)
+    if isinstance(segmentation, list):
+        polys = segmentation if segmentation and isinstance(segmentation[0], (list, tuple)) else [segmentation]
+        mask = torch.zeros(h, w, dtype=torch.bool)
+        for poly in polys:
+            if len(poly) >= 6:
+                mask |= polygon_to_mask(poly, h, w)
+        return mask
+    return None
+
+
+class COCOSegmentDataset(torch.utils.data.Dataset):
+    """``<data_dir>/<split>/_annotations.coco.json`` + images -> :class:`Datapoint` (``train_sam3_lora_native.py:46-232``):
+    image resized to 1008 x 1008 (PIL bilinear), scaled to [-1, 1]; per annotation a normalised xyxy box (the
+    reference's format quirk) and a nearest-resized boolean mask; one query per image whose text is the (most common)
+    category name, lower-cased, or "object" without annotations."""
+
+    def __init__(self, data_dir, split: str = "train", resolution: int = 1008):
+        import json
+        from pathlib import Path
+        self.data_dir, self.split = Path(data_dir), split
+        self.split_dir = self.data_dir / split
+        ann_file = self.split_dir / "_annotations.coco.json"
+        if not ann_file.exists():
+            raise FileNotFoundError(f"COCO annotation file not found: {ann_file}")
+        with open(ann_file) as f:
+            self.coco_data = json.load(f)
+        self.images = {img["id"]: img for img in self.coco_data["images"]}
+        self.image_ids = sorted(self.images)
+        self.img_to_anns: Dict[int, List[dict]] = {}
+        for ann in self.coco_data["annotations"]:
+            self.img_to_anns.setdefault(ann["image_id"], []).append(ann)
+        self.categories = {c["id"]: c["name"] for c in self.coco_data["categories"]}
+        self.resolution = resolution
+        print(f"Loaded COCO dataset: {split} split\n  Images: {len(self.image_ids)}\n"
+              f"  Annotations: {len(self.coco_data['annotations'])}\n  Categories: {self.categories}")
+
+    def __len__(self) -> int:
+        return len(self.image_ids)
+
+    def __getitem__(self, idx: int) -> Datapoint:
+        import numpy as np
+        from collections import Counter
+        from PIL import Image as PILImage
+        img_id = self.image_ids[idx]
+        info = self.images[img_id]
+        pil = PILImage.open(self.split_dir / info["file_name"]).convert("RGB")
+        orig_w, orig_h = pil.size
+        R = self.resolution
+        pil = pil.resize((R, R), PILImage.BILINEAR)
+        image = (torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+        objects, names = [], []
+        for i, ann in enumerate(self.img_to_anns.get(img_id, [])):
+            bbox = ann.get("bbox")
+            if bbox is None:
+                continue
+            names.append(self.categories.get(ann.get("category_id", 0), "object"))
+            x, y, bw, bh = bbox
+            box = torch.tensor([x / orig_w, y / orig_h, (x + bw) / orig_w, (y + bh) / orig_h], dtype=torch.float32)
+            segment = None
+            seg = ann.get("segmentation")
+            if seg:
+                try:
+                    m = segmentation_to_mask(seg, orig_h, orig_w)
+                    if m is None:
+                        print(f"Warning: Unknown segmentation format: {type(seg)}")
+                        continue
+                    m = torch.nn.functional.interpolate(m[None, None].float(), size=(R, R), mode="nearest")
+                    segment = m.squeeze() > 0.5
+                except Exception as e:                  # a broken mask keeps the box, as in the reference
+                    print(f"Warning: Error processing mask for image {img_id}, ann {i}: {e}")
+            objects.append(Object(bbox=box, area=(box[2] - box[0]) * (box[3] - box[1]), object_id=i, segment=segment))
+        if names:
+            uniq = list(set(names))
+            text = (uniq[0] if len(uniq) == 1 else Counter(names).most_common(1)[0][0]).lower()
+        else:
+            text = "object"
+        query = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=[o.object_id for o in objects],
+                                is_exhaustive=True, query_processing_order=0,
+                                inference_metadata=InferenceMetadata(coco_image_id=img_id, original_image_id=img_id,
+                                                                     original_category_id=0,
+                                                                     original_size=(orig_h, orig_w), object_id=-1,
+                                                                     frame_index=-1))
+        return Datapoint(find_queries=[query], images=[Image(data=image, objects=objects, size=(R, R))],
+                         raw_images=[pil])

@@ -17,16 +17,21 @@ What is restated here is the part of that script that belongs to the LoRA path a
     WORLD_SIZE > 1 the A/B gradients go through :class:`sam3_lora_amd.ddp.LoRAGradReducer`, the loss is
     normalised over ranks ("global") and rank 0 writes the artefacts.
 
-What is NOT here: the SAM3 image model itself (neck, text tower, DETR, mask head) and the COCO pipeline are
-outside this library's scope (DESIGN.md "Out of scope").  They plug in through two builders,
+The model and the data come from two builders,
 
     model_builder(config, device) -> nn.Module       model(input_batch) -> per-stage outputs; model.back_convert(t)
     data_builder(config, split)   -> sized iterable  of batches ({"input": batch} or batch), or None for no split
 
-named as ``module:function`` on the command line or in ``SAM3_LORA_MODEL_BUILDER`` / ``SAM3_LORA_DATA_BUILDER``.
-A maintainer of the reference passes thin wrappers of ``build_sam3_image_model`` and ``COCOSegmentDataset`` +
-``collate_fn_api``; without builders the trainer stops with that explanation rather
-than pretending.
+which default to this library's restatement of the SAM3 image model (:func:`default_model_builder`,
+``sam3_image.build_sam3_image_model``; random seeded initialisation unless ``model.checkpoint_path`` names a
+``sam3.pt``) and of the COCO pipeline (:func:`default_data_builder`: ``COCOSegmentDataset`` + ``collate_fn_api`` over
+``training.data_dir``, or the synthetic samples of SURVEY section 8(d) when ``data_dir`` is ``synthetic[:N]``), sharded
+across ranks with DistributedSampler semantics.  ``--model-builder / --data-builder module:function`` (or
+``SAM3_LORA_MODEL_BUILDER`` / ``SAM3_LORA_DATA_BUILDER``) substitute others.
+
+Settings that exist only on this engine live under an optional ``engine:`` section of the YAML (absent = reference
+behaviour) and as command-line switches: ``bf16_frozen`` (frozen tensors in bf16, A/B fp32 masters),
+``act_checkpoint`` (keep | auto | on | off), ``match_once`` (skip the model-internal matching that the loop repeats).
 """
 from __future__ import annotations
 
@@ -48,6 +53,7 @@ from .losses import CORE_LOSS_KEY, Boxes, BinaryOneToManyMatcher, IABCEMdetr, Ma
 from .matcher import BinaryHungarianMatcherV2
 
 __all__ = ["SAM3TrainerNative", "load_config", "lora_config_from", "build_criterion", "resolve_builder",
+           "default_model_builder", "default_data_builder",
            "match_all_steps", "move_to_device", "DEFAULT_CONFIG"]
 
 DEFAULT_CONFIG = "configs/full_lora_config.yaml"       # train_sam3_lora_native.py:1051
@@ -82,14 +88,42 @@ def build_criterion(normalization: str = "local"):
     return matcher, wrapper
 
 
+def default_model_builder(config: Dict[str, Any], device) -> torch.nn.Module:
+    """``build_sam3_image_model(device, compile=False, bpe_path="sam3/assets/...", eval_mode=False)`` of :705-711, minus
+    the Hugging Face download: ``model.checkpoint_path`` (optional) names a local ``sam3.pt``, otherwise the weights are
+    a seeded random initialisation (``model.seed``, default 0)."""
+    from .sam3_image import build_sam3_image_model
+    mcfg = config.get("model") or {}
+    eng = config.get("engine") or {}
+    return build_sam3_image_model(bpe_path=mcfg.get("bpe_path"), device=str(device), eval_mode=False,
+                                  checkpoint_path=mcfg.get("checkpoint_path"), load_from_HF=False,
+                                  match_in_forward=not eng.get("match_once", False),
+                                  seed=int(mcfg.get("seed", 0)))
+
+
+def default_data_builder(config: Dict[str, Any], split: str):
+    """The reference's loaders (:799-846): ``COCOSegmentDataset(data_dir, split)`` batched by
+    ``collate_fn_api(dict_key="input", with_seg_masks=True)``, shuffled for "train" only, ``num_workers=0`` -- here
+    behind a rank-sharding loader (DistributedSampler semantics; world size 1 = the reference's DataLoader).
+    ``data_dir: synthetic[:N]`` selects N (default 64; validation N/4) synthetic samples instead of files."""
+    from .sam3_data import COCOSegmentDataset, ShardedLoader, SyntheticSegmentDataset, collate_fn_api
+    data_dir = str(config["training"]["data_dir"])
+    if data_dir.startswith("synthetic"):
+        n = int(data_dir.split(":", 1)[1]) if ":" in data_dir else 64
+        dataset = SyntheticSegmentDataset(n if split == "train" else max(n // 4, 1), split=split)
+    else:
+        dataset = COCOSegmentDataset(data_dir=data_dir, split=split)
+    return ShardedLoader(dataset, config["training"]["batch_size"],
+                         lambda samples: collate_fn_api(samples, dict_key="input", with_seg_masks=True),
+                         shuffle=(split == "train"), rank=int(os.environ.get("RANK", "0")),
+                         world=int(os.environ.get("WORLD_SIZE", "1")),
+                         seed=int((config.get("training") or {}).get("seed", 0) or 0))
+
+
 def resolve_builder(spec: Optional[str], env: str, what: str) -> Callable:
     spec = spec or os.environ.get(env)
     if not spec:
-        raise RuntimeError(
-            f"no {what} builder: this library accelerates the LoRA adapter path and ships the ViT trunk, matcher and "
-            f"losses, not the whole SAM3 image model or its COCO pipeline.  Pass --{what}-builder module:function "
-            f"(or set {env}); INTEGRATION.md section 5 shows the two wrappers for the reference's "
-            f"build_sam3_image_model and COCOSegmentDataset.")
+        return default_model_builder if what == "model" else default_data_builder
     mod, _, fn = spec.partition(":")
     if not fn:
         raise ValueError(f"{what} builder must be 'module:function', got {spec!r}")
@@ -128,9 +162,13 @@ def match_all_steps(matcher, stage_outputs: Sequence, stage_targets: Sequence[Di
 
 class SAM3TrainerNative:
     def __init__(self, config_path: str, model_builder: Optional[Callable] = None,
-                 data_builder: Optional[Callable] = None, bf16_frozen: bool = False, act_checkpoint: str = "keep"):
+                 data_builder: Optional[Callable] = None, bf16_frozen: Optional[bool] = None,
+                 act_checkpoint: Optional[str] = None):
         self.config_path = config_path
         self.config = load_config(config_path)
+        engine = self.config.get("engine") or {}
+        bf16_frozen = bool(engine.get("bf16_frozen", False)) if bf16_frozen is None else bf16_frozen
+        act_checkpoint = str(engine.get("act_checkpoint", "keep")) if act_checkpoint is None else act_checkpoint
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -261,8 +299,9 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     parser.add_argument("--config", type=str, default=DEFAULT_CONFIG, help="Path to YAML configuration file")
     parser.add_argument("--model-builder", type=str, default=None, help="module:function -> nn.Module (see trainer.py)")
     parser.add_argument("--data-builder", type=str, default=None, help="module:function -> batches for a split")
-    parser.add_argument("--bf16-frozen", action="store_true", help="keep frozen tensors in bf16 (A/B stay fp32)")
-    parser.add_argument("--act-checkpoint", choices=["keep", "auto", "on", "off"], default="keep",
+    parser.add_argument("--bf16-frozen", action="store_true", default=None,
+                        help="keep frozen tensors in bf16 (A/B stay fp32); default: engine.bf16_frozen of the YAML")
+    parser.add_argument("--act-checkpoint", choices=["keep", "auto", "on", "off"], default=None,
                         help="per-block recompute of this library's ViT trunk; auto = off when the activations fit in HBM")
     args = parser.parse_args(argv)
     trainer = SAM3TrainerNative(

@@ -598,4 +598,13 @@ def set_activation_checkpointing(model: nn.Module, mode="auto", batch: int = 8, 
         use = bool(mode)
     for v in vits:
         v.use_act_checkpoint = use
+    # the layers around the trunk (this library's SAM3 restatement) follow the same setting: their activations are
+    # a few GB at batch 8 (5184 image tokens x 256 channels x 12 layers)
+    flags = {"TransformerEncoderFusion": "use_act_checkpoint", "TransformerDecoder": "use_act_checkpoint",
+             "Transformer": "grad_checkpointing", "UniversalSegmentationHead": "act_ckpt",
+             "Sam3Image": "use_act_checkpoint_seg_head", "SequenceGeometryEncoder": "use_act_ckpt"}
+    for m in model.modules():
+        attr = flags.get(type(m).__name__)
+        if attr is not None and type(m).__module__.startswith("sam3_lora_amd.") and hasattr(m, attr):
+            setattr(m, attr, use)
     return use

@@ -24,7 +24,7 @@ def _last_json(out: str):
 @pytest.mark.gpu
 def test_single_gpu_line_has_the_contract_keys():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--blocks", "2", "--batch", "1",
-           "--kernel-iters", "2", "--no-trunk"]
+           "--kernel-iters", "2", "--model", "tiny"]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     r = _last_json(p.stdout)
@@ -36,7 +36,12 @@ def test_single_gpu_line_has_the_contract_keys():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000 and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = r["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"], cb
+    assert "whole training step" in r["metric"] and r["config"]["finite"] and r["config"]["adapted_modules"] == 8
+    assert r["adapter_path"]["value"] > 0 and r["adapter_path"]["no_recompute"]["value"] > 0
+    assert r["adapter_path"]["cpu_port"]["value"] > 0
+    assert set(r["phases_ms"]) == {"forward", "matching (host LSAP)", "loss", "backward", "exchange + AdamW"}
+    assert r["distributed"]["rank_device_ids"] == [0] and 0 < r["mfma_bound"]["frac"] < 1
 
 
 @pytest.mark.gpu
@@ -45,10 +50,12 @@ def test_two_ranks_launched_like_the_driver_complete():
     env = dict(os.environ, BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--blocks", "2", "--batch", "1", "--kernel-iters", "2", "--trunk-steps", "1", "--no-cpu-baseline"]
+           "--blocks", "2", "--batch", "1", "--kernel-iters", "2", "--model", "tiny", "--no-cpu-baseline"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     r = _last_json(p.stdout)
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
-    assert r["no_recompute"]["value"] > 0 and r["trunk_step"]["loss_finite"] and r["trunk_step_no_checkpoint"]["loss_finite"]
+    assert r["adapter_path"]["no_recompute"]["value"] > 0 and r["config"]["finite"]
+    assert r["exchange_overlap"]["world"] == 2 and r["exchange_overlap"]["step_ms_exposed"] > 0
+    assert r["distributed"]["rank_device_ids"] == [0, 0] and r["distributed"]["backend"] == "gloo"
     assert sum(1 for l in p.stdout.splitlines() if l.startswith("{")) == 1      # rank 0 only

@@ -54,8 +54,10 @@ def test_lora_section_keys_are_all_mandatory():
 def test_cli_defaults_and_builder_resolution(monkeypatch):
     assert T.DEFAULT_CONFIG == "configs/full_lora_config.yaml"
     monkeypatch.delenv("SAM3_LORA_MODEL_BUILDER", raising=False)
-    with pytest.raises(RuntimeError, match="--model-builder"):
-        T.resolve_builder(None, "SAM3_LORA_MODEL_BUILDER", "model")
+    monkeypatch.delenv("SAM3_LORA_DATA_BUILDER", raising=False)
+    # without flags the CLI builds this library's SAM3 image model and its COCO / synthetic pipeline
+    assert T.resolve_builder(None, "SAM3_LORA_MODEL_BUILDER", "model") is T.default_model_builder
+    assert T.resolve_builder(None, "SAM3_LORA_DATA_BUILDER", "data") is T.default_data_builder
     with pytest.raises(ValueError, match="module:function"):
         T.resolve_builder("json", "X", "model")
     assert T.resolve_builder("json:dumps", "X", "model") is json.dumps
