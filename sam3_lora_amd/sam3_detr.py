@@ -88,7 +88,7 @@ class MLP(nn.Module):
 
 def masked_mean(seq: torch.Tensor, pad_mask: torch.Tensor) -> torch.Tensor:
     """Mean over the valid positions of ``seq[L, B, C]`` (``pad_mask[B, L]``, True = padding); at least one counted."""
-    valid = (~pad_mask).float().permute(1, 0)[..., None]
+    valid = (~pad_mask).to(seq.dtype).permute(1, 0)[..., None]
     return (seq * valid).sum(dim=0) / valid.sum(dim=0).clamp(min=1.0)
 
 
@@ -115,7 +115,7 @@ class DotProductScoring(nn.Module):
         if self.prompt_mlp is not None:
             prompt = self.prompt_mlp(prompt)
         pooled = self.prompt_proj(masked_mean(prompt, prompt_mask))
-        scores = torch.matmul(self.hs_proj(hs), pooled.unsqueeze(-1)) * self.scale
+        scores = torch.matmul(self.hs_proj(hs), pooled.unsqueeze(-1)).float() * self.scale
         if self.clamp_logits:
             scores = scores.clamp(min=-self.clamp_max_val, max=self.clamp_max_val)
         return scores
@@ -412,7 +412,7 @@ class TransformerDecoder(nn.Module):
         from the box's two edges go through a small MLP per axis; the per-head bias of token (y, x) is the sum of its
         row and column terms.  [Q, B, 4] -> [B, heads, Q, H*W]."""
         H, W = int(feat_size[0]), int(feat_size[1])
-        xyxy = box_cxcywh_to_xyxy(reference_boxes).transpose(0, 1)              # [B, Q, 4]
+        xyxy = box_cxcywh_to_xyxy(reference_boxes.float()).transpose(0, 1)      # [B, Q, 4]
         ys, xs = self._grid(H, W, reference_boxes.device)
         dy = ys.view(1, 1, H, 1) - xyxy[:, :, None, 1::2]                       # [B, Q, H, 2] (to y0, y1)
         dx = xs.view(1, 1, W, 1) - xyxy[:, :, None, 0::2]                       # [B, Q, W, 2] (to x0, x1)
@@ -426,8 +426,9 @@ class TransformerDecoder(nn.Module):
         elif self.boxRPB == "both":
             dx, dy = torch.cat([dx, log_scale(dx)], dim=-1), torch.cat([dy, log_scale(dy)], dim=-1)
         ckpt = self.training and self.use_act_checkpoint and torch.is_grad_enabled()
-        bx = _maybe_checkpoint(ckpt, self.boxRPB_embed_x, dx)                  # [B, Q, W, heads]
-        by = _maybe_checkpoint(ckpt, self.boxRPB_embed_y, dy)                  # [B, Q, H, heads]
+        wd = self.norm.weight.dtype
+        bx = _maybe_checkpoint(ckpt, self.boxRPB_embed_x, dx.to(wd))           # [B, Q, W, heads]
+        by = _maybe_checkpoint(ckpt, self.boxRPB_embed_y, dy.to(wd))           # [B, Q, H, heads]
         bias = by.unsqueeze(3) + bx.unsqueeze(2)                               # [B, Q, H, W, heads]
         return bias.flatten(2, 3).permute(0, 3, 1, 2).contiguous()
 
@@ -448,18 +449,20 @@ class TransformerDecoder(nn.Module):
                 assert reference_boxes.shape[0] == self.num_queries
                 reference_boxes = reference_boxes.repeat(2, 1, 1)
         bs = tgt.shape[1]
+        wd = self.norm.weight.dtype          # layer dtype (bf16 layout); box arithmetic itself stays fp32 throughout
         if reference_boxes is None:
-            reference_boxes = self.reference_points.weight.unsqueeze(1).repeat(2 if apply_dac else 1, bs, 1).sigmoid()
+            reference_boxes = self.reference_points.weight.float().unsqueeze(1).repeat(2 if apply_dac else 1, bs, 1).sigmoid()
+        reference_boxes = reference_boxes.float()
         ref_per_layer = [reference_boxes]
         hs_per_layer, presence_logits = [], []
         presence_feats = None
         output = tgt
         presence = self.presence_token.weight[None].expand(1, bs, -1) if self.presence_token is not None else None
         ckpt = self.training and self.use_act_checkpoint and torch.is_grad_enabled()
-        ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[None, :]           # [1, B, levels, 4]
+        ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[None, :].float()   # [1, B, levels, 4]
         for idx, layer in enumerate(self.layers):
             ref_in = reference_boxes[:, :, None] * ratios4                        # [Q, B, levels, 4]
-            query_pos = self.ref_point_head(gen_sineembed_for_position(ref_in[:, :, 0, :], self.d_model))
+            query_pos = self.ref_point_head(gen_sineembed_for_position(ref_in[:, :, 0, :], self.d_model).to(wd))
             if self.boxRPB != "none":
                 assert spatial_shapes.shape[0] == 1, "only single scale support implemented"
                 memory_mask = self._get_rpb_matrix(reference_boxes, (spatial_shapes[0, 0], spatial_shapes[0, 1]))
@@ -472,7 +475,7 @@ class TransformerDecoder(nn.Module):
             output, presence = _maybe_checkpoint(ckpt, run, output, query_pos, memory_text, text_attention_mask, memory,
                                                  pos, memory_mask, presence)
             normed = self.norm(output)
-            delta = self.bbox_embed(normed if self.use_normed_output_consistently else output)
+            delta = self.bbox_embed(normed if self.use_normed_output_consistently else output).float()
             refined = (delta + inverse_sigmoid(reference_boxes)).sigmoid()
             reference_boxes = refined.detach()
             if idx != self.num_layers - 1:
@@ -481,7 +484,7 @@ class TransformerDecoder(nn.Module):
             if presence is not None:
                 # (the reference calls an out-of-place clamp here and drops its result, decoder.py:575-579: the logits
                 # leave unclamped, and so do these)
-                presence_logits.append(self.presence_token_head(self.presence_token_out_norm(presence)).squeeze(-1))
+                presence_logits.append(self.presence_token_head(self.presence_token_out_norm(presence)).squeeze(-1).float())
                 presence_feats = presence.clone()
         return (torch.stack(hs_per_layer), torch.stack(ref_per_layer),
                 torch.stack(presence_logits) if presence is not None else None, presence_feats)

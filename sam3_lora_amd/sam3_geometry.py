@@ -189,26 +189,31 @@ class SequenceGeometryEncoder(nn.Module):
 
     # -- one embedding per point / box: the sum of the enabled encodings plus the label embedding --------------
     def _encode_points(self, points, labels, img_nchw):
+        """Coordinates stay fp32 for the geometry; what enters a Linear takes the layer's dtype (bf16 layout)."""
         n, bs = points.shape[:2]
+        wd = self.label_embed.weight.dtype
+        points = points.float()
         parts = []
         if self.points_direct_project is not None:
-            parts.append(self.points_direct_project(points))
+            parts.append(self.points_direct_project(points.to(wd)))
         if self.points_pool_project is not None:
             grid = points.transpose(0, 1).unsqueeze(2) * 2 - 1               # [B, n, 1, 2] in [-1, 1]
-            picked = F.grid_sample(img_nchw, grid, align_corners=False)      # [B, C, n, 1]
+            picked = F.grid_sample(img_nchw, grid.to(img_nchw.dtype), align_corners=False)      # [B, C, n, 1]
             parts.append(self.points_pool_project(picked.squeeze(-1).permute(2, 0, 1)))
         if self.points_pos_enc_project is not None:
             x, y = points.unbind(-1)
             ex, ey = self.pos_enc._encode_xy(x.flatten(), y.flatten())
             code = torch.cat([ex.view(n, bs, ex.shape[-1]), ey.view(n, bs, ey.shape[-1])], -1)
-            parts.append(self.points_pos_enc_project(code))
+            parts.append(self.points_pos_enc_project(code.to(wd)))
         return self.label_embed(labels.long()) + sum(parts[1:], parts[0])
 
     def _encode_boxes(self, boxes, labels, img_nchw):
         n, bs = boxes.shape[:2]
+        wd = self.label_embed.weight.dtype
+        boxes = boxes.float()
         parts = []
         if self.boxes_direct_project is not None:
-            parts.append(self.boxes_direct_project(boxes))
+            parts.append(self.boxes_direct_project(boxes.to(wd)))
         if self.boxes_pool_project is not None:
             H, W = img_nchw.shape[-2:]
             px = box_cxcywh_to_xyxy(boxes) * torch.tensor([W, H, W, H], dtype=boxes.dtype, device=boxes.device)
@@ -217,7 +222,7 @@ class SequenceGeometryEncoder(nn.Module):
         if self.boxes_pos_enc_project is not None:
             cx, cy, w, h = boxes.unbind(-1)
             code = self.pos_enc.encode_boxes(cx.flatten(), cy.flatten(), w.flatten(), h.flatten())
-            parts.append(self.boxes_pos_enc_project(code.view(n, bs, code.shape[-1])))
+            parts.append(self.boxes_pos_enc_project(code.view(n, bs, code.shape[-1]).to(wd)))
         return self.label_embed(labels.long()) + sum(parts[1:], parts[0])
 
     def forward(self, geo_prompt: Prompt, img_feats: List[torch.Tensor], img_sizes, img_pos_embeds=None):

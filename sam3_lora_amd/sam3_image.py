@@ -214,7 +214,8 @@ class Sam3Image(nn.Module):
         aux = self.training
         out["queries"] = hs[-1][:, :n_o2o]
         logits = self.dot_prod_scoring(hs, prompt, prompt_mask)
-        boxes = (inverse_sigmoid(reference_boxes) + self.transformer.decoder.bbox_embed(hs)).sigmoid()
+        # scores and boxes leave in fp32 whatever the layer dtype: they feed the matcher's cost and the box losses
+        boxes = (inverse_sigmoid(reference_boxes.float()) + self.transformer.decoder.bbox_embed(hs).float()).sigmoid()
         boxes_xyxy = box_cxcywh_to_xyxy(boxes)
         if dec_presence_out is not None:
             _spread(out, "presence_logit_dec", dec_presence_out, aux)
@@ -274,7 +275,9 @@ class Sam3Image(nn.Module):
     def forward(self, input) -> SAM3Output:
         device = self.device
         backbone_out = {"img_batch_all_stages": input.img_batch}
-        backbone_out.update(self.backbone.forward_image(input.img_batch))
+        # images arrive fp32 from the collator; the trunk computes in its weights' dtype (bf16 in the MI355X layout)
+        images = input.img_batch.to(next(self.backbone.vision_backbone.parameters()).dtype)
+        backbone_out.update(self.backbone.forward_image(images))
         assert len(input.find_inputs) == 1, "image training has exactly one find stage"
         backbone_out.update(self.backbone.forward_text(input.find_text_batch, device=device))
         stages = SAM3Output(iter_mode=SAM3Output.IterMode.LAST_STEP_PER_STAGE)

@@ -222,7 +222,6 @@ def test_bf16_training_layout_tracks_reference_curve(gold):
     matcher, wrapper = _criterion()
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.LR, weight_decay=D.WD)
     batch = move_to_device(make_batch(), dev)
-    batch.img_batch = batch.img_batch.bfloat16()
     losses = []
     for step in range(D.STEPS):
         outputs = model(batch)
@@ -233,7 +232,10 @@ def test_bf16_training_layout_tracks_reference_curve(gold):
         loss.backward()
         opt.step()
         losses.append(loss.item())
-        assert outputs[0][0]["pred_logits"].dtype == torch.bfloat16
+        out = outputs[0][0]
+        assert out["pred_masks"].dtype == torch.bfloat16 and out["encoder_hidden_states"].dtype == torch.bfloat16
+        # scores and boxes leave in fp32 (matcher cost, box losses)
+        assert out["pred_logits"].dtype == out["pred_boxes"].dtype == out["presence_logit_dec"].dtype == torch.float32
     ref = gold["losses"]
     rel = np.abs(np.array(losses) - ref) / np.abs(ref)
     assert rel.max() <= 2e-2, f"bf16 loss curve {losses} vs reference {ref.tolist()} (rel {rel})"
