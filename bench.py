@@ -360,6 +360,11 @@ def adapter_cpu_port(rank, seconds_budget=10.0):
     import numpy as np
     from oracle import lora_oracle as O
     M, r, s = TOKENS, rank, 2.0
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(host_cores()[1])        # BLAS threads = the cores this process may use
+    except Exception:
+        pass
     rng = np.random.default_rng(0)
     x1 = rng.standard_normal((M, D_MODEL), dtype=np.float32)
     h = rng.standard_normal((M, D_HID), dtype=np.float32)
@@ -390,20 +395,33 @@ def adapter_cpu_port(rank, seconds_budget=10.0):
         n += 1
     dt = time.perf_counter() - t0
     per_img_s = dt / n * N_BLOCKS
-    return dict(value=round(1.0 / per_img_s, 4), unit="images/s", kind="port",
+    return dict(value=round(1.0 / per_img_s, 4), unit="images/s", kind="port", cores=host_cores()[1],
                 sample=f"numpy fp32 oracle of the adapter arithmetic, 1 image (M={M}), {n}/{N_BLOCKS} ViT blocks timed, "
                        f"extrapolated to 32 blocks; {dt:.1f}s of CPU work")
 
 
 def host_cores():
-    """(threads torch uses, physical cores of the host)."""
-    phys = None
+    """(threads torch uses now, cores this process may actually use): physical cores, capped by the CPU affinity mask
+    and by the cgroup CPU quota (a container that sees 256 hardware threads may be allowed 16 CPUs of them; running 128
+    OpenMP threads against that quota is several times slower than 16)."""
+    usable = None
     try:
         import psutil
-        phys = psutil.cpu_count(logical=False)
+        usable = psutil.cpu_count(logical=False)
     except Exception:
         pass
-    return torch.get_num_threads(), int(phys or os.cpu_count() or 1)
+    usable = int(usable or os.cpu_count() or 1)
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = min(usable, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return torch.get_num_threads(), usable
 
 
 def model_setup(kind):
@@ -459,15 +477,23 @@ def cpu_baseline(kind="sam3", seconds_budget=45.0):
         trunk.blocks, trunk.full_attn_ids = torch.nn.ModuleList(all_blocks), all_global
         return dt, loss.item()
 
-    # T(w windowed, g global blocks) = R + w Tw + g Tg from three short probes
-    w0, g0 = windowed[:3], all_global[:1]
-    t_11, _ = one_step(w0[:1] + g0)
-    t_31, _ = one_step(w0[:3] + g0)
-    t_20, _ = one_step(w0[:2])
-    Tw = max((t_31 - t_11) / 2, 1e-4)
-    R = max(t_20 - 2 * Tw, 0.0)
-    Tg = max(t_11 - R - Tw, Tw)
-    predicted = R + len(windowed) * Tw + len(all_global) * Tg
+    # bounded sample: ONE step of the whole model with the trunk cut to (1 windowed + 1 global) block, plus the cost
+    # of one more windowed / global block measured on the block alone (forward, recompute, backward -- the
+    # per-block activation checkpointing of the reference)
+    from torch.utils.checkpoint import checkpoint as _ckpt
+    w0, g0 = windowed[0], all_global[0]
+    t_11, _ = one_step([w0, g0])
+    side = res // SAM3_CONFIG["vit"]["patch_size"]
+    probe_x = torch.randn(1, side, side, SAM3_CONFIG["vit"]["embed_dim"])
+
+    def block_alone(i):
+        x = probe_x.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        _ckpt(all_blocks[i], x, use_reentrant=False).sum().backward()
+        return time.perf_counter() - t0
+    Tw, Tg = block_alone(w0), block_alone(g0)
+    R = t_11
+    predicted = t_11 + (len(windowed) - 1) * Tw + (len(all_global) - 1) * Tg
     if predicted <= seconds_budget:
         t_full, loss = one_step(None)
         sample = (f"whole CPU training step timed once: 1 synthetic image @ {res}^2 (configs[0] has 2), "
@@ -476,10 +502,10 @@ def cpu_baseline(kind="sam3", seconds_budget=45.0):
                   f"recompute) + AdamW, fp32; loss {loss:.2f}; {t_full:.1f}s of CPU work (predicted {predicted:.1f}s)")
     else:
         t_full = predicted
-        sample = (f"extrapolated from three probe steps of the whole model with the trunk cut to (1 windowed + 1 global), "
-                  f"(3 + 1) and (2 + 0) blocks: {t_11:.1f}s / {t_31:.1f}s / {t_20:.1f}s for 1 synthetic image @ {res}^2 -> "
-                  f"{Tw:.2f}s per windowed block, {Tg:.2f}s per global block, {R:.1f}s for everything else -> "
-                  f"{predicted:.1f}s for the {len(all_blocks)}-block step (over the {seconds_budget:.0f}s budget, not run whole); "
+        sample = (f"extrapolated: one CPU training step of the whole model with the trunk cut to 1 windowed + 1 global block "
+                  f"took {t_11:.1f}s for 1 synthetic image @ {res}^2; one more windowed / global block (forward + recompute + "
+                  f"backward, timed alone) costs {Tw:.2f}s / {Tg:.2f}s -> {predicted:.1f}s for the {len(all_blocks)}-block step "
+                  f"(over the {seconds_budget:.0f}s budget, not run whole); "
                   f"{n_adapted} rank-4 adapters in reference form, fp32, fwd + 2x matching + loss + bwd (recompute) + AdamW")
     torch.set_num_threads(threads)
     return dict(value=round(1.0 / t_full, 5), unit="images/s", cores=phys, kind="port", s_per_step=round(t_full, 2),
@@ -661,7 +687,7 @@ def main():
                                           "twice (model + loop, as the reference)" if args.match_twice else "once"),
                            "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                            "grad_allreduce_bytes": full.reducer.nbytes, "finite": finite,
-                           "loss": round(float(full.last_loss), 4), "adapted_modules": full.n_adapted,
+                           "loss": round(full.last_loss.item(), 4), "adapted_modules": full.n_adapted,
                            "trainable_parameters": sum(p.numel() for p in full.params)},
                 # ~18 TFLOP per image and step -> ~140 images/s per GPU at the 2.5 PFLOP/s dense
                 # bf16 MFMA peak; the whole step is MFMA/attention-bound, the adapter kernels HBM-bound (roofline below)

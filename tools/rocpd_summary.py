@@ -42,6 +42,21 @@ def stats(db):
         print(f"{k:60s} {gx:6d} {gy:6d} {vg:5d} {lds:6d} {len(d):6d} {sum(d) / len(d) / 1e3:10.2f} {min(d) / 1e3:10.2f} {max(d) / 1e3:10.2f}")
 
 
+def stats_all(db, top=45):
+    """Every kernel of a whole-model step (library kernels included): top `top` by total time."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, duration from kernels").fetchall()
+    tot = sum(r[1] for r in rows)
+    by_k = {}
+    for name, dur in rows:
+        by_k.setdefault(short(name, 110), []).append(dur)
+    print("# rocprofv3 --kernel-trace --stats (rocpd) -- durations in microseconds")
+    print(f"# total kernel time {tot / 1e3:.1f} us over {len(rows)} dispatches, {len(by_k)} distinct kernels\n")
+    print(f"{'kernel':112s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
+    for k, d in sorted(by_k.items(), key=lambda kv: -sum(kv[1]))[:int(top)]:
+        print(f"{k:112s} {len(d):6d} {sum(d) / 1e3:12.1f} {sum(d) / len(d) / 1e3:10.2f} {100 * sum(d) / tot:6.2f}")
+
+
 def pmc(db):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, grid_size_x, grid_size_y, workgroup_size_x, counter_name, value "
@@ -84,4 +99,4 @@ def traffic(db_fetch, db_write):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "stats_all": stats_all, "pmc": pmc, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
