@@ -59,6 +59,7 @@ def parse():
                     help="activation checkpointing of the whole-model step (auto: off when the activations fit in HBM)")
     ap.add_argument("--match-twice", action="store_true", help="also match inside the model's forward, as the reference does")
     ap.add_argument("--no-overlap", action="store_true", help="skip the exchange-overlap measurement (N > 1)")
+    ap.add_argument("--full-only", action="store_true", help="only the whole-model step (profiling runs)")
     ap.add_argument("--model", choices=["sam3", "tiny"], default="sam3",
                     help="tiny: the parity fixture's widths at 112^2 (contract tests only; the line says so)")
     return ap.parse_args()
@@ -112,8 +113,8 @@ class Workload:
             for b in range(self.blocks):                       # forward
                 k = b & 1
                 if prepack:     # A/B changed at the optimizer step: pack once, use for fwd, recompute and bwd
-                    self.P1[b] = pack_operands(self.A1[b], self.B1[b], L, out=self.P1[b])
-                    self.P2[b] = pack_operands(self.A2[b], self.B2[b], L, out=self.P2[b])
+                    self.P1[b] = pack_operands(self.A1[b], self.B1[b], L, out=self.P1[b], dtype=self.x1[0].dtype)
+                    self.P2[b] = pack_operands(self.A2[b], self.B2[b], L, out=self.P2[b], dtype=self.x1[0].dtype)
                 p1, p2 = (self.P1[b], self.P2[b]) if prepack else (None, None)
                 t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=not recompute, drop_p=dp,
                                seed=2 * b, packed=p1)
@@ -235,7 +236,7 @@ def op_table(w, iters):
     x1, h, y2, g2, gh, g1 = w.x1[0], w.h[0], w.y2[0], w.g2[0], w.gh[0], w.g1[0]
     A1, B1, A2, B2 = w.A1[0], w.B1[0], w.A2[0], w.B2[0]
     gA1, gB1, gA2, gB2 = (torch.zeros_like(p) for p in (A1, B1, A2, B2))
-    p1, p2 = pack_operands(A1, B1, 0), pack_operands(A2, B2, 0)     # as the step calls them: operands pre-packed
+    p1, p2 = pack_operands(A1, B1, 0, dtype=x1.dtype), pack_operands(A2, B2, 0, dtype=x1.dtype)     # as the step calls them: operands pre-packed
     t1 = lora_fwd_(x1, A1, B1, h, s, 0, save_t=True, packed=p1)
     t2 = lora_fwd_(h, A2, B2, y2, s, 0, save_t=True, packed=p2)
     fwd1 = lambda: lora_fwd_(x1, A1, B1, h, s, 0, packed=p1)
@@ -557,6 +558,8 @@ class FullStep:
             self.ckpt = V.set_activation_checkpointing(self.model, mode, batch=batch)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.reducer = LoRAGradReducer(self.params, bucket_bytes=8 << 20)
+        from sam3_lora_amd.functional import enable_direct_grad_accumulation
+        enable_direct_grad_accumulation(True, notify=self.reducer.notify)    # kernels add straight into the flat buffer
         self.opt = torch.optim.AdamW(self.params, lr=5e-5, weight_decay=0.01)
         self.matcher, self.wrapper = build_criterion("global" if world > 1 else "local")
         ds = SyntheticSegmentDataset(2 * batch * world, resolution=res, source=src)
@@ -707,6 +710,13 @@ def main():
                 out["exchange_overlap"] = ov
         del full
         torch.cuda.empty_cache()
+        if args.full_only:
+            if rank == 0:
+                print(json.dumps(out))
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
     # ------------------------------------------------------------------ the adapter path on its own (HBM roofline)
     w = Workload(dev, args.batch, args.rank, args.blocks, seed=1234 + rank, dropout=args.dropout, act_dtype=act_dtype)
     a_steps = args.steps if args.adapter_only else max(3, min(args.steps, 6))

@@ -28,9 +28,14 @@
  *     module they come from:
  *         SAM3_LORA_LAYOUT_ROOT    (0): A[in, r],  B[r, out]   lora_layers.py:38-39
  *         SAM3_LORA_LAYOUT_PACKAGE (1): A[r, in],  B[out, r]   sam3_lora/lora/lora_layer.py:47-48
- *     1 <= r <= 32.
- *   - activation dtype (x, y, gy, gx): SAM3_LORA_BF16 or SAM3_LORA_F32.  All contractions run
- *     on bf16 MFMA with fp32 accumulation; gA/gB are accumulated and returned in fp32.
+ *     1 <= r <= SAM3_LORA_MAX_RANK; ranks above 32 run as consecutive groups of 32 rank indices (one more pass over
+ *     the activations per group -- the reference has no rank limit, configs/full_lora_config.yaml:12).
+ *   - activation dtype (x, y, gy, gx):
+ *         SAM3_LORA_BF16  bf16 operands on the bf16 MFMAs, fp32 accumulation; the rank-r intermediates t / gt are
+ *                         rounded to bf16 once;
+ *         SAM3_LORA_F32   exact fp32: fp32 operands on v_mfma_f32_16x16x4_f32, fp32 intermediates -- the arithmetic
+ *                         of the reference's un-autocast training (train_sam3_lora_native.py).
+ *     gA/gB are accumulated and returned in fp32 either way.
  */
 #ifndef SAM3_LORA_AMD_H
 #define SAM3_LORA_AMD_H
@@ -42,7 +47,8 @@
 extern "C" {
 #endif
 
-#define SAM3_LORA_ABI_VERSION 1
+#define SAM3_LORA_ABI_VERSION 2
+#define SAM3_LORA_MAX_RANK 1024
 
 #define SAM3_LORA_LAYOUT_ROOT 0
 #define SAM3_LORA_LAYOUT_PACKAGE 1
@@ -65,22 +71,23 @@ int sam3_lora_abi_version(void);
 /* Thread-local description of the last error returned to the calling thread ("" if none). */
 const char* sam3_lora_last_error(void);
 
-/* Bytes of the `tT` tensor (bf16, [r_pad, M_pad]) that sam3_lora_fwd can emit for the backward. */
-size_t sam3_lora_saved_t_bytes(int64_t M, int rank);
+/* Bytes of the `tT` tensor that sam3_lora_fwd can emit for the backward: per rank group t = drop(x) A_c as bf16
+ * [r_pad, M_pad] in MFMA fragment order (SAM3_LORA_BF16) or fp32 [M_pad, r_pad] row-major (SAM3_LORA_F32). */
+size_t sam3_lora_saved_t_bytes(int64_t M, int rank, int dtype);
 
 size_t sam3_lora_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype);
 size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype);
 
 /*
- * Operand images.  Every fwd/bwd call first converts the fp32 masters into the bf16 MFMA operand images it needs
- * (one small launch).  A and B only change at the optimizer step, while a training step calls fwd, the
+ * Operand images.  Every fwd/bwd call first converts the fp32 masters into the MFMA operand images it needs (bf16 for
+ * SAM3_LORA_BF16 activations, zero-padded fp32 for SAM3_LORA_F32; one small launch).  A and B only change at the optimizer step, while a training step calls fwd, the
  * activation-checkpoint recompute fwd and bwd on the same values: sam3_lora_pack writes all images once into a
  * caller-held blob (sam3_lora_packed_bytes, 256-byte aligned) that the three calls then take through
  * `layout | SAM3_LORA_PREPACKED`.  The caller re-packs after A or B changed; results are bit-identical either way.
  */
-size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank);
+size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank, int dtype);
 int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, int out_features, int rank,
-                   int layout, void* stream);
+                   int layout, int dtype, void* stream);
 
 /*
  * Forward of the LoRA branch, fused with the residual add into the base output:
@@ -91,8 +98,8 @@ int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, 
  * and        sam3_lora/lora/lora_layer.py:62-79 (LoRALayer.forward, which materialises B@A)
  *            + the add in :142-158 (LinearWithLoRA.forward).
  * On entry y_inout holds the frozen layer's output W x + b (computed by the caller, e.g.
- * hipBLASLt through PyTorch-ROCm).  If `tT_out` is non-NULL it receives t = drop(x) @ A_c as
- * bf16 [r_pad, M_pad] (sam3_lora_saved_t_bytes) for sam3_lora_bwd; pass NULL in inference.
+ * hipBLASLt through PyTorch-ROCm).  If `tT_out` is non-NULL it receives t = drop(x) @ A_c
+ * (sam3_lora_saved_t_bytes) for sam3_lora_bwd; pass NULL in inference.
  *
  * drop_p > 0 selects training-mode dropout on x with a counter-based generator keyed by
  * (seed, offset, element index); the same triple must be passed to sam3_lora_bwd.

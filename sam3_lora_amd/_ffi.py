@@ -18,7 +18,8 @@ LAYOUT_ROOT = 0
 LAYOUT_PACKAGE = 1
 DT_BF16 = 0
 DT_F32 = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
+MAX_RANK = 1024
 
 EXPORTS = (
     "sam3_lora_abi_version", "sam3_lora_last_error", "sam3_lora_saved_t_bytes",
@@ -49,14 +50,14 @@ def _declare(lib):
     lib.sam3_lora_last_error.restype = c_char_p
     lib.sam3_lora_last_error.argtypes = []
     lib.sam3_lora_saved_t_bytes.restype = c_size_t
-    lib.sam3_lora_saved_t_bytes.argtypes = [c_int64, c_int]
+    lib.sam3_lora_saved_t_bytes.argtypes = [c_int64, c_int, c_int]
     for f in (lib.sam3_lora_fwd_workspace_bytes, lib.sam3_lora_bwd_workspace_bytes):
         f.restype = c_size_t
         f.argtypes = [c_int64, c_int, c_int, c_int, c_int]
     lib.sam3_lora_packed_bytes.restype = c_size_t
-    lib.sam3_lora_packed_bytes.argtypes = [c_int, c_int, c_int]
+    lib.sam3_lora_packed_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.sam3_lora_pack.restype = c_int
-    lib.sam3_lora_pack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.sam3_lora_pack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.sam3_lora_fwd.restype = c_int
     lib.sam3_lora_fwd.argtypes = [
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,      # x, A, B, y_inout, tT_out

@@ -25,7 +25,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SRCS + [os.path.join(INCLUDE, "sam3_lora_amd.h"), os.path.join(INCLUDE, "sam3_vit_amd.h")]
+    deps = SRCS + [os.path.join(INCLUDE, "sam3_lora_amd.h"), os.path.join(INCLUDE, "sam3_vit_amd.h"),
+                   os.path.join(PKG_DIR, "csrc", "lora_f32_kernels.inc")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -135,10 +135,11 @@ __device__ __forceinline__ uint4 drop8(uint4 v, unsigned long long e8, const Dro
 // ------------------------------------------------------------------------------------------
 struct PackJob {
     const float* src;
-    bf16_t* dst;
+    void* dst;            // bf16 image, or fp32 image when f32 != 0 (exact-fp32 path)
     int I, J, Iv, Jv;     // dst is I x J, valid region Iv x Jv (the rest is zero-filled)
     long long si, sj;
     int ldd;              // row pitch of dst in elements (0 => J); > J when packing into a slice of a wider buffer
+    int f32;
 };
 
 struct PackJobs {
@@ -151,8 +152,13 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
     if (idx >= (long long)jb.I * jb.J) return;
     const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
     const float v = (i < jb.Iv && j < jb.Jv) ? jb.src[i * jb.si + j * jb.sj] : 0.f;
+    const long long o = (long long)i * (jb.ldd ? jb.ldd : jb.J) + j;
+    if (jb.f32) {
+        reinterpret_cast<float*>(jb.dst)[o] = v;
+        return;
+    }
     bf16x2 t = {(__bf16)v, (__bf16)0.f};
-    jb.dst[(long long)i * (jb.ldd ? jb.ldd : jb.J) + j] = (bf16_t)(__builtin_bit_cast(unsigned, t) & 0xffffu);
+    reinterpret_cast<bf16_t*>(jb.dst)[o] = (bf16_t)(__builtin_bit_cast(unsigned, t) & 0xffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -929,6 +935,8 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ W, cons
     Wm[idx] = W[idx] + scaling * s;
 }
 
+#include "lora_f32_kernels.inc"
+
 // ==========================================================================================
 // host side: C-ABI
 // ==========================================================================================
@@ -995,7 +1003,8 @@ int check_common(long long M, int in_f, int out_f, int rank, int layout, int dty
     if (M <= 0) return fail(SAM3_LORA_EINVAL, "M must be positive (got %lld)", M);
     if (in_f <= 0 || out_f <= 0 || (in_f % 8) || (out_f % 8))
         return fail(SAM3_LORA_EINVAL, "in_features/out_features must be positive multiples of 8 (got %d, %d)", in_f, out_f);
-    if (rank < 1 || rank > 32) return fail(SAM3_LORA_EINVAL, "rank must be in [1, 32] (got %d)", rank);
+    if (rank < 1 || rank > SAM3_LORA_MAX_RANK)
+        return fail(SAM3_LORA_EINVAL, "rank must be in [1, %d] (got %d)", SAM3_LORA_MAX_RANK, rank);
     if (layout != SAM3_LORA_LAYOUT_ROOT && layout != SAM3_LORA_LAYOUT_PACKAGE)
         return fail(SAM3_LORA_EINVAL, "unknown layout %d", layout);
     if (dtype != SAM3_LORA_BF16 && dtype != SAM3_LORA_F32) return fail(SAM3_LORA_EINVAL, "unknown dtype %d", dtype);
@@ -1100,19 +1109,37 @@ void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
 }
 
 // caller-held operand images (sam3_lora_pack): [ W1 = A_c^T | W2t = B_c^T | W1b = B_c | W2tb = A_c ], bf16
+// Ranks above 32 run as consecutive groups of <= 32 rank indices (the kernels hold one or two 16-wide rank tiles):
+// y += s (x A_g) B_g per group, and the four gradient products per group -- A_c / B_c slices are addressed through
+// the strides of the full tensors, so no copy is made.
+inline int n_groups(int rank) { return (rank + 31) / 32; }
+inline int group_rank(int rank, int g) { return rank - 32 * g < 32 ? rank - 32 * g : 32; }
+
+// caller-held operand images (sam3_lora_pack) of ONE group: [ W1 = A_c^T | W2t = B_c^T | W1b = B_c | W2tb = A_c ],
+// bf16 for SAM3_LORA_BF16 activations, fp32 for SAM3_LORA_F32 (exact path); groups follow each other in the blob
 struct PackedLayout {
     size_t w1, w2t, w1b, w2tb, total;
 };
-PackedLayout packed_layout(int in_f, int out_f, int rank) {
+PackedLayout packed_layout(int in_f, int out_f, int rank, int dtype) {
     const int RP = rpad(rank);
+    const size_t e = dtype == SAM3_LORA_F32 ? 4 : 2;
     PackedLayout p;
     size_t off = 0;
-    p.w1 = off; off += al256((size_t)RP * round_up(in_f, 128) * 2);
-    p.w2t = off; off += al256((size_t)out_f * RP * 2);
-    p.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * 2);
-    p.w2tb = off; off += al256((size_t)in_f * RP * 2);
+    p.w1 = off; off += al256((size_t)RP * round_up(in_f, 128) * e);
+    p.w2t = off; off += al256((size_t)out_f * RP * e);
+    p.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * e);
+    p.w2tb = off; off += al256((size_t)in_f * RP * e);
     p.total = off;
     return p;
+}
+size_t packed_total(int in_f, int out_f, int rank, int dtype) {
+    size_t n = 0;
+    for (int g = 0; g < n_groups(rank); ++g) n += packed_layout(in_f, out_f, group_rank(rank, g), dtype).total;
+    return n;
+}
+// bytes of the saved t of one group: bf16 fragment-major [r_pad, M_pad], or fp32 row-major [M_pad, r_pad]
+inline size_t saved_t_group_bytes(long long M, int rank, int dtype) {
+    return (size_t)rpad(rank) * (size_t)round_up(M, 64) * (dtype == SAM3_LORA_F32 ? 4 : 2);
 }
 
 template <typename XT>
@@ -1220,48 +1247,95 @@ void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part,
                        GT, GTT, Mp);
 }
 
+// ---- exact-fp32 launchers (lora_f32_kernels.inc) ----------------------------------------------------
+void launch32_t1(const void* X, long long ldx, const float* W1, float* T, long long M, long long Mp, int K, int RT,
+                 hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
+    dim3 grid((unsigned)(Mp / 64));
+    ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
+#define L(RTV, DV) hipLaunchKernelGGL((k32_t1<RTV, DV>), grid, dim3(256), 0, st, (const float*)X, ldx, W1, T, M, Mp, K, dk)
+    if (RT == 1) { if (dk.thr) L(1, true); else L(1, false); }
+    else { if (dk.thr) L(2, true); else L(2, false); }
+#undef L
+}
+void launch32_t2(void* Y, long long ldy, const float* T, const float* W2t, long long M, int N, float scale, int RT,
+                 hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0) {
+    const long long ntiles = (M + 15) / 16;
+    const int nchunks = (N + 127) / 128;
+    long long tiles_per_wg = 16;
+    while (tiles_per_wg > 4 && nchunks * ((ntiles + tiles_per_wg - 1) / tiles_per_wg) < 1024) tiles_per_wg -= 4;
+    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
+    ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
+#define L(RTV, DV, AV) \
+    hipLaunchKernelGGL((k32_t2<RTV, DV, AV>), grid, dim3(256), 0, st, (float*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
+                       (float*)aux, ldaux)
+#define LR(RTV)                                                                  \
+    do {                                                                         \
+        if (act == 1) L(RTV, false, 1);                                          \
+        else if (act == 2) { if (dk.thr) L(RTV, true, 2); else L(RTV, false, 2); } \
+        else { if (dk.thr) L(RTV, true, 0); else L(RTV, false, 0); }             \
+    } while (0)
+    if (RT == 1) LR(1); else LR(2);
+#undef LR
+#undef L
+}
+void launch32_t3(const void* X, long long ldx, const float* T, float* part, long long M, long long Mp, int N,
+                 const T3Plan& p, int RT, unsigned stage_bit, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
+    dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
+    ProfScope ps(stage_bit, N, st);
+#define L(RTV, DV) hipLaunchKernelGGL((k32_t3<RTV, DV>), grid, dim3(256), 0, st, (const float*)X, ldx, T, part, M, Mp, N, p.rows_per_wg, dk)
+    if (RT == 1) { if (dk.thr) L(1, true); else L(1, false); }
+    else { if (dk.thr) L(2, true); else L(2, false); }
+#undef L
+}
+
+// ---- workspace plans of ONE rank group ---------------------------------------------------------------
 struct FwdWs {
     size_t w1, w2t, t, tt, t1p, total;
 };
-// fp32 split-K partials of k_t1 (r <= 16 and fewer than 512 row tiles): up to 8 splits x Mp x 16
-inline size_t t1_part_bytes(long long Mp, int RP) { return (RP == 16 && Mp / 64 < 512) ? (size_t)8 * Mp * 64 : 0; }
-FwdWs fwd_ws(long long M, int in_f, int out_f, int rank) {
+// fp32 split-K partials of k_t1 (bf16 path, r <= 16 and fewer than 512 row tiles): up to 8 splits x Mp x 16
+inline size_t t1_part_bytes(long long Mp, int RP, int dtype) {
+    return (dtype != SAM3_LORA_F32 && RP == 16 && Mp / 64 < 512) ? (size_t)8 * Mp * 64 : 0;
+}
+FwdWs fwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     const int RP = rpad(rank);
     const long long Mp = round_up(M, 64);
+    const size_t e = dtype == SAM3_LORA_F32 ? 4 : 2;
     FwdWs w;
     size_t off = 0;
-    w.w1 = off; off += al256((size_t)RP * round_up(in_f, 128) * 2);
-    w.w2t = off; off += al256((size_t)out_f * RP * 2);
-    w.t = off; off += al256((size_t)Mp * RP * 2);
-    w.tt = off; off += al256((size_t)RP * Mp * 2);
-    w.t1p = off; off += al256(t1_part_bytes(Mp, RP));
+    w.w1 = off; off += al256((size_t)RP * round_up(in_f, 128) * e);
+    w.w2t = off; off += al256((size_t)out_f * RP * e);
+    w.t = off; off += al256((size_t)Mp * RP * e);
+    w.tt = off; off += al256((size_t)RP * Mp * e);
+    w.t1p = off; off += al256(t1_part_bytes(Mp, RP, dtype));
     w.total = off;
     return w;
 }
 
 struct BwdWs {
     size_t w1b, w2tb, w1a, gt, gtt, t, tt, pb, pa, gtp, total;
-    T3Plan pB, pA, pE;      // pE: the one-pass (k_t3e) plan over gy, r <= 16
+    T3Plan pB, pA, pE;      // pE: the one-pass (k_t3e) plan over gy, bf16 path with r <= 16
 };
-BwdWs bwd_ws(long long M, int in_f, int out_f, int rank) {
+BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     const int RP = rpad(rank);
     const long long Mp = round_up(M, 64);
+    const size_t e = dtype == SAM3_LORA_F32 ? 4 : 2;
     BwdWs w;
     w.pB = plan_t3(Mp, out_f, RP / 16);
     w.pA = plan_t3(Mp, in_f, RP / 16);
     w.pE = plan_t3e(Mp, out_f);
     size_t off = 0;
-    w.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * 2);
-    w.w2tb = off; off += al256((size_t)in_f * RP * 2);
-    w.w1a = off; off += al256((size_t)RP * round_up(in_f, 128) * 2);
-    w.gt = off; off += al256((size_t)Mp * RP * 2);
-    w.gtt = off; off += al256((size_t)RP * Mp * 2);
-    w.t = off; off += al256((size_t)Mp * RP * 2);
-    w.tt = off; off += al256((size_t)RP * Mp * 2);
+    w.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * e);
+    w.w2tb = off; off += al256((size_t)in_f * RP * e);
+    w.w1a = off; off += al256((size_t)RP * round_up(in_f, 128) * e);
+    w.gt = off; off += al256((size_t)Mp * RP * e);
+    w.gtt = off; off += al256((size_t)RP * Mp * e);
+    w.t = off; off += al256((size_t)Mp * RP * e);
+    w.tt = off; off += al256((size_t)RP * Mp * e);
     w.pb = off; off += al256((size_t)(w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR) * RP * out_f * 4);
     w.pa = off; off += al256((size_t)w.pA.NR * RP * in_f * 4);
-    {   // gt partials of k_t3e (r <= 16); the same region serves k_t1's split-K partials at small M
-        const size_t a = RP == 16 ? (size_t)w.pE.nchunks * Mp * 16 * 4 : 0, b = t1_part_bytes(Mp, RP);
+    {   // gt partials of k_t3e (bf16, r <= 16); the same region serves k_t1's split-K partials at small M
+        const size_t a = (dtype != SAM3_LORA_F32 && RP == 16) ? (size_t)w.pE.nchunks * Mp * 16 * 4 : 0;
+        const size_t b = t1_part_bytes(Mp, RP, dtype);
         w.gtp = off; off += al256(a > b ? a : b);
     }
     w.total = off;
@@ -1317,44 +1391,89 @@ int sam3_lora_prof_stop(float* us_out, int* stage_out, int* dim_out, int capacit
 
 const char* sam3_lora_last_error(void) { return g_err; }
 
-size_t sam3_lora_saved_t_bytes(int64_t M, int rank) {
-    if (M <= 0 || rank < 1 || rank > 32) return 0;
-    return (size_t)rpad(rank) * (size_t)round_up(M, 64) * 2;
+size_t sam3_lora_saved_t_bytes(int64_t M, int rank, int dtype) {
+    if (M <= 0 || rank < 1 || rank > SAM3_LORA_MAX_RANK) return 0;
+    size_t n = 0;
+    for (int g = 0; g < n_groups(rank); ++g) n += saved_t_group_bytes(M, group_rank(rank, g), dtype);
+    return n;
 }
 
 size_t sam3_lora_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
     if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
-    return fwd_ws(M, in_features, out_features, rank).total;
+    return fwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
 }
 
 size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
     if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
-    return bwd_ws(M, in_features, out_features, rank).total;
+    return bwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
 }
 
-size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank) {
-    if (check_common(1, in_features, out_features, rank, 0, SAM3_LORA_BF16)) return 0;
-    return packed_layout(in_features, out_features, rank).total;
+size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank, int dtype) {
+    if (check_common(1, in_features, out_features, rank, 0, dtype)) return 0;
+    return packed_total(in_features, out_features, rank, dtype);
 }
 
 int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, int out_features, int rank, int layout,
-                   void* stream) {
+                   int dtype, void* stream) {
     g_err[0] = 0;
     int rc;
-    if ((rc = check_common(1, in_features, out_features, rank, layout, SAM3_LORA_BF16))) return rc;
+    if ((rc = check_common(1, in_features, out_features, rank, layout, dtype))) return rc;
     if (!A || !B || !packed) return fail(SAM3_LORA_EINVAL, "NULL pointer");
     if (((uintptr_t)packed & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
-    const int RP = rpad(rank);
-    const PackedLayout pl = packed_layout(in_features, out_features, rank);
     const Strides s = strides_of(layout, in_features, out_features, rank);
+    const int f32 = dtype == SAM3_LORA_F32;
     char* p = (char*)packed;
-    const PackJob jobs[4] = {
-        {(const float*)A, (bf16_t*)(p + pl.w1), RP, in_features, rank, in_features, s.a_sr, s.a_si, 0},
-        {(const float*)B, (bf16_t*)(p + pl.w2t), out_features, RP, out_features, rank, s.b_so, s.b_sr, 0},
-        {(const float*)B, (bf16_t*)(p + pl.w1b), RP, out_features, rank, out_features, s.b_sr, s.b_so, 0},
-        {(const float*)A, (bf16_t*)(p + pl.w2tb), in_features, RP, in_features, rank, s.a_si, s.a_sr, 0}};
-    launch_pack(jobs, 4, (hipStream_t)stream);
+    for (int g = 0; g < n_groups(rank); ++g) {
+        const int rg = group_rank(rank, g), RP = rpad(rg);
+        const PackedLayout pl = packed_layout(in_features, out_features, rg, dtype);
+        const float* Ag = (const float*)A + 32LL * g * s.a_sr;
+        const float* Bg = (const float*)B + 32LL * g * s.b_sr;
+        const PackJob jobs[4] = {
+            {Ag, p + pl.w1, RP, in_features, rg, in_features, s.a_sr, s.a_si, 0, f32},
+            {Bg, p + pl.w2t, out_features, RP, out_features, rg, s.b_so, s.b_sr, 0, f32},
+            {Bg, p + pl.w1b, RP, out_features, rg, out_features, s.b_sr, s.b_so, 0, f32},
+            {Ag, p + pl.w2tb, in_features, RP, in_features, rg, s.a_si, s.a_sr, 0, f32}};
+        launch_pack(jobs, 4, (hipStream_t)stream);
+        p += pl.total;
+    }
     return launch_ok("sam3_lora_pack");
+}
+
+// forward of one rank group.  A_g / B_g: the group's slice of the fp32 masters (strides `s` of the full tensors), or the
+// group's operand blob when `pre`.
+static void fwd_group(const void* x, const void* A_g, const void* B_g, bool pre, void* y_inout, void* tT_out, long long M,
+                      int in_features, int out_features, int rank, long long ldx, long long ldy, const Strides& s,
+                      float scale, const DropKey& dk, int dtype, char* ws, hipStream_t st, int act, void* act_out,
+                      long long ldact) {
+    const int RP = rpad(rank), RT = RP / 16;
+    const long long Mp = round_up(M, 64);
+    const bool f32 = dtype == SAM3_LORA_F32;
+    const FwdWs w = fwd_ws(M, in_features, out_features, rank, dtype);
+    const PackedLayout pl = packed_layout(in_features, out_features, rank, dtype);
+    void* W1 = pre ? (void*)((char*)A_g + pl.w1) : (void*)(ws + w.w1);
+    void* W2t = pre ? (void*)((char*)A_g + pl.w2t) : (void*)(ws + w.w2t);
+    // W1[RP][in] = A_c^T ; W2t[out][RP] = B_c^T
+    if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
+        PackJob ja{(const float*)A_g, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0, f32};
+        PackJob jb{(const float*)B_g, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0, f32};
+        launch_pack(ja, jb, st);
+    }
+    if (f32) {
+        // exact-fp32 path: t kept in fp32, row-major; the saved tensor for the backward IS that array
+        float* T = tT_out ? (float*)tT_out : (float*)(ws + w.t);
+        if (stage_on(SAM3_LORA_STAGE_T1)) launch32_t1(x, ldx, (const float*)W1, T, M, Mp, in_features, RT, st, dk);
+        if (stage_on(SAM3_LORA_STAGE_T2))
+            launch32_t2(y_inout, ldy, T, (const float*)W2t, M, out_features, scale, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
+                        act_out, ldact);
+        return;
+    }
+    bf16_t* T = (bf16_t*)(ws + w.t);
+    bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
+    if (stage_on(SAM3_LORA_STAGE_T1))
+        launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1, T, TT, M, Mp, in_features, RT, st, dk, RT == 1 ? (float*)(ws + w.t1p) : nullptr);
+    if (stage_on(SAM3_LORA_STAGE_T2))
+        launch_t2<bf16_t>(y_inout, ldy, T, (const bf16_t*)W2t, M, out_features, scale, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
+                          act_out, ldact);
 }
 
 static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
@@ -1372,41 +1491,29 @@ static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, 
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
     if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
     float inv_keep; const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
-    const FwdWs w = fwd_ws(M, in_features, out_features, rank);
-    if (!workspace || workspace_bytes < w.total)
-        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
+    const size_t need = fwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
+    if (!workspace || workspace_bytes < need)
+        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
     if (tT_out && ((uintptr_t)tT_out & 15)) return fail(SAM3_LORA_EINVAL, "tT_out must be 16-byte aligned");
     if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
     if (act && (rc = check_act(act_out, ldact, out_features, dtype, "act_out"))) return rc;
+    if (dtype != SAM3_LORA_BF16 && dtype != SAM3_LORA_F32) return fail(SAM3_LORA_EINVAL, "unknown dtype %d", dtype);
 
-    hipStream_t st = (hipStream_t)stream;
-    const int RP = rpad(rank), RT = RP / 16;
-    const long long Mp = round_up(M, 64);
-    char* ws = (char*)workspace;
-    const PackedLayout pl = packed_layout(in_features, out_features, rank);
-    bf16_t* W1 = pre ? (bf16_t*)((char*)A + pl.w1) : (bf16_t*)(ws + w.w1);
-    bf16_t* W2t = pre ? (bf16_t*)((char*)A + pl.w2t) : (bf16_t*)(ws + w.w2t);
-    bf16_t* T = (bf16_t*)(ws + w.t);
-    bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
     const Strides s = strides_of(layout, in_features, out_features, rank);
-
-    // W1[RP][in] = A_c^T ; W2t[out][RP] = B_c^T
-    if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
-        PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0};
-        PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0};
-        launch_pack(ja, jb, st);
-    }
-    if (dtype == SAM3_LORA_BF16) {
-        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<bf16_t>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk, RT == 1 ? (float*)(ws + w.t1p) : nullptr);
-        if (stage_on(SAM3_LORA_STAGE_T2))
-            launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
-                              act_out, ldact);
-    } else {
-        if (stage_on(SAM3_LORA_STAGE_T1)) launch_t1<float>(x, ldx, W1, T, TT, M, Mp, in_features, RT, st, dk, RT == 1 ? (float*)(ws + w.t1p) : nullptr);
-        if (stage_on(SAM3_LORA_STAGE_T2))
-            launch_t2<float>(y_inout, ldy, T, W2t, M, out_features, scaling * inv_keep, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
-                             act_out, ldact);
+    const int ng = n_groups(rank);
+    const char* blob = (const char*)A;
+    char* tT = (char*)tT_out;
+    for (int g = 0; g < ng; ++g) {
+        const int rg = group_rank(rank, g);
+        const void* Ag = pre ? (const void*)blob : (const void*)((const float*)A + 32LL * g * s.a_sr);
+        const void* Bg = pre ? nullptr : (const void*)((const float*)B + 32LL * g * s.b_sr);
+        // the activation rides on the LAST group's update: by then y holds the complete sum
+        const int act_g = (g == ng - 1) ? act : 0;
+        fwd_group(x, Ag, Bg, pre, y_inout, tT, M, in_features, out_features, rg, ldx, ldy, s, scaling * inv_keep, dk, dtype,
+                  (char*)workspace, (hipStream_t)stream, act_g, act_out, ldact);
+        if (pre) blob += packed_layout(in_features, out_features, rg, dtype).total;
+        if (tT) tT += saved_t_group_bytes(M, rg, dtype);
     }
     return launch_ok("sam3_lora_fwd");
 }
@@ -1425,6 +1532,80 @@ int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout
                       void* stream, int act, void* act_out, int64_t ldact) {
     return fwd_impl(x, A, B, y_inout, tT_out, M, in_features, out_features, rank, ldx, ldy, layout, scaling, drop_p, seed,
                     offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact);
+}
+
+// backward of one rank group (see fwd_group for A_g / B_g); gA_g / gB_g point at the group's slice of the gradients.
+// `act2` (GELU' on gx) must only be requested for the last group: gx is complete then.
+static void bwd_group(const void* gy, const void* x, const void* tT_saved, const void* A_g, const void* B_g, bool pre,
+                      void* gx_inout, float* gA_g, float* gB_g, long long M, int in_features, int out_features, int rank,
+                      long long ldgy, long long ldx, long long ldgx, const Strides& s, float scale, const DropKey& dk,
+                      int dtype, int accumulate, char* ws, hipStream_t st, int a2, void* hpre, long long ldpre) {
+    const int RP = rpad(rank), RT = RP / 16;
+    const long long Mp = round_up(M, 64);
+    const bool f32 = dtype == SAM3_LORA_F32;
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank, dtype);
+    const PackedLayout pl = packed_layout(in_features, out_features, rank, dtype);
+    void* W1b = pre ? (void*)((char*)A_g + pl.w1b) : (void*)(ws + w.w1b);
+    void* W2tb = pre ? (void*)((char*)A_g + pl.w2tb) : (void*)(ws + w.w2tb);
+    void* W1a = pre ? (void*)((char*)A_g + pl.w1) : (void*)(ws + w.w1a);
+    float* PB = (float*)(ws + w.pb);
+    float* PA = (float*)(ws + w.pa);
+    // W1b[RP][out] = B_c ; W2tb[in][RP] = A_c ; W1a[RP][in] = A_c^T (only to recompute t)
+    if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
+        PackJob jobs[3] = {{(const float*)B_g, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so, 0, f32},
+                           {(const float*)A_g, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0, f32},
+                           {(const float*)A_g, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0, f32}};
+        launch_pack(jobs, tT_saved ? 2 : 3, st);
+    }
+    const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
+    const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
+    bool one_pass = false;
+    if (f32) {
+        const float* T32 = (const float*)tT_saved;
+        if (!T32) {     // no saved t: recompute t = drop(x) . A_c
+            float* Ts = (float*)(ws + w.t);
+            launch32_t1(x, ldx, (const float*)W1a, Ts, M, Mp, in_features, RT, st, dk);
+            T32 = Ts;
+        }
+        float* GT32 = (float*)(ws + w.gt);
+        if (s1) launch32_t1(gy, ldgy, (const float*)W1b, GT32, M, Mp, out_features, RT, st);                       // gt = gy . B_c^T
+        if (gB_g && s3b) launch32_t3(gy, ldgy, T32, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
+        if (gA_g && s3a) launch32_t3(x, ldx, GT32, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk); // gA^T = gt^T . drop(x)
+        if (gx_inout && s2)
+            launch32_t2(gx_inout, ldgx, GT32, (const float*)W2tb, M, in_features, scale, RT, st, dk, a2, hpre, ldpre);
+    } else {
+        bf16_t* GT = (bf16_t*)(ws + w.gt);
+        bf16_t* GTT = (bf16_t*)(ws + w.gtt);
+        const bf16_t* TT = (const bf16_t*)tT_saved;
+        if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
+            bf16_t* TTs = (bf16_t*)(ws + w.tt);
+            float* t1p = RT == 1 ? (float*)(ws + w.gtp) : nullptr;     // free until k_t3e runs (stream order)
+            launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1a, (bf16_t*)(ws + w.t), TTs, M, Mp, in_features, RT, st, dk, t1p);
+            TT = TTs;
+        }
+        // r <= 16 with weight gradients wanted: gy is read ONCE -- k_t3e emits the gt partials beside the gB partials
+        one_pass = RT == 1 && gB_g && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
+        float* GTP = (float*)(ws + w.gtp);
+        if (one_pass) {
+            launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, (const bf16_t*)W1b, GTP, GT, GTT, st);
+        } else {
+            if (s1) launch_t1<bf16_t>(gy, ldgy, (const bf16_t*)W1b, GT, GTT, M, Mp, out_features, RT, st, DropKey{0u, 0u, 0},
+                                      RT == 1 ? GTP : nullptr);                                                          // gt = gy . B_c^T
+            if (gB_g && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
+        }
+        if (gA_g && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
+        if (gx_inout && s2)
+            launch_t2<bf16_t>(gx_inout, ldgx, GT, (const bf16_t*)W2tb, M, in_features, scale, RT, st, dk, a2, hpre, ldpre);
+    }
+    if ((gA_g || gB_g) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
+        // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
+        ReduceJob rb{PB, gB_g, one_pass ? w.pE.NR : w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
+        ReduceJob ra{PA, gA_g, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
+        const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
+        dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);
+        ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
+        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scale, accumulate);
+    }
 }
 
 static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
@@ -1448,78 +1629,27 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
     if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
     if (act && !gx_inout) return fail(SAM3_LORA_EINVAL, "an activation derivative needs gx_inout");
     if (act && (rc = check_act(pre_act, ldpre, in_features, dtype, "pre_act"))) return rc;
-    const int a2 = act ? 2 : 0;
-    void* hpre = const_cast<void*>(pre_act);
-    const BwdWs w = bwd_ws(M, in_features, out_features, rank);
-    if (!workspace || workspace_bytes < w.total)
-        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
+    const size_t need = bwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
+    if (!workspace || workspace_bytes < need)
+        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
 
-    hipStream_t st = (hipStream_t)stream;
-    const int RP = rpad(rank), RT = RP / 16;
-    const long long Mp = round_up(M, 64);
-    char* ws = (char*)workspace;
-    const PackedLayout pl = packed_layout(in_features, out_features, rank);
-    bf16_t* W1b = pre ? (bf16_t*)((char*)A + pl.w1b) : (bf16_t*)(ws + w.w1b);
-    bf16_t* W2tb = pre ? (bf16_t*)((char*)A + pl.w2tb) : (bf16_t*)(ws + w.w2tb);
-    bf16_t* W1a = pre ? (bf16_t*)((char*)A + pl.w1) : (bf16_t*)(ws + w.w1a);
-    bf16_t* GT = (bf16_t*)(ws + w.gt);
-    bf16_t* GTT = (bf16_t*)(ws + w.gtt);
-    bf16_t* Tscr = (bf16_t*)(ws + w.t);
-    const bf16_t* TT = (const bf16_t*)tT_saved;
-    float* PB = (float*)(ws + w.pb);
-    float* PA = (float*)(ws + w.pa);
     const Strides s = strides_of(layout, in_features, out_features, rank);
-
-    // W1b[RP][out] = B_c ; W2tb[in][RP] = A_c
-    if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
-        PackJob jobs[3] = {{(const float*)B, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so, 0},
-                           {(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0},
-                           {(const float*)A, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0}};
-        launch_pack(jobs, TT ? 2 : 3, st);
-    }
-    const bool bf = dtype == SAM3_LORA_BF16;
-    if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
-        bf16_t* TTs = (bf16_t*)(ws + w.tt);
-        float* t1p = RT == 1 ? (float*)(ws + w.gtp) : nullptr;     // free until k_t3e runs (stream order)
-        if (bf) launch_t1<bf16_t>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk, t1p);
-        else launch_t1<float>(x, ldx, W1a, Tscr, TTs, M, Mp, in_features, RT, st, dk, t1p);
-        TT = TTs;
-    }
-    const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
-    const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
-    // r <= 16 with weight gradients wanted: gy is read ONCE -- k_t3 emits the gt partials beside the gB partials
-    const bool one_pass = RT == 1 && gB_accum && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
-    float* GTP = (float*)(ws + w.gtp);
-    if (one_pass) {
-        if (bf) launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, W1b, GTP, GT, GTT, st);
-        else launch_t3_emit<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, W1b, GTP, GT, GTT, st);
-        if (bf) {
-            if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
-            if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
-        } else {
-            if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
-            if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
-        }
-    } else if (bf) {
-        if (s1) launch_t1<bf16_t>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st, DropKey{0u, 0u, 0}, RT == 1 ? GTP : nullptr);   // gt = gy . B_c^T
-        if (gB_accum && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
-        if (gA_accum && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);     // gA^T = gt^T . x
-        if (gx_inout && s2) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
-    } else {
-        if (s1) launch_t1<float>(gy, ldgy, W1b, GT, GTT, M, Mp, out_features, RT, st, DropKey{0u, 0u, 0}, RT == 1 ? GTP : nullptr);
-        if (gB_accum && s3b) launch_t3<float>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);
-        if (gA_accum && s3a) launch_t3<float>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);
-        if (gx_inout && s2) launch_t2<float>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling * inv_keep, RT, st, dk, a2, hpre, ldpre);
-    }
-    if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
-        // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
-        ReduceJob rb{PB, gB_accum, one_pass ? w.pE.NR : w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
-        ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
-        const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
-        dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);
-        ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
-        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling * inv_keep, accumulate);
+    const int ng = n_groups(rank);
+    const char* blob = (const char*)A;
+    const char* tT = (const char*)tT_saved;
+    for (int g = 0; g < ng; ++g) {
+        const int rg = group_rank(rank, g);
+        const void* Ag = pre ? (const void*)blob : (const void*)((const float*)A + 32LL * g * s.a_sr);
+        const void* Bg = pre ? nullptr : (const void*)((const float*)B + 32LL * g * s.b_sr);
+        float* gAg = gA_accum ? gA_accum + 32LL * g * s.a_sr : nullptr;
+        float* gBg = gB_accum ? gB_accum + 32LL * g * s.b_sr : nullptr;
+        const int a2 = (act && g == ng - 1) ? 2 : 0;
+        bwd_group(gy, x, tT, Ag, Bg, pre, gx_inout, gAg, gBg, M, in_features, out_features, rg, ldgy, ldx, ldgx, s,
+                  scaling * inv_keep, dk, dtype, accumulate, (char*)workspace, (hipStream_t)stream, a2,
+                  const_cast<void*>(pre_act), ldpre);
+        if (pre) blob += packed_layout(in_features, out_features, rg, dtype).total;
+        if (tT) tT += saved_t_group_bytes(M, rg, dtype);
     }
     return launch_ok("sam3_lora_bwd");
 }
@@ -1555,6 +1685,7 @@ int sam3_lora_aug_scatter(const void* A, const void* B, void* Waug, int64_t ldw,
     g_err[0] = 0;
     int rc;
     if ((rc = check_common(1, in_features, out_features, rank, layout, SAM3_LORA_BF16))) return rc;
+    if (rank > 32) return fail(SAM3_LORA_ENOTSUP, "fused mode holds the rank slot inside the weight: rank <= 32");
     if (!A || !B || !Waug) return fail(SAM3_LORA_EINVAL, "NULL pointer");
     const int RP = rpad(rank);
     if (ldw < in_features + RP) return fail(SAM3_LORA_EINVAL, "ldw (%lld) < in_features + r_pad", (long long)ldw);
@@ -1568,8 +1699,8 @@ int sam3_lora_aug_scatter(const void* A, const void* B, void* Waug, int64_t ldw,
 }
 
 size_t sam3_lora_fused_workspace_bytes(int64_t M, int in_features, int out_features, int rank) {
-    if (check_common(M, in_features, out_features, rank, 0, SAM3_LORA_BF16)) return 0;
-    const BwdWs w = bwd_ws(M, in_features, out_features, rank);   // superset of what the fused calls need
+    if (check_common(M, in_features, out_features, rank, 0, SAM3_LORA_BF16) || rank > 32) return 0;
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank, SAM3_LORA_BF16);   // superset of what the fused calls need
     return w.total;
 }
 
@@ -1580,10 +1711,11 @@ int sam3_lora_fwd_fused(const void* t, int64_t ldt, const void* B, void* y_inout
     int rc;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
     if (dtype != SAM3_LORA_BF16) return fail(SAM3_LORA_ENOTSUP, "fused mode is bf16 only");
+    if (rank > 32) return fail(SAM3_LORA_ENOTSUP, "fused mode holds the rank slot inside the weight: rank <= 32");
     if ((rc = check_act(y_inout, ldy, out_features, dtype, "y_inout"))) return rc;
     if (!t || !B) return fail(SAM3_LORA_EINVAL, "t or B is NULL");
     if (((uintptr_t)t & 7) || ((ldt * 2) & 7)) return fail(SAM3_LORA_EINVAL, "t: base and row pitch must be 8-byte aligned");
-    const BwdWs w = bwd_ws(M, in_features, out_features, rank);
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank, SAM3_LORA_BF16);
     if (!workspace || workspace_bytes < w.total)
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -1616,12 +1748,13 @@ int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, con
     int rc;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
     if (dtype != SAM3_LORA_BF16) return fail(SAM3_LORA_ENOTSUP, "fused mode is bf16 only");
+    if (rank > 32) return fail(SAM3_LORA_ENOTSUP, "fused mode holds the rank slot inside the weight: rank <= 32");
     if ((rc = check_act(gy, ldgy, out_features, dtype, "gy"))) return rc;
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
     if (!tT_saved || !gt || !A) return fail(SAM3_LORA_EINVAL, "tT_saved, gt or A is NULL");
     if (((uintptr_t)gt & 7) || ((ldgt * 2) & 7)) return fail(SAM3_LORA_EINVAL, "gt: base and row pitch must be 8-byte aligned");
-    const BwdWs w = bwd_ws(M, in_features, out_features, rank);
+    const BwdWs w = bwd_ws(M, in_features, out_features, rank, SAM3_LORA_BF16);
     if (!workspace || workspace_bytes < w.total)
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
     hipStream_t st = (hipStream_t)stream;

@@ -23,7 +23,8 @@ import torch.nn.functional as F
 from . import _ffi
 from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
-__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE"]
+__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE",
+           "enable_direct_grad_accumulation"]
 
 _ws_lock = threading.Lock()
 _workspaces = {}  # (device index, stream handle) -> uint8 tensor
@@ -99,24 +100,38 @@ def _pad_masters(A: torch.Tensor, B: torch.Tensor, layout: int, fin: int, fout: 
     return Ap, Bp
 
 
-def saved_t_like(M: int, rank: int, device) -> torch.Tensor:
-    n = _ffi.load().sam3_lora_saved_t_bytes(M, rank)
+def saved_t_like(M: int, rank: int, device, dt: int = DT_BF16) -> torch.Tensor:
+    n = _ffi.load().sam3_lora_saved_t_bytes(M, rank, dt)
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
-def pack_operands(A: torch.Tensor, B: torch.Tensor, layout: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bf16 operand images of the current A/B for ``lora_fwd_/lora_bwd_(..., packed=blob)`` (sam3_lora_pack)."""
+def _dt_of(dtype) -> int:
+    """Activation dtype (torch dtype or DT_* code) -> DT_* code."""
+    if isinstance(dtype, int):
+        return dtype
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    if dtype == torch.float32:
+        return DT_F32
+    raise LoRAKernelError(f"sam3_lora_amd: activations must be bfloat16 or float32, got {dtype}")
+
+
+def pack_operands(A: torch.Tensor, B: torch.Tensor, layout: int, out: Optional[torch.Tensor] = None,
+                  dtype=torch.bfloat16) -> torch.Tensor:
+    """Operand images of the current A/B for ``lora_fwd_/lora_bwd_(..., packed=blob)`` (sam3_lora_pack): bf16 images for
+    bf16 activations, fp32 images for the exact-fp32 path -- ``dtype`` is the ACTIVATION dtype the blob will be used with."""
     lib = _ffi.load()
     _require_cuda(A, B)
+    dt = _dt_of(dtype)
     rank = _rank_of(A, layout)
     fin = A.shape[0] if layout == LAYOUT_ROOT else A.shape[1]
     fout = B.shape[1] if layout == LAYOUT_ROOT else B.shape[0]
-    n = lib.sam3_lora_packed_bytes(fin, fout, rank)
+    n = lib.sam3_lora_packed_bytes(fin, fout, rank, dt)
     if n == 0:
         raise LoRAKernelError(f"sam3_lora_packed_bytes: {_ffi.last_error()}")
     if out is None or out.numel() != n or out.device != A.device:
         out = torch.empty(n, dtype=torch.uint8, device=A.device)
-    rc = lib.sam3_lora_pack(A.data_ptr(), B.data_ptr(), out.data_ptr(), fin, fout, rank, layout,
+    rc = lib.sam3_lora_pack(A.data_ptr(), B.data_ptr(), out.data_ptr(), fin, fout, rank, layout, dt,
                             ctypes.c_void_p(torch.cuda.current_stream(A.device).cuda_stream))
     _ffi.check(rc, "sam3_lora_pack")
     return out
@@ -129,15 +144,20 @@ class PackedOperands:
     whenever the previous one may still be referenced by a saved autograd context."""
 
     def __init__(self):
-        self.blob = None
-        self._stamp = None
+        self._held = {}          # DT_* code -> (stamp, blob)
 
-    def get(self, A: torch.Tensor, B: torch.Tensor, layout: int) -> torch.Tensor:
+    def get(self, A: torch.Tensor, B: torch.Tensor, layout: int, dtype=torch.bfloat16) -> torch.Tensor:
+        dt = _dt_of(dtype)
         stamp = (A.data_ptr(), A._version, B.data_ptr(), B._version, layout, A.device)
-        if stamp != self._stamp:
-            self.blob = pack_operands(_master(A), _master(B), layout)
-            self._stamp = stamp
-        return self.blob
+        held = self._held.get(dt)
+        if held is None or held[0] != stamp:
+            held = (stamp, pack_operands(_master(A), _master(B), layout, dtype=dt))
+            self._held[dt] = held
+        return held[1]
+
+    def invalidate(self) -> None:
+        """Forget the images (after an in-place edit through ``.data`` that the version counters cannot see)."""
+        self._held.clear()
 
 
 class TransposedCopy:
@@ -206,7 +226,7 @@ def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tens
     if nws == 0:
         raise LoRAKernelError(f"sam3_lora_fwd_workspace_bytes: {_ffi.last_error()}")
     ws = _workspace(x2.device, nws)
-    tT = saved_t_like(M, rank, x2.device) if save_t else None
+    tT = saved_t_like(M, rank, x2.device, dt) if save_t else None
     args = (x2.data_ptr(), (packed if packed is not None else A).data_ptr(), B.data_ptr(), y2.data_ptr(),
             tT.data_ptr() if tT is not None else None,
             M, fin, fout, rank, x2.stride(0), y2.stride(0), layout | (PREPACKED if packed is not None else 0), float(scaling),
@@ -272,6 +292,47 @@ def merge_weight(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: flo
     return out
 
 
+def _compute_dtype(x: torch.Tensor, weight: Optional[torch.Tensor]) -> torch.dtype:
+    """The dtype the adapted layer computes in: the frozen weight's (bf16 layout or the reference's fp32), or the
+    autocast dtype while autocast is on.  weight None: a bare LoRA branch (zero base) computes in x's dtype."""
+    ref = weight if weight is not None else x
+    cdt = ref.dtype if ref.dtype in (torch.bfloat16, torch.float32) else torch.float32
+    if torch.is_autocast_enabled("cuda"):
+        cdt = torch.get_autocast_dtype("cuda")
+        if cdt not in (torch.bfloat16, torch.float32):
+            raise LoRAKernelError(f"sam3_lora_amd: autocast dtype {cdt} unsupported (use bfloat16)")
+    return cdt
+
+
+# Direct accumulation of the weight gradients (opt-in, see enable_direct_grad_accumulation): `sam3_lora_bwd` adds
+# straight into ``param.grad`` (accumulate = 1) instead of returning fresh gA / gB for autograd's AccumulateGrad to add.
+_DIRECT = {"on": False, "notify": None}
+
+
+def enable_direct_grad_accumulation(on: bool = True, notify=None) -> None:
+    """With this on, the backward of an adapted Linear whose ``lora_A.grad`` / ``lora_B.grad`` already exist (fp32,
+    contiguous -- e.g. the views of :class:`sam3_lora_amd.ddp.LoRAGradReducer`'s flat buffer, or grads zeroed with
+    ``zero_grad(set_to_none=False)``) accumulates into them inside the kernel's fixed-order reduction and returns no
+    gradient tensors for A / B: one pass and two allocations less per layer and step.  ``notify(param)`` is called for
+    A and B afterwards (the reducer's ``notify``), because autograd's post-accumulate hooks do not fire on this route.
+    Tensor hooks registered on A / B do not fire either; leave it off if you rely on them."""
+    _DIRECT["on"], _DIRECT["notify"] = bool(on), notify
+
+
+def _is_master(p: torch.Tensor) -> bool:
+    return p.dtype == torch.float32 and p.is_contiguous()
+
+
+def _direct_targets(A: torch.Tensor, B: torch.Tensor):
+    if not _DIRECT["on"]:
+        return None
+    for p in (A, B):
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not g.is_cuda:
+            return None
+    return A.grad, B.grad
+
+
 class _LoRALinearFn(torch.autograd.Function):
     """Frozen linear + LoRA branch as one autograd node (saved tensors: x, t^T -- never y or delta)."""
 
@@ -279,12 +340,7 @@ class _LoRALinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, A, B, scaling, layout, drop_p, seed, packed=None, wt=None):
         _require_cuda(x, weight, A, B)
         ctx.wt = wt
-        ref = weight if weight is not None else x        # weight None: bare LoRA branch (zero base)
-        cdt = ref.dtype if ref.dtype in (torch.bfloat16, torch.float32) else torch.float32
-        if torch.is_autocast_enabled("cuda"):
-            cdt = torch.get_autocast_dtype("cuda")
-            if cdt not in (torch.bfloat16, torch.float32):
-                raise LoRAKernelError(f"sam3_lora_amd: autocast dtype {cdt} unsupported (use bfloat16)")
+        cdt = _compute_dtype(x, weight)
         x2 = _rows(x if x.dtype == cdt else x.to(cdt))
         w = weight if (weight is None or weight.dtype == cdt) else weight.to(cdt)
         b = bias if (bias is None or bias.dtype == cdt) else bias.to(cdt)
@@ -333,6 +389,15 @@ class _LoRALinearFn(torch.autograd.Function):
             else:
                 with torch.autocast("cuda", enabled=False):
                     gx2 = _dx(gy2, w, ctx.wt)            # frozen GEMM (TN form when W^T is at hand)
+        direct = _direct_targets(A, B) if (need_w and ctx.pad is None and gy2.shape[0] > 0 and _is_master(A) and _is_master(B)
+                                           and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]) else None
+        if direct is not None:
+            lora_bwd_(gy2, x2, tT, Am, Bm, gx2, direct[0], direct[1], ctx.scaling, ctx.layout, accumulate=True,
+                      drop_p=ctx.drop_p, seed=ctx.seed, packed=ctx.packed)
+            if _DIRECT["notify"] is not None:
+                _DIRECT["notify"](A), _DIRECT["notify"](B)
+            gx = gx2.view(ctx.x_shape).to(ctx.x_dtype) if need_x else None
+            return gx, None, None, None, None, None, None, None, None, None, None
         gA = torch.empty_like(Am) if need_w else None
         gB = torch.empty_like(Bm) if need_w else None
         if gy2.shape[0] == 0:
@@ -396,18 +461,31 @@ class _LoRAMlpFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
         gy2 = _rows(gy if gy.dtype == x2.dtype else gy.to(x2.dtype))
         A1m, B1m, A2m, B2m = _master(A1), _master(B1), _master(A2), _master(B2)
-        gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
+        d1 = d2 = None
+        if need_w and all(ctx.needs_input_grad[i] for i in (3, 4, 8, 9)) and all(_is_master(t) for t in (A1, B1, A2, B2)):
+            d1, d2 = _direct_targets(A1, B1), _direct_targets(A2, B2)
+        direct = d1 is not None and d2 is not None
+        if direct:          # accumulate straight into param.grad (see enable_direct_grad_accumulation)
+            (gA1, gB1), (gA2, gB2) = d1, d2
+        else:
+            gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
         with torch.autocast("cuda", enabled=False):
             ga = _dx(gy2, W2, ctx.wt[1])                             # frozen GEMM
         # fc2's adapter backward; its in-place pass over ga also applies GELU'(h): ga leaves as gh
-        lora_bwd_(gy2, a, t2, A2m, B2m, ga, gA2, gB2, s2, layout, drop_p=drop_p, seed=seed2, packed=pk2, gelu_pre=h)
+        lora_bwd_(gy2, a, t2, A2m, B2m, ga, gA2, gB2, s2, layout, accumulate=direct, drop_p=drop_p, seed=seed2, packed=pk2,
+                  gelu_pre=h)
         gx2 = None
         if need_x:
             with torch.autocast("cuda", enabled=False):
                 gx2 = _dx(ga, W1, ctx.wt[0])                         # frozen GEMM
         if need_x or need_w:
-            lora_bwd_(ga, x2, t1, A1m, B1m, gx2, gA1, gB1, s1, layout, drop_p=drop_p, seed=seed1, packed=pk1)
+            lora_bwd_(ga, x2, t1, A1m, B1m, gx2, gA1, gB1, s1, layout, accumulate=direct, drop_p=drop_p, seed=seed1, packed=pk1)
         gx = gx2.view(x_shape).to(x_dtype) if need_x else None
+        if direct:
+            if _DIRECT["notify"] is not None:
+                for p_ in (A2, B2, A1, B1):
+                    _DIRECT["notify"](p_)
+            return (gx,) + (None,) * 18
         g = lambda t, p, i: (t.to(p.dtype) if (t is not None and ctx.needs_input_grad[i]) else None)
         return (gx, None, None, g(gA1, A1, 3), g(gB1, B1, 4), None, None, None, g(gA2, A2, 8), g(gB2, B2, 9), None, None,
                 None, None, None, None, None, None, None)
@@ -422,15 +500,15 @@ def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool, wt_cac
           and not W1.requires_grad and not W2.requires_grad and not torch.is_autocast_enabled("cuda")
           and x.dtype == W1.dtype and all(d % 8 == 0 for d in (*W1.shape, *W2.shape))
           and (b1 is None or b1.dtype == W1.dtype) and (b2 is None or b2.dtype == W1.dtype)
-          and l1.dropout_p == l2.dropout_p and max(_rank_of(l1.lora_A, layout), _rank_of(l2.lora_A, layout)) <= 32)
+          and l1.dropout_p == l2.dropout_p)
     if not ok:
         return None
     p, seed1, seed2 = 0.0, 0, 0
     if training and l1.dropout_p > 0.0:
         p = float(l1.dropout_p)
         seed1, seed2 = (int(v) for v in torch.randint(0, 2 ** 62, (2,)).tolist())
-    pk1 = l1._packed.get(l1.lora_A, l1.lora_B, int(layout))
-    pk2 = l2._packed.get(l2.lora_A, l2.lora_B, int(layout))
+    pk1 = l1._packed.get(l1.lora_A, l1.lora_B, int(layout), W1.dtype)
+    pk2 = l2._packed.get(l2.lora_A, l2.lora_B, int(layout), W1.dtype)
     Wt1 = wt_caches[0].get(W1) if wt_caches is not None else None
     Wt2 = wt_caches[1].get(W2) if wt_caches is not None else None
     return _LoRAMlpFn.apply(x, W1, b1, l1.lora_A, l1.lora_B, float(l1.scaling), W2, b2, l2.lora_A, l2.lora_B,
@@ -582,7 +660,7 @@ def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[
         fin = A.shape[0] if layout == LAYOUT_ROOT else A.shape[1]
         fout = B.shape[1] if layout == LAYOUT_ROOT else B.shape[0]
         if fin % 8 == 0 and fout % 8 == 0:
-            packed = cache.get(A, B, int(layout))
+            packed = cache.get(A, B, int(layout), _compute_dtype(x, weight))
     wt = None
     if (wt_cache is not None and weight is not None and weight.is_cuda and not weight.requires_grad and x.requires_grad
             and torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda") and weight.dtype == x.dtype):

@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .._ffi import MAX_RANK
 from ..functional import LAYOUT_PACKAGE, AugmentedWeight, PackedOperands, TransposedCopy, lora_linear, merge_weight
 
 
@@ -20,6 +21,8 @@ class LoRALayer(nn.Module):
     def __init__(self, in_features: int, out_features: int, rank: int = 4, alpha: float = 1.0,
                  dropout: float = 0.0):
         super().__init__()
+        if not 1 <= int(rank) <= MAX_RANK:
+            raise ValueError(f"LoRA rank must be in [1, {MAX_RANK}] (got {rank})")
         self.in_features = in_features
         self.out_features = out_features
         self.rank = rank

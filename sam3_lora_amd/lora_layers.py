@@ -17,6 +17,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
+from ._ffi import MAX_RANK
 from .functional import LAYOUT_ROOT, AugmentedWeight, PackedOperands, TransposedCopy, lora_linear
 
 __all__ = [
@@ -37,6 +38,8 @@ class LoRALayer(nn.Module):
     def __init__(self, in_features: int, out_features: int, rank: int = 8, alpha: int = 16,
                  dropout: float = 0.0):
         super().__init__()
+        if not 1 <= int(rank) <= MAX_RANK:
+            raise ValueError(f"LoRA rank must be in [1, {MAX_RANK}] (got {rank})")
         self.rank = rank
         self.alpha = alpha
         self.scaling = alpha / rank

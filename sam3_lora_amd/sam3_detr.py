@@ -304,8 +304,9 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, tgt_query_pos, memory_text, text_attention_mask, memory, memory_pos, cross_attn_mask,
                 presence_token=None, dac: bool = False, dac_use_selfatt_ln: bool = True, self_attn_mask=None,
-                memory_key_padding_mask=None):
-        """tgt / tgt_query_pos [Q, B, C]; memory [HW, B, C]; cross_attn_mask [B*heads, Q, HW] additive."""
+                memory_key_padding_mask=None, mask_has_presence_row: bool = False):
+        """tgt / tgt_query_pos [Q, B, C]; memory [HW, B, C]; cross_attn_mask [B*heads, Q (+1), HW] additive
+        (``mask_has_presence_row``: the caller already put the presence token's all-zero row in front)."""
         o2m = None
         o2o, o2o_pos = tgt, tgt_query_pos
         if dac:
@@ -333,7 +334,8 @@ class TransformerDecoderLayer(nn.Module):
                              need_weights=False)[0]
             tgt = self.catext_norm(tgt + self.catext_dropout(h))
 
-        if presence_token is not None:          # the presence token attends to the image without a position bias
+        if presence_token is not None and not mask_has_presence_row:
+            # the presence token attends to the image without a position bias
             cross_attn_mask = torch.cat([torch.zeros_like(cross_attn_mask[:, :1, :]), cross_attn_mask], dim=1)
         h = self.cross_attn(query=tgt + tgt_query_pos, key=memory + memory_pos, value=memory,
                             attn_mask=cross_attn_mask,
@@ -407,10 +409,13 @@ class TransformerDecoder(nn.Module):
                                  torch.arange(0, W, device=device, dtype=torch.float32) / W)
         return self._coords[key]
 
-    def _get_rpb_matrix(self, reference_boxes: torch.Tensor, feat_size) -> torch.Tensor:
+    def _get_rpb_matrix(self, reference_boxes: torch.Tensor, feat_size, presence_row: bool = False) -> torch.Tensor:
         """Box-relative position bias: for every query box, the signed (log-scaled) offsets of each token row / column
         from the box's two edges go through a small MLP per axis; the per-head bias of token (y, x) is the sum of its
-        row and column terms.  [Q, B, 4] -> [B, heads, Q, H*W]."""
+        row and column terms.  [Q, B, 4] -> [B, heads, Q (+1), H*W]; with ``presence_row`` an all-zero row for the
+        presence token comes first.  The [B, heads, Q, H, W] tensor (266 MB at batch 8 in bf16) is written ONCE, by the
+        broadcast add of the two small per-axis terms already laid out head-major -- the reference builds it query-major,
+        permutes + copies it, and concatenates the presence row with another full copy (decoder.py:395-407, :147-151)."""
         H, W = int(feat_size[0]), int(feat_size[1])
         xyxy = box_cxcywh_to_xyxy(reference_boxes.float()).transpose(0, 1)      # [B, Q, 4]
         ys, xs = self._grid(H, W, reference_boxes.device)
@@ -429,8 +434,11 @@ class TransformerDecoder(nn.Module):
         wd = self.norm.weight.dtype
         bx = _maybe_checkpoint(ckpt, self.boxRPB_embed_x, dx.to(wd))           # [B, Q, W, heads]
         by = _maybe_checkpoint(ckpt, self.boxRPB_embed_y, dy.to(wd))           # [B, Q, H, heads]
-        bias = by.unsqueeze(3) + bx.unsqueeze(2)                               # [B, Q, H, W, heads]
-        return bias.flatten(2, 3).permute(0, 3, 1, 2).contiguous()
+        by = by.permute(0, 3, 1, 2)                                            # [B, heads, Q, H]  (small)
+        bx = bx.permute(0, 3, 1, 2)                                            # [B, heads, Q, W]
+        if presence_row:
+            by, bx = F.pad(by, (0, 0, 1, 0)), F.pad(bx, (0, 0, 1, 0))
+        return (by.unsqueeze(-1) + bx.unsqueeze(-2)).flatten(3)                # [B, heads, Q(+1), H*W], contiguous
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, reference_boxes=None, level_start_index=None,
@@ -460,18 +468,22 @@ class TransformerDecoder(nn.Module):
         presence = self.presence_token.weight[None].expand(1, bs, -1) if self.presence_token is not None else None
         ckpt = self.training and self.use_act_checkpoint and torch.is_grad_enabled()
         ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[None, :].float()   # [1, B, levels, 4]
+        feat_hw = None
+        if self.boxRPB != "none":
+            assert spatial_shapes.shape[0] == 1, "only single scale support implemented"
+            feat_hw = tuple(int(v) for v in spatial_shapes[0].tolist())           # one host read per forward, not per layer
         for idx, layer in enumerate(self.layers):
             ref_in = reference_boxes[:, :, None] * ratios4                        # [Q, B, levels, 4]
             query_pos = self.ref_point_head(gen_sineembed_for_position(ref_in[:, :, 0, :], self.d_model).to(wd))
             if self.boxRPB != "none":
-                assert spatial_shapes.shape[0] == 1, "only single scale support implemented"
-                memory_mask = self._get_rpb_matrix(reference_boxes, (spatial_shapes[0, 0], spatial_shapes[0, 1]))
-                memory_mask = memory_mask.flatten(0, 1)                           # [B*heads, Q, HW]
+                memory_mask = self._get_rpb_matrix(reference_boxes, feat_hw, presence_row=presence is not None)
+                memory_mask = memory_mask.flatten(0, 1)                           # [B*heads, Q (+1), HW]
 
             def run(out, qpos, mtext, tmask, mem, mpos, cmask, ptok, layer=layer):
                 return layer(out, qpos, mtext, tmask, mem, mpos, cmask, presence_token=ptok, dac=apply_dac,
                              dac_use_selfatt_ln=self.dac_use_selfatt_ln, self_attn_mask=tgt_mask,
-                             memory_key_padding_mask=memory_key_padding_mask)
+                             memory_key_padding_mask=memory_key_padding_mask,
+                             mask_has_presence_row=self.boxRPB != "none" and ptok is not None)
             output, presence = _maybe_checkpoint(ckpt, run, output, query_pos, memory_text, text_attention_mask, memory,
                                                  pos, memory_mask, presence)
             normed = self.norm(output)

@@ -121,10 +121,12 @@ class Sam3DualViTDetNeck(nn.Module):
             stage.add_module("conv_3x3", nn.Conv2d(d_model, d_model, kernel_size=3, padding=1, bias=True))
             self.convs.append(stage)
         self.sam2_convs = None
+        self.skip_coarsest = 0      # set by SAM3VLBackbone(scalp=...): levels nobody reads are not computed
 
     def forward(self, images: torch.Tensor):
         x = self.trunk(images)[-1]
-        feats = [stage(x) for stage in self.convs]
+        stages = list(self.convs)[:len(self.convs) - self.skip_coarsest]
+        feats = [stage(x) for stage in stages]
         pos = [self.position_encoding(f).to(f.dtype) for f in feats]
         return feats, pos, None, None
 
@@ -137,16 +139,20 @@ class SAM3VLBackbone(nn.Module):
         self.vision_backbone = visual
         self.language_backbone = text
         self.scalp = scalp
+        self._text_cache = {}
+        if scalp > 0 and hasattr(visual, "skip_coarsest"):
+            visual.skip_coarsest = scalp    # the reference computes the dropped levels and throws them away (:89-99)
 
     def forward_image(self, samples: torch.Tensor) -> Dict:
         feats, pos, _, _ = self.vision_backbone(samples)
-        if self.scalp > 0:
-            feats, pos = feats[:-self.scalp], pos[:-self.scalp]
+        dropped = getattr(self.vision_backbone, "skip_coarsest", 0)
+        if self.scalp > dropped:
+            feats, pos = feats[:-(self.scalp - dropped)], pos[:-(self.scalp - dropped)]
         return {"vision_features": feats[-1], "vision_pos_enc": pos, "backbone_fpn": feats, "sam2_backbone_out": None}
 
     def forward_text(self, captions: List[str], input_boxes=None, additional_text=None, device="cuda") -> Dict:
         texts = list(captions) + list(additional_text or [])
-        mask, memory, embeds = self.language_backbone(texts, input_boxes, device=device)
+        mask, memory, embeds = self._encode_text(texts, input_boxes, device)
         out = {}
         if additional_text is not None:
             out["additional_text_features"] = memory[:, -len(additional_text):]
@@ -154,6 +160,25 @@ class SAM3VLBackbone(nn.Module):
         n = len(captions)
         out["language_features"], out["language_mask"], out["language_embeds"] = memory[:, :n], mask[:n], embeds[:, :n]
         return out
+
+    def _encode_text(self, texts, input_boxes, device):
+        """The text tower is deterministic (no dropout) and, with no adapter inside it, frozen: its output for a given
+        list of prompts is a constant of the run.  Cached per prompt list while nothing in the tower requires grad
+        (keyed on the weights' version counters, so a load_state_dict refreshes it)."""
+        tower = self.language_backbone
+        if (not isinstance(texts[0], str)) or (input_boxes is not None and len(input_boxes) > 0) \
+                or any(p.requires_grad for p in tower.parameters()):
+            return tower(texts, input_boxes, device=device)
+        w = tower.resizer.weight
+        key = (tuple(texts), str(device), w.dtype, w._version, tower.encoder.token_embedding.weight._version)
+        hit = self._text_cache.get(key)
+        if hit is None:
+            with torch.no_grad():
+                hit = tower(texts, input_boxes, device=device)
+            if len(self._text_cache) > 64:
+                self._text_cache.clear()
+            self._text_cache[key] = hit
+        return hit
 
     def forward(self, samples, captions, input_boxes=None, additional_text=None):
         out = self.forward_image(samples)

@@ -203,6 +203,11 @@ class SAM3TrainerNative:
         self.optimizer = AdamW(trainable, lr=float(self.config["training"]["learning_rate"]),
                                weight_decay=self.config["training"]["weight_decay"])
         self.reducer = LoRAGradReducer(trainable) if self.world_size > 1 else None
+        # the adapters' backward adds straight into param.grad (the reducer's flat buffer under data parallelism)
+        # instead of handing fresh gradient tensors to autograd: engine.direct_grad (default on)
+        if (self.config.get("engine") or {}).get("direct_grad", True) and self.device.type == "cuda":
+            from .functional import enable_direct_grad_accumulation
+            enable_direct_grad_accumulation(True, notify=self.reducer.notify if self.reducer is not None else None)
         self.matcher, self.loss_wrapper = build_criterion("global" if self.world_size > 1 else "local")
 
     # ------------------------------------------------------------------------------------------------
@@ -226,7 +231,7 @@ class SAM3TrainerNative:
             loss.backward()
             self.reducer.finish()
         else:
-            self.optimizer.zero_grad()
+            self.optimizer.zero_grad(set_to_none=False)      # keep the .grad tensors: the kernels accumulate into them
             loss.backward()
         self.optimizer.step()
         return loss.item()

@@ -6,10 +6,12 @@ GPU parity (run with ``-m gpu`` on an MI355X): the HIP path, called through the 
     GPU plus size-independent properties (linearity, bitwise run-to-run determinism).
 
 Tolerances (floating point; stated per check):
-  the kernels contract bf16 operands with fp32 accumulation and round the rank-r intermediate
-  (t, gt) to bf16 once.  Against a model of exactly those roundings
-  (``adapter_delta_bf16_model``) outputs agree to 2e-3 of the tensor's max magnitude; against
-  the fp32 reference to 1e-2 of it (bf16 has 8 mantissa bits: 2^-9 = 2e-3 relative per rounding).
+  bf16 activations: the kernels contract bf16 operands with fp32 accumulation and round the rank-r intermediate
+  (t, gt) to bf16 once.  Against a model of exactly those roundings (``adapter_delta_bf16_model``) outputs agree to
+  6e-3 of the tensor's max magnitude; against the fp32 reference to 1e-2 of it (bf16 has 8 mantissa bits: 2^-9 = 2e-3
+  relative per rounding).
+  fp32 activations: exact fp32 products and accumulation (v_mfma_f32_16x16x4_f32), fp32 intermediates: 1e-5 of the
+  tensor's max magnitude against the reference's own fp32 outputs and against the fp64 oracle.
 """
 import os
 
@@ -47,7 +49,7 @@ def _golden(golden_dir, name):
 def test_library_is_the_hip_one():
     from sam3_lora_amd import _ffi
     lib = _ffi.load()
-    assert lib.sam3_lora_abi_version() == 1
+    assert lib.sam3_lora_abi_version() == 2
     assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
 
 
@@ -68,20 +70,21 @@ def test_kernels_vs_oracle_and_reference(golden_dir, name, dtype):
     tT = Fn.lora_fwd_(x, A, B, y, s, lay, save_t=True)
     d_model = O.adapter_delta_bf16_model(c["x"], c["A"], c["B"], s, lay).reshape(M, -1)
     d_ref = O.adapter_delta(c["x"], c["A"], c["B"], s, lay, acc_dtype=np.float64).reshape(M, -1)
-    tol_model = 2e-3 if dtype == "f32" else 6e-3      # bf16 output adds one more 2^-9 rounding
-    assert _relmax(y.float().cpu().numpy(), d_model) < tol_model
-    assert _relmax(y.float().cpu().numpy(), d_ref) < 1e-2
+    tol = 1e-5 if dtype == "f32" else 1e-2            # f32: the exact path; bf16: 8 mantissa bits
+    if dtype == "bf16":
+        assert _relmax(y.float().cpu().numpy(), d_model) < 6e-3
+    assert _relmax(y.float().cpu().numpy(), d_ref) < tol
     # backward, overwrite mode
     gx = torch.zeros(M, x.shape[1], device=DEV, dtype=td)
     gA, gB = torch.full_like(A, 7.0), torch.full_like(B, 7.0)
     Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, s, lay, accumulate=False)
     gx_r, gA_r, gB_r = O.adapter_backward(c["gy"], c["x"], c["A"], c["B"], s, lay, acc_dtype=np.float64)
-    assert _relmax(gx.float().cpu().numpy(), gx_r.reshape(M, -1)) < 1e-2
-    assert _relmax(gA.cpu().numpy(), gA_r) < 1e-2
-    assert _relmax(gB.cpu().numpy(), gB_r) < 1e-2
+    assert _relmax(gx.float().cpu().numpy(), gx_r.reshape(M, -1)) < tol
+    assert _relmax(gA.cpu().numpy(), gA_r) < tol
+    assert _relmax(gB.cpu().numpy(), gB_r) < tol
     # golden cross-check: reference's autograd grads of A and B are exactly the adapter grads
-    assert _relmax(gA.cpu().numpy(), g["gA"]) < 1e-2
-    assert _relmax(gB.cpu().numpy(), g["gB"]) < 1e-2
+    assert _relmax(gA.cpu().numpy(), g["gA"]) < (2e-5 if dtype == "f32" else 1e-2)
+    assert _relmax(gB.cpu().numpy(), g["gB"]) < (2e-5 if dtype == "f32" else 1e-2)
     # accumulate mode adds on top; recompute-t mode (tT=None) agrees with saved-t mode
     gA2, gB2 = gA.clone(), gB.clone()
     Fn.lora_bwd_(gy, x, None, A, B, None, gA2, gB2, s, lay, accumulate=True)
@@ -114,13 +117,13 @@ def test_module_forward_backward_vs_reference_golden(golden_dir, name, dtype):
     x = _t(c["x"], td).requires_grad_(True)
     y = mod(x)
     y.backward(_t(c["gy"], td))
-    tol = 5e-3 if dtype == "f32" else 2e-2
+    tol = 2e-5 if dtype == "f32" else 2e-2          # f32: frozen GEMM in fp32 on hipBLASLt + the exact adapter path
     assert y.shape == g["y"].shape and y.dtype == td
     assert _relmax(y.detach().float().cpu().numpy(), g["y"]) < tol
     assert _relmax(x.grad.float().cpu().numpy(), g["gx"]) < tol
     assert mod.lora.lora_A.grad.dtype == torch.float32
-    assert _relmax(mod.lora.lora_A.grad.cpu().numpy(), g["gA"]) < 1e-2
-    assert _relmax(mod.lora.lora_B.grad.cpu().numpy(), g["gB"]) < 1e-2
+    assert _relmax(mod.lora.lora_A.grad.cpu().numpy(), g["gA"]) < (2e-5 if dtype == "f32" else 1e-2)
+    assert _relmax(mod.lora.lora_B.grad.cpu().numpy(), g["gB"]) < (2e-5 if dtype == "f32" else 1e-2)
     base = mod.original_layer if hasattr(mod, "original_layer") else mod.linear
     assert base.weight.grad is None and base.bias.grad is None
 

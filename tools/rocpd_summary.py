@@ -42,16 +42,29 @@ def stats(db):
         print(f"{k:60s} {gx:6d} {gy:6d} {vg:5d} {lds:6d} {len(d):6d} {sum(d) / len(d) / 1e3:10.2f} {min(d) / 1e3:10.2f} {max(d) / 1e3:10.2f}")
 
 
-def stats_all(db, top=45):
-    """Every kernel of a whole-model step (library kernels included): top `top` by total time."""
+def stats_all(db, top=45, after=None):
+    """Every kernel of a whole-model step (library kernels included): top `top` by total time.  With `after`
+    (a substring of a kernel name, e.g. naive_conv: MIOpen's find pass runs reference convolutions on the first call
+    of each configuration) only dispatches that start after the LAST dispatch of a matching kernel are counted --
+    the steady-state steps."""
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select name, duration from kernels").fetchall()
+    rows = cur.execute("select name, duration, start from kernels").fetchall()
+    cut = None
+    if after:
+        hits = [st for name, _, st in rows if after in name]
+        cut = max(hits) if hits else None
+        if cut is not None:
+            rows = [r for r in rows if r[2] > cut]
     tot = sum(r[1] for r in rows)
     by_k = {}
-    for name, dur in rows:
+    for name, dur, _ in rows:
         by_k.setdefault(short(name, 110), []).append(dur)
+    span = (max(r[2] for r in rows) - min(r[2] for r in rows)) / 1e3 if rows else 0.0
     print("# rocprofv3 --kernel-trace --stats (rocpd) -- durations in microseconds")
-    print(f"# total kernel time {tot / 1e3:.1f} us over {len(rows)} dispatches, {len(by_k)} distinct kernels\n")
+    if cut is not None:
+        print(f"# steady state only: dispatches after the last '{after}' kernel (MIOpen find pass of the first step)")
+    print(f"# total kernel time {tot / 1e3:.1f} us over {len(rows)} dispatches, {len(by_k)} distinct kernels, "
+          f"wall span {span:.1f} us\n")
     print(f"{'kernel':112s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
     for k, d in sorted(by_k.items(), key=lambda kv: -sum(kv[1]))[:int(top)]:
         print(f"{k:112s} {len(d):6d} {sum(d) / 1e3:12.1f} {sum(d) / len(d) / 1e3:10.2f} {100 * sum(d) / tot:6.2f}")
