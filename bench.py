@@ -559,7 +559,7 @@ class FullStep:
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.reducer = LoRAGradReducer(self.params, bucket_bytes=8 << 20)
         from sam3_lora_amd.functional import enable_direct_grad_accumulation
-        enable_direct_grad_accumulation(True, notify=self.reducer.notify)    # kernels add straight into the flat buffer
+        enable_direct_grad_accumulation(True)    # the kernels add straight into the reducer's flat buffer
         self.opt = torch.optim.AdamW(self.params, lr=5e-5, weight_decay=0.01)
         self.matcher, self.wrapper = build_criterion("global" if world > 1 else "local")
         ds = SyntheticSegmentDataset(2 * batch * world, resolution=res, source=src)

@@ -305,18 +305,28 @@ def _compute_dtype(x: torch.Tensor, weight: Optional[torch.Tensor]) -> torch.dty
 
 
 # Direct accumulation of the weight gradients (opt-in, see enable_direct_grad_accumulation): `sam3_lora_bwd` adds
-# straight into ``param.grad`` (accumulate = 1) instead of returning fresh gA / gB for autograd's AccumulateGrad to add.
-_DIRECT = {"on": False, "notify": None}
+# straight into ``param.grad`` (accumulate = 1) instead of writing fresh gA / gB tensors for autograd to add.
+_DIRECT = {"on": False}
+_ZEROS = {}
 
 
-def enable_direct_grad_accumulation(on: bool = True, notify=None) -> None:
+def enable_direct_grad_accumulation(on: bool = True) -> None:
     """With this on, the backward of an adapted Linear whose ``lora_A.grad`` / ``lora_B.grad`` already exist (fp32,
     contiguous -- e.g. the views of :class:`sam3_lora_amd.ddp.LoRAGradReducer`'s flat buffer, or grads zeroed with
-    ``zero_grad(set_to_none=False)``) accumulates into them inside the kernel's fixed-order reduction and returns no
-    gradient tensors for A / B: one pass and two allocations less per layer and step.  ``notify(param)`` is called for
-    A and B afterwards (the reducer's ``notify``), because autograd's post-accumulate hooks do not fire on this route.
-    Tensor hooks registered on A / B do not fire either; leave it off if you rely on them."""
-    _DIRECT["on"], _DIRECT["notify"] = bool(on), notify
+    ``zero_grad(set_to_none=False)``) accumulates into them inside the kernel's fixed-order reduction (accumulate = 1
+    of the C-ABI): no gradient tensors are allocated and no separate overwrite-then-add happens.  Autograd still
+    receives a gradient for A and B -- a stride-0 view of one shared zero scalar -- so its own bookkeeping stays exact:
+    a parameter used several times in a graph is final only after its last use, post-accumulate hooks (the reducer's
+    bucket launches) fire exactly once, tensor hooks see a (zero) gradient."""
+    _DIRECT["on"] = bool(on)
+
+
+def _zero_grad_like(p: torch.Tensor) -> torch.Tensor:
+    key = (p.device, p.dtype)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros((), device=p.device, dtype=p.dtype)
+    return z.expand(p.shape)
 
 
 def _is_master(p: torch.Tensor) -> bool:
@@ -394,10 +404,8 @@ class _LoRALinearFn(torch.autograd.Function):
         if direct is not None:
             lora_bwd_(gy2, x2, tT, Am, Bm, gx2, direct[0], direct[1], ctx.scaling, ctx.layout, accumulate=True,
                       drop_p=ctx.drop_p, seed=ctx.seed, packed=ctx.packed)
-            if _DIRECT["notify"] is not None:
-                _DIRECT["notify"](A), _DIRECT["notify"](B)
             gx = gx2.view(ctx.x_shape).to(ctx.x_dtype) if need_x else None
-            return gx, None, None, None, None, None, None, None, None, None, None
+            return gx, None, None, _zero_grad_like(A), _zero_grad_like(B), None, None, None, None, None, None
         gA = torch.empty_like(Am) if need_w else None
         gB = torch.empty_like(Bm) if need_w else None
         if gy2.shape[0] == 0:
@@ -482,10 +490,9 @@ class _LoRAMlpFn(torch.autograd.Function):
             lora_bwd_(ga, x2, t1, A1m, B1m, gx2, gA1, gB1, s1, layout, accumulate=direct, drop_p=drop_p, seed=seed1, packed=pk1)
         gx = gx2.view(x_shape).to(x_dtype) if need_x else None
         if direct:
-            if _DIRECT["notify"] is not None:
-                for p_ in (A2, B2, A1, B1):
-                    _DIRECT["notify"](p_)
-            return (gx,) + (None,) * 18
+            z = _zero_grad_like
+            return (gx, None, None, z(A1), z(B1), None, None, None, z(A2), z(B2), None, None, None, None, None, None, None,
+                    None, None)
         g = lambda t, p, i: (t.to(p.dtype) if (t is not None and ctx.needs_input_grad[i]) else None)
         return (gx, None, None, g(gA1, A1, 3), g(gB1, B1, 4), None, None, None, g(gA2, A2, 8), g(gB2, B2, 9), None, None,
                 None, None, None, None, None, None, None)

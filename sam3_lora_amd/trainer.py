@@ -207,7 +207,7 @@ class SAM3TrainerNative:
         # instead of handing fresh gradient tensors to autograd: engine.direct_grad (default on)
         if (self.config.get("engine") or {}).get("direct_grad", True) and self.device.type == "cuda":
             from .functional import enable_direct_grad_accumulation
-            enable_direct_grad_accumulation(True, notify=self.reducer.notify if self.reducer is not None else None)
+            enable_direct_grad_accumulation(True)
         self.matcher, self.loss_wrapper = build_criterion("global" if self.world_size > 1 else "local")
 
     # ------------------------------------------------------------------------------------------------

@@ -40,7 +40,7 @@ def _inputs(M, fin, fout, r, seed, layout=0):
     gy = O.bf16_round(rng.standard_normal((M, fout), dtype=np.float32))
     base = O.bf16_round(rng.standard_normal((M, fout), dtype=np.float32))
     gxb = O.bf16_round(rng.standard_normal((M, fin), dtype=np.float32))
-    A = rng.uniform(-1, 1, (fin, r) if layout == 0 else (r, fin)).astype(np.float32) / np.sqrt(r)
+    A = (rng.uniform(-1, 1, (fin, r) if layout == 0 else (r, fin)) / np.sqrt(r)).astype(np.float32)
     B = (rng.standard_normal((r, fout) if layout == 0 else (fout, r)) * 0.02).astype(np.float32)
     return x, gy, base, gxb, A, B
 
@@ -94,10 +94,10 @@ def test_named_configs_at_full_size_against_oracle(tag, batch, fin, fout, r, alp
     gA_w, gB_w = _oracle_full_grads(gy, x, A, B, s, 0, mask)
     assert _relmax(gA.cpu().numpy(), gA_w) < tol, "gA"
     assert _relmax(gB.cpu().numpy(), gB_w) < tol, "gB"
-    if dtype == "f32":     # element-wise, where the reference value is not tiny: relative error of every sampled output
+    if dtype == "f32":     # element-wise relative error of every sampled output that is not small against the tensor
         got, ref = y[rows].float().cpu().numpy(), want_y
-        big = np.abs(ref) > 1e-2
-        assert (np.abs(got - ref)[big] / np.abs(ref)[big]).max() < 1e-4
+        big = np.abs(ref) >= 0.05 * np.abs(ref).max()
+        assert (np.abs(got - ref)[big] / np.abs(ref)[big]).max() < 5e-4
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
@@ -152,7 +152,8 @@ def test_modules_accept_rank_64_and_validate_rank():
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_direct_grad_accumulation_equals_autograd_accumulation(dtype):
     """enable_direct_grad_accumulation: the kernel adds into param.grad (accumulate = 1) -- same values as the gradients
-    autograd would have accumulated, two steps in a row, single Linears and the fused MLP node, with a notify callback."""
+    autograd would have accumulated, two steps in a row, single Linears (one of them used twice in the graph) and the
+    fused MLP node; post-accumulate hooks still fire exactly once per parameter and backward."""
     import lora_layers as L
     from sam3_lora_amd.vit import Mlp
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
@@ -161,8 +162,8 @@ def test_direct_grad_accumulation_equals_autograd_accumulation(dtype):
         torch.manual_seed(3)
         mlp = Mlp(64, 128)
         mlp.fc1, mlp.fc2 = L.LoRALinear(mlp.fc1, rank=8, alpha=16), L.LoRALinear(mlp.fc2, rank=8, alpha=16)
-        head = L.LoRALinear(torch.nn.Linear(64, 40), rank=4, alpha=8)
-        net = torch.nn.Sequential(mlp, head)
+        head = L.LoRALinear(torch.nn.Linear(64, 64), rank=4, alpha=8)
+        net = torch.nn.Sequential(mlp, head, head)          # `head` is used twice: final only after its second backward
         with torch.no_grad():
             for m in net.modules():
                 if isinstance(m, L.LoRALayer):
@@ -181,16 +182,16 @@ def test_direct_grad_accumulation_equals_autograd_accumulation(dtype):
         net = build()
         params = [p for p in net.parameters() if p.requires_grad]
         seen = []
-        Fn.enable_direct_grad_accumulation(direct, notify=seen.append if direct else None)
+        Fn.enable_direct_grad_accumulation(direct)
         try:
             for p in params:
                 p.grad = torch.zeros_like(p)
+                p.register_post_accumulate_grad_hook(seen.append)
             for _ in range(2):                      # two accumulating backward passes
                 net(x.clone().requires_grad_(True)).float().pow(2).mean().backward()
         finally:
             Fn.enable_direct_grad_accumulation(False)
         grads.append([p.grad.clone() for p in params])
-        if direct:
-            assert len(seen) == 2 * len(params) and {id(p) for p in seen} == {id(p) for p in params}
+        assert len(seen) == 2 * len(params) and {id(p) for p in seen} == {id(p) for p in params}
     for a, b in zip(*grads):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (a - b).abs().max()

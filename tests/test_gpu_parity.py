@@ -475,13 +475,16 @@ def test_module_repacks_when_parameters_change():
     torch.nn.init.normal_(mod.lora.lora_B)
     x = torch.randn(32, 64, device=DEV)
     y0 = mod(x).detach().clone()
-    blob0 = mod.lora._packed.blob
-    assert blob0 is not None and mod(x) is not None and mod.lora._packed.blob is blob0      # cached
+    held = lambda: mod.lora._packed._held[Fn.DT_F32][1]       # fp32 activations -> fp32 operand images
+    blob0 = held()
+    assert blob0 is not None and mod(x) is not None and held() is blob0                     # cached
     with torch.no_grad():
         mod.lora.lora_B.mul_(2.0)                                                               # optimizer-like in-place update
     y1 = mod(x).detach()
     base = lin(x).detach()
-    assert mod.lora._packed.blob is not blob0
+    assert held() is not blob0
+    mod.lora._packed.invalidate()
+    assert not mod.lora._packed._held and mod(x) is not None and Fn.DT_F32 in mod.lora._packed._held
     assert _relmax((y1 - base).cpu().numpy(), 2 * (y0 - base).cpu().numpy()) < 1e-2
 
 
