@@ -110,11 +110,14 @@ class Workload:
         prepack = os.environ.get("BENCH_PREPACK", "1") != "0"
         self.reducer.zero_grad()
         with torch.no_grad():
+            if prepack:         # A/B changed at the optimizer step: pack ALL adapters once (4 launches for 64 of them);
+                                # forward, checkpoint recompute and backward of the step use these images
+                from sam3_lora_amd.functional import pack_operands_many
+                pairs = [(self.A1[b], self.B1[b]) for b in range(self.blocks)] + [(self.A2[b], self.B2[b]) for b in range(self.blocks)]
+                blobs = pack_operands_many(pairs, L, dtype=self.x1[0].dtype, outs=self.P1 + self.P2)
+                self.P1, self.P2 = blobs[:self.blocks], blobs[self.blocks:]
             for b in range(self.blocks):                       # forward
                 k = b & 1
-                if prepack:     # A/B changed at the optimizer step: pack once, use for fwd, recompute and bwd
-                    self.P1[b] = pack_operands(self.A1[b], self.B1[b], L, out=self.P1[b], dtype=self.x1[0].dtype)
-                    self.P2[b] = pack_operands(self.A2[b], self.B2[b], L, out=self.P2[b], dtype=self.x1[0].dtype)
                 p1, p2 = (self.P1[b], self.P2[b]) if prepack else (None, None)
                 t1 = lora_fwd_(self.x1[k], self.A1[b], self.B1[b], self.h[k], s, L, save_t=not recompute, drop_p=dp,
                                seed=2 * b, packed=p1)
@@ -573,6 +576,8 @@ class FullStep:
             self.batches.append(b)
         self.n = 0
         self.last_loss = None
+        from sam3_lora_amd.functional import repack_adapters
+        self._repack = repack_adapters
 
     def step(self, timers=None):
         from sam3_lora_amd.trainer import match_all_steps
@@ -596,6 +601,7 @@ class FullStep:
         mark("backward")
         self.reducer.finish()
         self.opt.step()
+        self._repack(self.model)            # operand images of all adapters, batched (sam3_lora_pack_many)
         mark("exchange + AdamW")
         self.last_loss = loss
         return loss
@@ -727,8 +733,8 @@ def main():
         msa = dta / a_steps * 1e3
         ap = {"value": round(world * args.batch / (dta / a_steps), 2), "unit": "images/s", "ms_per_step": round(msa, 3),
               "steps": a_steps,
-              "what": "the adapter path alone: %d ViT blocks x {fc1 1024->4736, fc2 4736->1024}, M=%d rows: 64 x "
-                      "sam3_lora_pack + 64 x sam3_lora_fwd + 64 x sam3_lora_fwd (checkpoint recompute) + 64 x sam3_lora_bwd "
+              "what": "the adapter path alone: %d ViT blocks x {fc1 1024->4736, fc2 4736->1024}, M=%d rows: one "
+                      "sam3_lora_pack_many + 64 x sam3_lora_fwd + 64 x sam3_lora_fwd (checkpoint recompute) + 64 x sam3_lora_bwd "
                       "+ exchange; frozen GEMMs / attention / DETR / loss excluded" % (args.blocks, w.M)}
         if out is None:     # --adapter-only: the adapter path is the line
             out = {"metric": "images/sec through the LoRA adapter path (r=%d)" % args.rank, "value": ap["value"],

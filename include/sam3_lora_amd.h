@@ -88,6 +88,12 @@ size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_feature
 size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank, int dtype);
 int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, int out_features, int rank,
                    int layout, int dtype, void* stream);
+/* The same for `count` adapters at once (HOST tables of device pointers and of shapes; one layout and dtype): the
+ * images of up to 16 adapters are written per launch.  After an optimizer step every adapter of the model is stale;
+ * this re-packs the 64 adapters of the SAM3 trunk with 4 launches instead of 64. */
+int sam3_lora_pack_many(int count, const void* const* A, const void* const* B, void* const* packed,
+                        const int* in_features, const int* out_features, const int* rank, int layout, int dtype,
+                        void* stream);
 
 /*
  * Forward of the LoRA branch, fused with the residual add into the base output:

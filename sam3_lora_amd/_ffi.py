@@ -27,7 +27,7 @@ EXPORTS = (
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_aug_scatter", "sam3_lora_fused_workspace_bytes", "sam3_lora_fwd_fused", "sam3_lora_bwd_fused",
-    "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
+    "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
 )
 ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
@@ -58,6 +58,8 @@ def _declare(lib):
     lib.sam3_lora_packed_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.sam3_lora_pack.restype = c_int
     lib.sam3_lora_pack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.sam3_lora_pack_many.restype = c_int
+    lib.sam3_lora_pack_many.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.sam3_lora_fwd.restype = c_int
     lib.sam3_lora_fwd.argtypes = [
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,      # x, A, B, y_inout, tT_out

@@ -142,8 +142,9 @@ struct PackJob {
     int f32;
 };
 
+constexpr int PACK_JOBS_MAX = 64;    // 64 x 56 B of kernel arguments per launch
 struct PackJobs {
-    PackJob j[4];
+    PackJob j[PACK_JOBS_MAX];
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
@@ -1090,18 +1091,21 @@ struct ProfScope {
 };
 
 void launch_pack(const PackJob* jobs, int n, hipStream_t st) {
-    PackJobs pj;
-    long long nmax = 0;
-    int dim = 0;
-    for (int i = 0; i < 4; ++i) {
-        pj.j[i] = i < n ? jobs[i] : PackJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
-        const long long ne = (long long)pj.j[i].I * pj.j[i].J;
-        nmax = ne > nmax ? ne : nmax;
-        dim = pj.j[i].J > dim ? pj.j[i].J : dim;
+    for (int base = 0; base < n; base += PACK_JOBS_MAX) {       // one launch per 64 jobs (16 layers x 4 images)
+        const int cnt = n - base < PACK_JOBS_MAX ? n - base : PACK_JOBS_MAX;
+        PackJobs pj;
+        long long nmax = 0;
+        int dim = 0;
+        for (int i = 0; i < PACK_JOBS_MAX; ++i) {
+            pj.j[i] = i < cnt ? jobs[base + i] : PackJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+            const long long ne = (long long)pj.j[i].I * pj.j[i].J;
+            nmax = ne > nmax ? ne : nmax;
+            dim = pj.j[i].J > dim ? pj.j[i].J : dim;
+        }
+        dim3 grid((unsigned)((nmax + 255) / 256), (unsigned)cnt);
+        ProfScope ps(SAM3_LORA_STAGE_PACK, dim, st);
+        hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, pj);
     }
-    dim3 grid((unsigned)((nmax + 255) / 256), (unsigned)n);
-    ProfScope ps(SAM3_LORA_STAGE_PACK, dim, st);
-    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, pj);
 }
 void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
     const PackJob jobs[2] = {a, b};
@@ -1413,6 +1417,27 @@ size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank, int d
     return packed_total(in_features, out_features, rank, dtype);
 }
 
+// the pack jobs of one adapter (all rank groups) appended to `jobs`; returns the number appended
+static int pack_jobs_of(const void* A, const void* B, void* packed, int in_features, int out_features, int rank, int layout,
+                        int dtype, PackJob* jobs) {
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+    const int f32 = dtype == SAM3_LORA_F32;
+    char* p = (char*)packed;
+    int n = 0;
+    for (int g = 0; g < n_groups(rank); ++g) {
+        const int rg = group_rank(rank, g), RP = rpad(rg);
+        const PackedLayout pl = packed_layout(in_features, out_features, rg, dtype);
+        const float* Ag = (const float*)A + 32LL * g * s.a_sr;
+        const float* Bg = (const float*)B + 32LL * g * s.b_sr;
+        jobs[n++] = PackJob{Ag, p + pl.w1, RP, in_features, rg, in_features, s.a_sr, s.a_si, 0, f32};
+        jobs[n++] = PackJob{Bg, p + pl.w2t, out_features, RP, out_features, rg, s.b_so, s.b_sr, 0, f32};
+        jobs[n++] = PackJob{Bg, p + pl.w1b, RP, out_features, rg, out_features, s.b_sr, s.b_so, 0, f32};
+        jobs[n++] = PackJob{Ag, p + pl.w2tb, in_features, RP, in_features, rg, s.a_si, s.a_sr, 0, f32};
+        p += pl.total;
+    }
+    return n;
+}
+
 int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, int out_features, int rank, int layout,
                    int dtype, void* stream) {
     g_err[0] = 0;
@@ -1420,23 +1445,35 @@ int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, 
     if ((rc = check_common(1, in_features, out_features, rank, layout, dtype))) return rc;
     if (!A || !B || !packed) return fail(SAM3_LORA_EINVAL, "NULL pointer");
     if (((uintptr_t)packed & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
-    const Strides s = strides_of(layout, in_features, out_features, rank);
-    const int f32 = dtype == SAM3_LORA_F32;
-    char* p = (char*)packed;
-    for (int g = 0; g < n_groups(rank); ++g) {
-        const int rg = group_rank(rank, g), RP = rpad(rg);
-        const PackedLayout pl = packed_layout(in_features, out_features, rg, dtype);
-        const float* Ag = (const float*)A + 32LL * g * s.a_sr;
-        const float* Bg = (const float*)B + 32LL * g * s.b_sr;
-        const PackJob jobs[4] = {
-            {Ag, p + pl.w1, RP, in_features, rg, in_features, s.a_sr, s.a_si, 0, f32},
-            {Bg, p + pl.w2t, out_features, RP, out_features, rg, s.b_so, s.b_sr, 0, f32},
-            {Bg, p + pl.w1b, RP, out_features, rg, out_features, s.b_sr, s.b_so, 0, f32},
-            {Ag, p + pl.w2tb, in_features, RP, in_features, rg, s.a_si, s.a_sr, 0, f32}};
-        launch_pack(jobs, 4, (hipStream_t)stream);
-        p += pl.total;
-    }
+    PackJob* jobs = new PackJob[4 * (size_t)n_groups(rank)];
+    const int n = pack_jobs_of(A, B, packed, in_features, out_features, rank, layout, dtype, jobs);
+    launch_pack(jobs, n, (hipStream_t)stream);
+    delete[] jobs;
     return launch_ok("sam3_lora_pack");
+}
+
+int sam3_lora_pack_many(int count, const void* const* A, const void* const* B, void* const* packed,
+                        const int* in_features, const int* out_features, const int* rank, int layout, int dtype,
+                        void* stream) {
+    g_err[0] = 0;
+    if (count < 0) return fail(SAM3_LORA_EINVAL, "count must be >= 0");
+    if (count == 0) return 0;
+    if (!A || !B || !packed || !in_features || !out_features || !rank) return fail(SAM3_LORA_EINVAL, "NULL table");
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) {
+        int rc;
+        if ((rc = check_common(1, in_features[i], out_features[i], rank[i], layout, dtype))) return rc;
+        if (!A[i] || !B[i] || !packed[i]) return fail(SAM3_LORA_EINVAL, "NULL pointer in entry %d", i);
+        if (((uintptr_t)packed[i] & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned (entry %d)", i);
+        total += 4 * (size_t)n_groups(rank[i]);
+    }
+    PackJob* jobs = new PackJob[total];
+    int n = 0;
+    for (int i = 0; i < count; ++i)
+        n += pack_jobs_of(A[i], B[i], packed[i], in_features[i], out_features[i], rank[i], layout, dtype, jobs + n);
+    launch_pack(jobs, n, (hipStream_t)stream);
+    delete[] jobs;
+    return launch_ok("sam3_lora_pack_many");
 }
 
 // forward of one rank group.  A_g / B_g: the group's slice of the fp32 masters (strides `s` of the full tensors), or the

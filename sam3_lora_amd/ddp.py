@@ -29,7 +29,7 @@ import torch.distributed as dist
 class LoRAGradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
                  bucket_bytes: int = 16 << 20, average: bool = True, overlap: bool = True,
-                 broadcast_parameters: bool = True):
+                 broadcast_parameters: bool = True, run_collectives_alone: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("LoRAGradReducer: no trainable parameters")
@@ -40,6 +40,9 @@ class LoRAGradReducer:
         self.group = process_group
         self.average = average
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # world size 1 normally skips the exchange; `run_collectives_alone` issues it anyway (a 1-rank RCCL all-reduce is
+        # the identity) so that the whole side-stream path can be exercised on a single GPU
+        self.run_alone = bool(run_collectives_alone) and dist.is_initialized()
         self.overlap = overlap and dev.type == "cuda"
         # flat buffer, 64-element aligned slots, params in registration order
         offs, n = [], 0
@@ -131,7 +134,7 @@ class LoRAGradReducer:
         return hook
 
     def _launch(self, b: int):
-        if self._launched[b] or self.world_size == 1:
+        if self._launched[b] or (self.world_size == 1 and not self.run_alone):
             self._launched[b] = True
             return
         self._launched[b] = True

@@ -24,7 +24,7 @@ from . import _ffi
 from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
 __all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE",
-           "enable_direct_grad_accumulation"]
+           "enable_direct_grad_accumulation", "pack_operands_many", "repack_adapters"]
 
 _ws_lock = threading.Lock()
 _workspaces = {}  # (device index, stream handle) -> uint8 tensor
@@ -135,6 +135,66 @@ def pack_operands(A: torch.Tensor, B: torch.Tensor, layout: int, out: Optional[t
                             ctypes.c_void_p(torch.cuda.current_stream(A.device).cuda_stream))
     _ffi.check(rc, "sam3_lora_pack")
     return out
+
+
+def pack_operands_many(pairs, layout: int, dtype=torch.bfloat16, outs=None):
+    """:func:`pack_operands` for a list of ``(A, B)`` pairs of one layout with ONE C-ABI call (``sam3_lora_pack_many``:
+    the images of 16 adapters per launch).  ``outs``: blobs to overwrite (entries of the right size are reused)."""
+    lib = _ffi.load()
+    dt = _dt_of(dtype)
+    n = len(pairs)
+    if n == 0:
+        return []
+    outs = list(outs) if outs is not None else [None] * n
+    fins, fouts, ranks = [], [], []
+    for i, (A, B) in enumerate(pairs):
+        _require_cuda(A, B)
+        rank = _rank_of(A, layout)
+        fin = A.shape[0] if layout == LAYOUT_ROOT else A.shape[1]
+        fout = B.shape[1] if layout == LAYOUT_ROOT else B.shape[0]
+        nb = lib.sam3_lora_packed_bytes(fin, fout, rank, dt)
+        if nb == 0:
+            raise LoRAKernelError(f"sam3_lora_packed_bytes: {_ffi.last_error()}")
+        if outs[i] is None or outs[i].numel() != nb or outs[i].device != A.device:
+            outs[i] = torch.empty(nb, dtype=torch.uint8, device=A.device)
+        fins.append(fin), fouts.append(fout), ranks.append(rank)
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ints = lambda v: (ctypes.c_int * n)(*v)
+    dev = pairs[0][0].device
+    rc = lib.sam3_lora_pack_many(n, ptrs([a for a, _ in pairs]), ptrs([b for _, b in pairs]), ptrs(outs), ints(fins),
+                                 ints(fouts), ints(ranks), int(layout), dt,
+                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _ffi.check(rc, "sam3_lora_pack_many")
+    return outs
+
+
+def repack_adapters(model: torch.nn.Module) -> int:
+    """Refresh the cached operand images of every adapter of ``model`` in one batched call per (layout, dtype) -- call
+    it right after ``optimizer.step()``: every A / B just changed, and the lazy per-layer refresh would otherwise cost
+    one small launch per adapter in the next forward (64 for the SAM3 trunk).  Blobs are overwritten in place, so call
+    it between steps (no autograd graph of the previous step alive).  Returns the number of adapters packed."""
+    groups = {}
+    for m in model.modules():
+        lora = getattr(m, "lora", None)
+        base = getattr(m, "original_layer", None) or getattr(m, "linear", None)
+        cache = getattr(lora, "_packed", None)
+        if cache is None or base is None or not isinstance(cache, PackedOperands):
+            continue
+        A, B = lora.lora_A, lora.lora_B
+        if not (A.is_cuda and _is_master(A) and _is_master(B)) or base.weight.dtype not in (torch.bfloat16, torch.float32):
+            continue
+        layout = LAYOUT_ROOT if A.shape[1] == getattr(lora, "rank", -1) and A.shape[0] == base.in_features else LAYOUT_PACKAGE
+        if base.in_features % 8 or base.out_features % 8:
+            continue
+        groups.setdefault((layout, _dt_of(base.weight.dtype), A.device), []).append((cache, A, B))
+    total = 0
+    for (layout, dt, _), items in groups.items():
+        olds = [c._held.get(dt, (None, None))[1] for c, _, _ in items]
+        blobs = pack_operands_many([(_master(A), _master(B)) for _, A, B in items], layout, dtype=dt, outs=olds)
+        for (c, A, B), blob in zip(items, blobs):
+            c._held[dt] = ((A.data_ptr(), A._version, B.data_ptr(), B._version, layout, A.device), blob)
+        total += len(items)
+    return total
 
 
 class PackedOperands:

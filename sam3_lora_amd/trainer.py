@@ -234,6 +234,9 @@ class SAM3TrainerNative:
             self.optimizer.zero_grad(set_to_none=False)      # keep the .grad tensors: the kernels accumulate into them
             loss.backward()
         self.optimizer.step()
+        if self.device.type == "cuda":      # A / B just changed: refresh every adapter's operand images in one batch
+            from .functional import repack_adapters
+            repack_adapters(self.model)
         return loss.item()
 
     @torch.no_grad()

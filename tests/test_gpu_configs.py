@@ -195,3 +195,38 @@ def test_direct_grad_accumulation_equals_autograd_accumulation(dtype):
         assert len(seen) == 2 * len(params) and {id(p) for p in seen} == {id(p) for p in params}
     for a, b in zip(*grads):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (a - b).abs().max()
+
+
+def test_batched_pack_equals_per_adapter_pack_and_repack_adapters():
+    """sam3_lora_pack_many: byte-identical to sam3_lora_pack per adapter (mixed shapes and ranks, both dtypes); and
+    functional.repack_adapters refreshes every module cache after an optimizer-like update."""
+    import lora_layers as L
+    g = torch.Generator(device=DEV).manual_seed(0)
+    shapes = [(1024, 4736, 16), (4736, 1024, 16), (256, 256, 4), (64, 128, 40), (128, 64, 32)] * 5      # 25 adapters: 2 launches
+    pairs = [(torch.randn(fi, r, device=DEV, generator=g), torch.randn(r, fo, device=DEV, generator=g)) for fi, fo, r in shapes]
+    for td in (torch.bfloat16, torch.float32):
+        many = Fn.pack_operands_many(pairs, 0, dtype=td)
+        for (A, B), blob in zip(pairs, many):
+            assert torch.equal(blob, Fn.pack_operands(A, B, 0, dtype=td))
+    net = torch.nn.Sequential(*[L.LoRALinear(torch.nn.Linear(64, 64), rank=8, alpha=16) for _ in range(3)]).to(DEV)
+    with torch.no_grad():
+        for m in net:
+            m.lora.lora_B.normal_(0, 0.1)
+    x = torch.randn(10, 64, device=DEV)
+    y0 = net(x)
+    blobs0 = [m.lora._packed._held[Fn.DT_F32][1] for m in net]
+    with torch.no_grad():
+        for m in net:
+            m.lora.lora_B.mul_(0.5)
+    assert Fn.repack_adapters(net) == 3
+    for m, b0 in zip(net, blobs0):
+        stamp, blob = m.lora._packed._held[Fn.DT_F32]
+        assert blob is b0 and stamp[1] == m.lora.lora_A._version and stamp[3] == m.lora.lora_B._version    # refreshed in place
+    y1 = net(x)
+    for m, b0 in zip(net, blobs0):
+        assert m.lora._packed._held[Fn.DT_F32][1] is b0            # the forward found fresh images: no lazy re-pack
+    fresh = torch.nn.Sequential(*[L.LoRALinear(m.original_layer, rank=8, alpha=16) for m in net]).to(DEV)
+    with torch.no_grad():
+        for a, b in zip(fresh, net):
+            a.lora.lora_A.copy_(b.lora.lora_A), a.lora.lora_B.copy_(b.lora.lora_B)
+    assert torch.equal(fresh(x), y1) and not torch.equal(y0, y1)

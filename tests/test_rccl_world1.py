@@ -1,0 +1,25 @@
+"""The data-parallel exchange on the real backend: "nccl" = RCCL, world size 1 on the one GPU of the test box -- enough
+to load RCCL, create the communicator and run the reducer's side-stream all-reduces.  Runs in a
+subprocess so that the pytest process keeps no default process group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.gpu
+def test_reducer_runs_on_rccl_with_world_size_1():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run([sys.executable, os.path.join(HERE, "rccl_world1_worker.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["rccl_version"][0].isdigit()
+    assert r["params_unchanged_by_broadcast"] and r["buckets"] >= 2
+    assert r["allreduce_calls"] == r["buckets"] and r["all_on_side_stream_async"]
+    assert r["elements_reduced"] == r["flat_elements"]
+    assert r["grads_equal"] and r["scalar"] == 5.0
