@@ -34,6 +34,8 @@ PREPACKED = 0x100
 VIT_EXPORTS = ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd", "sam3_vit_qkv_rope_win_fwd",
                "sam3_vit_qkv_rope_win_bwd", "sam3_vit_win_residual", "sam3_vit_layernorm_fwd",
                "sam3_vit_layernorm_bwd", "sam3_vit_layernorm_bwd_add")      # include/sam3_vit_amd.h
+LOSS_EXPORTS = ("sam3_loss_last_error", "sam3_mask_loss_workspace_bytes", "sam3_mask_loss_fwd",
+                "sam3_mask_loss_bwd")                                          # include/sam3_loss_amd.h
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
 _lib = None
@@ -115,6 +117,16 @@ def _declare(lib):
     lib.sam3_vit_layernorm_bwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]
     lib.sam3_vit_layernorm_bwd_add.restype = c_int
     lib.sam3_vit_layernorm_bwd_add.argtypes = [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]
+    lib.sam3_loss_last_error.restype = c_char_p
+    lib.sam3_loss_last_error.argtypes = []
+    lib.sam3_mask_loss_workspace_bytes.restype = c_size_t
+    lib.sam3_mask_loss_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    lib.sam3_mask_loss_fwd.restype = c_int
+    lib.sam3_mask_loss_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                       c_int, c_void_p, c_size_t, c_void_p]
+    lib.sam3_mask_loss_bwd.restype = c_int
+    lib.sam3_mask_loss_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_float, c_int, c_int, c_void_p]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]
@@ -148,7 +160,7 @@ def load(path: str | None = None):
             lib = ctypes.CDLL(p)
         except OSError as e:  # missing libamdhip64 etc.
             raise LoRAKernelError(f"sam3_lora_amd: cannot load {p}: {e}") from e
-        missing = [s for s in EXPORTS + VIT_EXPORTS if not hasattr(lib, s)]
+        missing = [s for s in EXPORTS + VIT_EXPORTS + LOSS_EXPORTS if not hasattr(lib, s)]
         if missing:
             raise LoRAKernelError(f"sam3_lora_amd: {p} lacks symbols {missing}")
         _declare(lib)

@@ -65,6 +65,62 @@ def dice_loss(inputs: torch.Tensor, targets: torch.Tensor, num_boxes) -> torch.T
     return (1 - (num + 1) / (den + 1)).sum() / num_boxes
 
 
+class _MaskLossSums(torch.autograd.Function):
+    """``sums[n] = (sum focal, sum p t, sum p, sum t)`` over the target-resolution pixels of instance n, with the mask
+    logits bilinearly upsampled on the fly -- C-ABI ``sam3_mask_loss_fwd / _bwd`` (include/sam3_loss_amd.h).  The
+    upsampled [N, H, W] tensor is never materialised; the backward is a deterministic gather."""
+
+    @staticmethod
+    def forward(ctx, src, tgt, alpha, gamma):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        N, h, w = src.shape
+        H, W = tgt.shape[-2:]
+        src = src.contiguous()
+        tgt = tgt.contiguous()
+        if tgt.dtype != torch.bool:
+            tgt = tgt > 0.5
+        dt = 0 if src.dtype == torch.bfloat16 else 1
+        sums = torch.empty(N, 4, device=src.device, dtype=torch.float32)
+        nws = lib.sam3_mask_loss_workspace_bytes(N, H, W)
+        ws = torch.empty(nws, dtype=torch.uint8, device=src.device)
+        rc = lib.sam3_mask_loss_fwd(src.data_ptr(), tgt.data_ptr(), sums.data_ptr(), N, h, w, H, W, float(alpha), float(gamma),
+                                    dt, ws.data_ptr(), nws, ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_mask_loss_fwd failed ({rc}): {(lib.sam3_loss_last_error() or b'').decode()}")
+        ctx.save_for_backward(src, tgt)
+        ctx.meta = (float(alpha), float(gamma), dt)
+        return sums
+
+    @staticmethod
+    def backward(ctx, gsums):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        src, tgt = ctx.saved_tensors
+        alpha, gamma, dt = ctx.meta
+        N, h, w = src.shape
+        H, W = tgt.shape[-2:]
+        coef = gsums.detach().float().contiguous()
+        gsrc = torch.empty_like(src)
+        rc = lib.sam3_mask_loss_bwd(src.data_ptr(), tgt.data_ptr(), coef.data_ptr(), gsrc.data_ptr(), N, h, w, H, W, alpha,
+                                    gamma, dt, dt, ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_mask_loss_bwd failed ({rc}): {(lib.sam3_loss_last_error() or b'').decode()}")
+        return gsrc, None, None, None
+
+
+def mask_losses_fused(src: torch.Tensor, tgt: torch.Tensor, num_boxes, alpha: float, gamma: float):
+    """(loss_mask, loss_dice) of loss_fns.py:679-707 for matched mask logits ``src [N, h, w]`` (bf16 / fp32, on the GPU)
+    against boolean targets ``tgt [N, H, W]`` through the mask-loss kernels."""
+    H, W = tgt.shape[-2:]
+    s = _MaskLossSums.apply(src, tgt, alpha, gamma)
+    loss_mask = (s[:, 0] / float(H * W)).sum() / num_boxes
+    loss_dice = (1 - (2 * s[:, 1] + 1) / (s[:, 2] + s[:, 3] + 1)).sum() / num_boxes
+    return loss_mask, loss_dice
+
+
 # ------------------------------------------------------------------------------------------ weighted losses --
 class LossWithWeights(nn.Module):
     """A loss returns a dict of named terms; ``core_loss`` = sum of the terms listed in ``weight_dict``."""
@@ -185,6 +241,7 @@ class Masks(LossWithWeights):
         super().__init__(weight_dict, compute_aux)
         self.focal_alpha, self.focal_gamma = focal_alpha, focal_gamma
         self.target_keys += ["masks", "is_valid_mask"]
+        self.use_kernel = True        # GPU tensors go through the mask-loss kernels; False = the PyTorch formulation
 
     def get_loss(self, outputs, targets, indices, num_boxes):
         assert "pred_masks" in outputs and "is_valid_mask" in targets
@@ -193,7 +250,9 @@ class Masks(LossWithWeights):
             z = torch.tensor(0.0, device=src.device)
             return {"loss_mask": z, "loss_dice": z.clone()}
         b, s, t = indices
-        tgt = (targets["masks"] if t is None else targets["masks"][t]).to(src)
+        tgt = targets["masks"] if t is None else targets["masks"][t]
+        if not (src.is_cuda and self.use_kernel):
+            tgt = tgt.to(src)
         keep = targets["is_valid_mask"] if t is None else targets["is_valid_mask"][t]
         src = src[(b, s)][keep]
         tgt = tgt[keep]
@@ -201,6 +260,12 @@ class Masks(LossWithWeights):
             src = src.flatten(1)
             tgt = tgt.reshape(src.shape)
         else:
+            if (src.is_cuda and src.ndim == 3 and src.dtype in (torch.bfloat16, torch.float32) and src.shape[0] > 0
+                    and tgt.ndim == 3 and self.use_kernel):
+                # one HIP pass over the target resolution instead of upsample + ~20 elementwise passes (f-2)
+                lm, ld = mask_losses_fused(src, tgt > 0.5 if tgt.dtype != torch.bool else tgt, num_boxes,
+                                           self.focal_alpha, self.focal_gamma)
+                return {"loss_mask": lm, "loss_dice": ld}
             if src.ndim == 3:
                 src = src[:, None]
             if src.dtype == torch.bfloat16:

@@ -227,9 +227,12 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     vit_hdr = open(os.path.join(build.INCLUDE, "sam3_vit_amd.h")).read()
     vit_declared = set(re.findall(r"\b(sam3_vit_[a-z_]+)\s*\(", vit_hdr))
     assert vit_declared == set(_ffi.VIT_EXPORTS), vit_declared ^ set(_ffi.VIT_EXPORTS)
+    loss_hdr = open(os.path.join(build.INCLUDE, "sam3_loss_amd.h")).read()
+    loss_declared = set(re.findall(r"\b(sam3_(?:loss|mask_loss)_[a-z_]+)\s*\(", loss_hdr))
+    assert loss_declared == set(_ffi.LOSS_EXPORTS), loss_declared ^ set(_ffi.LOSS_EXPORTS)
     assert lib_has_packed_sizes()
     lib = ctypes.CDLL(path)
-    for sym in declared | vit_declared:
+    for sym in declared | vit_declared | loss_declared:
         assert hasattr(lib, sym), sym
     lib2 = _ffi.load()
     assert lib2.sam3_lora_abi_version() == 2

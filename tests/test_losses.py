@@ -69,3 +69,61 @@ def test_focal_and_dice_edge_cases():
             targets={"masks": torch.zeros(0, 16, 16, dtype=torch.bool), "is_valid_mask": torch.zeros(0, dtype=torch.bool)},
             indices=(e, e, None), num_boxes=1.0)
     assert float(out["loss_mask"]) == 0.0 and float(out["loss_dice"]) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("N,h,w,H,W", [(3, 16, 16, 40, 40), (5, 288, 288, 1008, 1008), (2, 20, 24, 70, 50), (1, 8, 8, 8, 8),
+                                       (4, 32, 32, 112, 112)])
+def test_mask_loss_kernels_match_the_pytorch_formulation(N, h, w, H, W, dtype):
+    """sam3_mask_loss_fwd / _bwd (upsample + focal + dice in one pass, gather backward) against F.interpolate + the
+    formulas of losses.py in fp32: both loss values to 2e-5 relative, the logit gradient to 2e-4 of its max (fp32
+    logits; bf16 logits: the same inputs rounded, the gradient rounded to bf16 -> 4e-3), bit-identical run to run."""
+    dev = "cuda:0"
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(N * 1000 + h)
+    src = (torch.randn(N, h, w, device=dev, generator=g) * 3).to(td)
+    tgt = torch.rand(N, H, W, device=dev, generator=g) > 0.6
+    tgt[0, : H // 2] = True                              # one large object: dice terms of very different sizes
+    nb = 2.0
+    for alpha, gamma in ((0.25, 2.0), (-1.0, 1.5)):
+        a = src.clone().requires_grad_(True)
+        lm, ld = LS.mask_losses_fused(a, tgt, nb, alpha, gamma)
+        (200.0 * lm + 10.0 * ld).backward()
+        b = src.float().clone().requires_grad_(True)
+        up = torch.nn.functional.interpolate(b[:, None], size=(H, W), mode="bilinear", align_corners=False)[:, 0].flatten(1)
+        t = tgt.flatten(1).float()
+        lm_ref = LS.sigmoid_focal_loss(up, t, nb, alpha=alpha, gamma=gamma)
+        ld_ref = LS.dice_loss(up, t, nb)
+        (200.0 * lm_ref + 10.0 * ld_ref).backward()
+        assert abs(lm.item() - lm_ref.item()) <= 2e-5 * abs(lm_ref.item()) + 1e-7, (lm.item(), lm_ref.item())
+        assert abs(ld.item() - ld_ref.item()) <= 2e-5 * abs(ld_ref.item()) + 1e-7, (ld.item(), ld_ref.item())
+        err = (a.grad.float() - b.grad).abs().max().item() / b.grad.abs().max().item()
+        assert err <= (2e-4 if dtype == "f32" else 4e-3), err
+        assert a.grad.dtype == td
+        a2 = src.clone().requires_grad_(True)
+        lm2, ld2 = LS.mask_losses_fused(a2, tgt, nb, alpha, gamma)
+        (200.0 * lm2 + 10.0 * ld2).backward()
+        assert lm2.item() == lm.item() and ld2.item() == ld.item() and torch.equal(a2.grad, a.grad)
+
+
+@pytest.mark.gpu
+def test_masks_loss_kernel_and_pytorch_paths_agree_in_the_loss_stack(golden_dir):
+    """The Masks loss inside the wrapper: kernel path (default on the GPU) against use_kernel = False."""
+    cfg = CLI_LOSS_CFG
+    res = []
+    for use_kernel in (True, False):
+        matcher = BinaryHungarianMatcherV2(**cfg["matcher"])
+        masks = LS.Masks(**cfg["masks"])
+        masks.use_kernel = use_kernel
+        leaves, targets = make_raw()
+        leaves = {k: v.to("cuda:0").requires_grad_(True) for k, v in leaves.items()}
+        targets = {k: v.to("cuda:0") for k, v in targets.items()}
+        out = assemble(leaves)
+        idx = matcher(out, targets)
+        d = masks(outputs=out, targets=targets, indices=idx, num_boxes=3.0)
+        d[LS.CORE_LOSS_KEY].backward()
+        res.append((d, leaves["main/masks"].grad.clone()))
+    for k in ("loss_mask", "loss_dice", LS.CORE_LOSS_KEY):
+        assert abs(float(res[0][0][k]) - float(res[1][0][k])) <= 2e-5 * abs(float(res[1][0][k]))
+    assert (res[0][1] - res[1][1]).abs().max() <= 2e-4 * res[1][1].abs().max()
