@@ -111,6 +111,14 @@ class _MaskLossSums(torch.autograd.Function):
         return gsrc, None, None, None
 
 
+def mask_kernels_support(h: int, w: int, H: int, W: int) -> bool:
+    """Tile geometry of csrc/loss_kernels.hip: a 32 x 64 target tile must need a logits patch of at most 48 x 80, an
+    8 x 16 logits block a target region of at most 64 x 96 -- any resize ratio between 1/2 and ~5 (SAM3: 3.5).  Outside
+    it the Masks loss uses the PyTorch formulation."""
+    sy, sx = h / H, w / W
+    return (32 * sy + 3) * (64 * sx + 3) <= 48 * 80 and (10 / sy + 3) * (18 / sx + 3) <= 64 * 96
+
+
 def mask_losses_fused(src: torch.Tensor, tgt: torch.Tensor, num_boxes, alpha: float, gamma: float):
     """(loss_mask, loss_dice) of loss_fns.py:679-707 for matched mask logits ``src [N, h, w]`` (bf16 / fp32, on the GPU)
     against boolean targets ``tgt [N, H, W]`` through the mask-loss kernels."""
@@ -251,8 +259,6 @@ class Masks(LossWithWeights):
             return {"loss_mask": z, "loss_dice": z.clone()}
         b, s, t = indices
         tgt = targets["masks"] if t is None else targets["masks"][t]
-        if not (src.is_cuda and self.use_kernel):
-            tgt = tgt.to(src)
         keep = targets["is_valid_mask"] if t is None else targets["is_valid_mask"][t]
         src = src[(b, s)][keep]
         tgt = tgt[keep]
@@ -261,7 +267,7 @@ class Masks(LossWithWeights):
             tgt = tgt.reshape(src.shape)
         else:
             if (src.is_cuda and src.ndim == 3 and src.dtype in (torch.bfloat16, torch.float32) and src.shape[0] > 0
-                    and tgt.ndim == 3 and self.use_kernel):
+                    and tgt.ndim == 3 and self.use_kernel and mask_kernels_support(*src.shape[-2:], *tgt.shape[-2:])):
                 # one HIP pass over the target resolution instead of upsample + ~20 elementwise passes (f-2)
                 lm, ld = mask_losses_fused(src, tgt > 0.5 if tgt.dtype != torch.bool else tgt, num_boxes,
                                            self.focal_alpha, self.focal_gamma)
@@ -272,6 +278,7 @@ class Masks(LossWithWeights):
                 src = src.float()
             src = F.interpolate(src, size=tgt.shape[-2:], mode="bilinear", align_corners=False)[:, 0].flatten(1)
             tgt = tgt.flatten(1).to(src.dtype)
+        tgt = tgt.to(src.dtype)
         return {"loss_mask": sigmoid_focal_loss(src, tgt, num_boxes, alpha=self.focal_alpha, gamma=self.focal_gamma),
                 "loss_dice": dice_loss(src, tgt, num_boxes)}
 
