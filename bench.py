@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--match-twice", action="store_true", help="also match inside the model's forward, as the reference does")
     ap.add_argument("--no-overlap", action="store_true", help="skip the exchange-overlap measurement (N > 1)")
     ap.add_argument("--full-only", action="store_true", help="only the whole-model step (profiling runs)")
+    ap.add_argument("--fp8-frozen", action="store_true",
+                    help="headline step with fp8 frozen-W base GEMMs (BASELINE configs[4] mode; default: measured as a sub-object)")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 frozen-W sub-measurement")
     ap.add_argument("--model", choices=["sam3", "tiny"], default="sam3",
                     help="tiny: the parity fixture's widths at 112^2 (contract tests only; the line says so)")
     return ap.parse_args()
@@ -666,6 +669,8 @@ def main():
     # ------------------------------------------------------------------ the headline: the whole training step
     full = None
     if not args.adapter_only:
+        from sam3_lora_amd.fp8 import enable_fp8_frozen
+        enable_fp8_frozen(bool(args.fp8_frozen))
         full = FullStep(dev, args.batch, args.rank, world, rank, dropout=args.dropout, act_checkpoint=args.act_checkpoint,
                         match_once=not args.match_twice, bf16=args.act_dtype == "bf16", kind=args.model)
         for _ in range(args.warmup):
@@ -691,6 +696,7 @@ def main():
                                        "mask focal + dice, o2m twins) + backward + A/B-gradient all-reduce + AdamW; frozen "
                                        "tensors and activations %s, A/B fp32; LoRA on the %d ViT-MLP Linears through the "
                                        "HIP adapter path; activation checkpointing %s; matching %s per step"
+                                       + ("; frozen base GEMMs in fp8 (e4m3 weights / activations, e5m2 gradients)" if args.fp8_frozen else "")
                                        % (args.rank, 2 * args.rank, args.batch, args.act_dtype, full.n_adapted,
                                           "on (per block / layer)" if full.ckpt else "off (activations kept in HBM)",
                                           "twice (model + loop, as the reference)" if args.match_twice else "once"),
@@ -714,6 +720,24 @@ def main():
             ov = overlap_measurement(full, world)
             if rank == 0:
                 out["exchange_overlap"] = ov
+        if not args.no_fp8 and not args.fp8_frozen and args.act_dtype == "bf16":
+            # BASELINE configs[4]'s mode on the same workload: frozen base GEMMs on the fp8 MFMA kernels
+            loss_bf16 = full.last_loss.item()
+            enable_fp8_frozen(True)
+            for _ in range(2):
+                full.step()
+            f_steps = max(3, min(args.steps, 6))
+            dtf = timed(full.step, f_steps)
+            if rank == 0:
+                out["fp8_frozen_w"] = {
+                    "value": round(world * args.batch * f_steps / dtf, 2), "unit": "images/s",
+                    "ms_per_step": round(dtf / f_steps * 1e3, 3), "steps": f_steps,
+                    "loss": round(full.last_loss.item(), 4), "loss_bf16_build": round(loss_bf16, 4),
+                    "finite": bool(torch.isfinite(full.last_loss).item()),
+                    "what": "the same whole training step with the frozen Linears' GEMMs in fp8 (weights e4m3 per-tensor scale, "
+                            "activations e4m3 / gradients e5m2 by the HIP quantiser with delayed scaling, hipBLASLt fp8 MFMA "
+                            "through torch._scaled_mm); LoRA branch bf16 / fp32 as before"}
+            enable_fp8_frozen(False)
         del full
         torch.cuda.empty_cache()
         if args.full_only:

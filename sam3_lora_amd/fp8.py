@@ -1,0 +1,111 @@
+"""
+"fp8 frozen-W" mode of the frozen Linears around the adapters (BASELINE.json configs[4]: "mixed fp8 frozen-W / bf16 LoRA,
+CDNA4 fp8 MFMA on base GEMMs").  A build-side extension -- the reference has no fp8 path.
+
+  W            stored once as OCP e4m3 with one scale per tensor (it never changes), plus its transpose for the
+               input-gradient GEMM;
+  activations  bf16 -> e4m3 (forward) / e5m2 (incoming gradients) by the HIP quantiser (C-ABI ``sam3_fp8_quantize``,
+               include/sam3_fp8_amd.h) with delayed scaling: a call scales with the amax its predecessor on the same
+               tensor role observed, and gathers the amax for its successor in the same pass;
+  GEMMs        hipBLASLt fp8 MFMA kernels through ``torch._scaled_mm`` (measured on MI355X at M = 41,472: fc1 429 -> 268 us,
+               fc2 317 -> 146 us, qkv 218 -> 126 us, proj 75 -> 48 us), bf16 out;
+  LoRA branch  unchanged: bf16 activations through the adapter kernels, fp32 A / B.
+
+Enabled per process with :func:`enable_fp8_frozen` (trainer: ``engine.fp8_frozen`` / ``--fp8-frozen``); only bf16 frozen
+Linears whose widths are multiples of 16 take the fp8 route, everything else keeps its bf16 GEMM.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from typing import Optional, Tuple
+
+import torch
+
+from . import _ffi
+
+__all__ = ["enable_fp8_frozen", "fp8_enabled", "fp8_linear", "fp8_dx", "Fp8Quantizer", "Fp8Weight", "state_for"]
+
+_STATE = {"on": False}
+_WEIGHTS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def enable_fp8_frozen(on: bool = True) -> None:
+    _STATE["on"] = bool(on)
+    if not on:
+        _WEIGHTS.clear()
+
+
+def fp8_enabled() -> bool:
+    return _STATE["on"]
+
+
+class Fp8Quantizer:
+    """One tensor role (e.g. "input of fc1"): delayed-scaling state + the quantise call."""
+
+    def __init__(self, fmt: int):
+        self.fmt = fmt
+        self.amax = None            # two device scalars used alternately: [read by this call, written for the next]
+        self.scale = None
+        self.k = 0
+
+    def __call__(self, x2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        lib = _ffi.load()
+        if self.amax is None or self.amax[0].device != x2.device:
+            self.amax = [torch.zeros(1, device=x2.device), torch.zeros(1, device=x2.device)]
+            self.scale = torch.empty(1, device=x2.device)
+            self.amax[0].copy_(x2.detach().abs().max().float())       # first call: calibrate on the tensor itself
+            self.k = 0
+        cur, nxt = self.amax[self.k], self.amax[1 - self.k]
+        nxt.zero_()
+        fdt = torch.float8_e4m3fn if self.fmt == _ffi.FP8_E4M3 else torch.float8_e5m2
+        out = torch.empty(x2.shape, dtype=fdt, device=x2.device)
+        rc = lib.sam3_fp8_quantize(x2.data_ptr(), out.data_ptr(), cur.data_ptr(), nxt.data_ptr(), self.scale.data_ptr(),
+                                   x2.numel(), 0 if x2.dtype == torch.bfloat16 else 1, self.fmt,
+                                   ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_fp8_quantize failed ({rc}): {(lib.sam3_fp8_last_error() or b'').decode()}")
+        self.k ^= 1
+        return out, self.scale
+
+
+class Fp8Weight:
+    """The frozen weight of one Linear in e4m3 (+ transpose), its scale, and the two activation quantisers."""
+
+    def __init__(self, w: torch.Tensor):
+        amax = w.detach().abs().max().float().clamp(min=2.0 ** -24)
+        self.scale = (amax / 448.0).reshape(1)
+        wq = (w.detach().float() / self.scale).clamp(-448.0, 448.0)
+        self.wq = wq.to(torch.float8_e4m3fn)                                  # [N, K]
+        self.wtq = wq.t().contiguous().to(torch.float8_e4m3fn)                # [K, N] for gy @ W
+        self.qx = Fp8Quantizer(_ffi.FP8_E4M3)
+        self.qg = Fp8Quantizer(_ffi.FP8_E5M2)
+        self.stamp = (w.data_ptr(), w._version)
+
+
+def eligible(x2: torch.Tensor, w: torch.Tensor) -> bool:
+    return (_STATE["on"] and x2.is_cuda and x2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and not w.requires_grad
+            and x2.dim() == 2 and x2.shape[0] > 0 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 and x2.is_contiguous()
+            and not torch.is_autocast_enabled("cuda"))
+
+
+def state_for(w: torch.Tensor) -> Fp8Weight:
+    st = _WEIGHTS.get(w)
+    if st is None or st.stamp != (w.data_ptr(), w._version):
+        st = Fp8Weight(w)
+        _WEIGHTS[w] = st
+    return st
+
+
+def fp8_linear(x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """``F.linear(x2, w, b)`` with e4m3 operands on the fp8 MFMA GEMM, bf16 out."""
+    st = state_for(w)
+    xq, sx = st.qx(x2)
+    return torch._scaled_mm(xq, st.wq.t(), scale_a=sx, scale_b=st.scale, bias=b, out_dtype=torch.bfloat16)
+
+
+def fp8_dx(gy2: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``gy2 @ w`` with the gradient in e5m2 and the weight in e4m3."""
+    st = state_for(w)
+    gq, sg = st.qg(gy2)
+    return torch._scaled_mm(gq, st.wtq.t(), scale_a=sg, scale_b=st.scale, out_dtype=torch.bfloat16)

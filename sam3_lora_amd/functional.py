@@ -238,8 +238,19 @@ class TransposedCopy:
         return self.t
 
 
+def _frozen_fwd(x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """The frozen layer's GEMM ``x2 @ w^T + b``: hipBLASLt bf16 / fp32, or the fp8 route of sam3_lora_amd.fp8 when enabled."""
+    from . import fp8
+    if fp8.eligible(x2, w):
+        return fp8.fp8_linear(x2, w, b)
+    return F.linear(x2, w, b)
+
+
 def _dx(gy2: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor]) -> torch.Tensor:
     """Input gradient of a frozen linear: ``gy2 @ w``, through the transposed copy when one of gy2's dtype is at hand."""
+    from . import fp8
+    if fp8.eligible(gy2, w):
+        return fp8.fp8_dx(gy2, w)
     if wt is not None and wt.dtype == gy2.dtype and wt.shape == (w.shape[1], w.shape[0]):
         return F.linear(gy2, wt)
     return gy2 @ w
@@ -251,21 +262,29 @@ class _FrozenLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, wt):
         ctx.save_for_backward(weight, wt)
-        return F.linear(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1])
+        return _frozen_fwd(x2 if x2.is_contiguous() else x2.contiguous(), weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
         weight, wt = ctx.saved_tensors
         gy2 = gy.reshape(-1, gy.shape[-1])
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
         return _dx(gy2, weight, wt).view(*gy.shape[:-1], weight.shape[1]), None, None, None
 
 
 def frozen_linear(x: torch.Tensor, lin: torch.nn.Linear, cache: TransposedCopy) -> torch.Tensor:
     """``lin(x)``; a CUDA Linear with frozen parameters (and no autocast) gets the TN-form backward."""
     w = lin.weight
-    if (x.is_cuda and not w.requires_grad and (lin.bias is None or not lin.bias.requires_grad) and x.dtype == w.dtype
-            and x.requires_grad and torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda")):
-        return _FrozenLinearFn.apply(x, w, lin.bias, cache.get(w))
+    from . import fp8
+    frozen = x.is_cuda and not w.requires_grad and (lin.bias is None or not lin.bias.requires_grad) and x.dtype == w.dtype \
+        and not torch.is_autocast_enabled("cuda")
+    if frozen and x.requires_grad and torch.is_grad_enabled():
+        return _FrozenLinearFn.apply(x, w, lin.bias, None if fp8.fp8_enabled() else cache.get(w))
+    if frozen and fp8.fp8_enabled():        # no gradient needed (first block, eval): still the fp8 GEMM
+        x2 = x.reshape(-1, x.shape[-1])
+        return _frozen_fwd(x2 if x2.is_contiguous() else x2.contiguous(), w, lin.bias).view(*x.shape[:-1], w.shape[0])
     return lin(x)
 
 
@@ -419,7 +438,7 @@ class _LoRALinearFn(torch.autograd.Function):
             y2 = x2.new_zeros(x2.shape[0], fout)
         else:
             with torch.autocast("cuda", enabled=False):
-                y2 = F.linear(x2, w, b)                  # frozen GEMM: PyTorch-ROCm / hipBLASLt
+                y2 = _frozen_fwd(x2, w, b)               # frozen GEMM: PyTorch-ROCm / hipBLASLt
         Am, Bm = _master(A), _master(B)
         need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         fin, fout = x2.shape[1], y2.shape[1]
@@ -507,12 +526,12 @@ class _LoRAMlpFn(torch.autograd.Function):
         x2 = _rows(x if x.dtype == cdt else x.to(cdt))
         need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
         with torch.autocast("cuda", enabled=False):
-            h = F.linear(x2, W1, b1)
+            h = _frozen_fwd(x2, W1, b1)
         a = torch.empty_like(h)
         t1 = lora_fwd_(x2, _master(A1), _master(B1), h, s1, layout, save_t=need_w, drop_p=drop_p, seed=seed1, packed=pk1,
                        gelu_out=a)
         with torch.autocast("cuda", enabled=False):
-            y = F.linear(a, W2, b2)
+            y = _frozen_fwd(a, W2, b2)
         t2 = lora_fwd_(a, _master(A2), _master(B2), y, s2, layout, save_t=need_w, drop_p=drop_p, seed=seed2, packed=pk2)
         ctx.meta = (s1, s2, layout, drop_p, seed1, seed2, x.shape, x.dtype)
         ctx.pk = (pk1, pk2)

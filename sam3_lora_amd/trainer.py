@@ -193,6 +193,11 @@ class SAM3TrainerNative:
         if bf16_frozen:         # MI355X layout: frozen tensors bf16, A/B fp32 masters (not a reference behaviour)
             from .vit import to_training_layout
             to_training_layout(self.model)
+        if engine.get("fp8_frozen", False):     # fp8 frozen-W base GEMMs (BASELINE configs[4]); needs the bf16 layout
+            if not bf16_frozen:
+                raise ValueError("engine.fp8_frozen requires engine.bf16_frozen (fp8 operands are cut from bf16 tensors)")
+            from .fp8 import enable_fp8_frozen
+            enable_fp8_frozen(True)
         if act_checkpoint != "keep":   # "auto" | "on" | "off" for this library's ViT trunk (vit.set_activation_checkpointing)
             from .vit import set_activation_checkpointing
             mode = {"on": True, "off": False}.get(act_checkpoint, "auto")
