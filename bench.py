@@ -695,11 +695,11 @@ def main():
                                        "matching (final + 5 aux outputs) + Sam3LossWrapper (boxes, IA-BCE + presence, "
                                        "mask focal + dice, o2m twins) + backward + A/B-gradient all-reduce + AdamW; frozen "
                                        "tensors and activations %s, A/B fp32; LoRA on the %d ViT-MLP Linears through the "
-                                       "HIP adapter path; activation checkpointing %s; matching %s per step"
-                                       + ("; frozen base GEMMs in fp8 (e4m3 weights / activations, e5m2 gradients)" if args.fp8_frozen else "")
+                                       "HIP adapter path; activation checkpointing %s; matching %s per step%s"
                                        % (args.rank, 2 * args.rank, args.batch, args.act_dtype, full.n_adapted,
                                           "on (per block / layer)" if full.ckpt else "off (activations kept in HBM)",
-                                          "twice (model + loop, as the reference)" if args.match_twice else "once"),
+                                          "twice (model + loop, as the reference)" if args.match_twice else "once",
+                                          "; frozen base GEMMs in fp8 (e4m3 weights / activations, e5m2 gradients)" if args.fp8_frozen else ""),
                            "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                            "grad_allreduce_bytes": full.reducer.nbytes, "finite": finite,
                            "loss": round(full.last_loss.item(), 4), "adapted_modules": full.n_adapted,

@@ -27,7 +27,7 @@ from . import _ffi
 __all__ = ["enable_fp8_frozen", "fp8_enabled", "fp8_linear", "fp8_dx", "Fp8Quantizer", "Fp8Weight", "state_for"]
 
 _STATE = {"on": False}
-_WEIGHTS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_WEIGHTS = {}          # id(weight) -> (weakref to the weight, Fp8Weight); tensors compare element-wise, so not a dict key
 
 
 def enable_fp8_frozen(on: bool = True) -> None:
@@ -90,11 +90,13 @@ def eligible(x2: torch.Tensor, w: torch.Tensor) -> bool:
 
 
 def state_for(w: torch.Tensor) -> Fp8Weight:
-    st = _WEIGHTS.get(w)
-    if st is None or st.stamp != (w.data_ptr(), w._version):
+    key = id(w)
+    held = _WEIGHTS.get(key)
+    if held is None or held[0]() is not w or held[1].stamp != (w.data_ptr(), w._version):
         st = Fp8Weight(w)
-        _WEIGHTS[w] = st
-    return st
+        _WEIGHTS[key] = (weakref.ref(w, lambda _, k=key: _WEIGHTS.pop(k, None)), st)
+        return st
+    return held[1]
 
 
 def fp8_linear(x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:

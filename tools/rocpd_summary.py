@@ -15,6 +15,7 @@ import sys
 
 def short(name: str, n: int = 70) -> str:
     name = re.sub(r"^void\s+", "", name)
+    name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
     name = name.replace("unsigned short", "bf16").replace("long long", "i64")
     return name if len(name) <= n else name[: n - 3] + "..."
