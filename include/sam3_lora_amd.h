@@ -22,8 +22,11 @@
  *     functions.  It may be reused by the next call on the same stream.
  *   - return value: 0 on success, a negative SAM3_LORA_E* code otherwise; the calling thread
  *     can read a description from sam3_lora_last_error() (thread-local).  No C++ exception
- *     crosses this boundary.  Entry points are thread-safe and keep no thread-affine state
- *     (PyTorch runs backward, and the activation-checkpoint recompute, on other threads).
+ *     crosses this boundary.  The compute entry points are thread-safe and keep no thread-affine state
+ *     (PyTorch runs backward, and the activation-checkpoint recompute, on other threads); the
+ *     only process-wide state belongs to the profiling / debugging aids at the end of this file
+ *     (stage mask, in-situ timer, tuning knobs read once from the environment), which are not
+ *     meant to be used concurrently with training.
  *   - LoRA parameters A and B are the fp32 master tensors in the layout of the reference
  *     module they come from:
  *         SAM3_LORA_LAYOUT_ROOT    (0): A[in, r],  B[r, out]   lora_layers.py:38-39
@@ -207,6 +210,11 @@ int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, con
 #define SAM3_LORA_STAGE_GT_REDUCE 64u /* k_gt_reduce : chunk sum of the gt partials k_t3 emitted (r <= 16)  */
 #define SAM3_LORA_STAGE_ALL 0xffffffffu
 unsigned sam3_lora_debug_set_stages(unsigned mask);
+
+/* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
+ * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS) are read from the environment once, at the first launch; this
+ * re-reads them (tests that flip a knob between calls). */
+void sam3_lora_debug_reload_knobs(void);
 
 /*
  * In-situ kernel timer (profiling aid): between prof_start and prof_stop every launch of a stage in

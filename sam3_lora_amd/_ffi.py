@@ -24,7 +24,7 @@ MAX_RANK = 1024
 EXPORTS = (
     "sam3_lora_abi_version", "sam3_lora_last_error", "sam3_lora_saved_t_bytes",
     "sam3_lora_fwd_workspace_bytes", "sam3_lora_bwd_workspace_bytes",
-    "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages",
+    "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages", "sam3_lora_debug_reload_knobs",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_aug_scatter", "sam3_lora_fused_workspace_bytes", "sam3_lora_fwd_fused", "sam3_lora_bwd_fused",
     "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
@@ -85,6 +85,8 @@ def _declare(lib):
     lib.sam3_lora_fwd_act.argtypes = list(lib.sam3_lora_fwd.argtypes) + [c_int, c_void_p, c_int64]
     lib.sam3_lora_bwd_act.restype = c_int
     lib.sam3_lora_bwd_act.argtypes = list(lib.sam3_lora_bwd.argtypes) + [c_int, c_void_p, c_int64]
+    lib.sam3_lora_debug_reload_knobs.restype = None
+    lib.sam3_lora_debug_reload_knobs.argtypes = []
     lib.sam3_lora_debug_set_stages.restype = ctypes.c_uint
     lib.sam3_lora_debug_set_stages.argtypes = [ctypes.c_uint]
     lib.sam3_lora_prof_start.restype = c_int

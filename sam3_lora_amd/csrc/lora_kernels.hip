@@ -27,8 +27,10 @@
 //     hardware transpose read.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "sam3_lora_amd.h"
@@ -1041,13 +1043,39 @@ DropKey make_dropkey(float p, uint64_t seed, uint64_t offset, int width, float* 
     return dk;
 }
 
+// Tuning / validation knobs come from the environment ONCE (first use, or sam3_lora_debug_reload_knobs): no getenv on
+// the launch path.  Seven names, looked up by pointer-stable literals through a tiny table.
+struct Knob {
+    const char* name;
+    bool set;
+    long long value;
+};
+Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", false, 0},   {"SAM3_LORA_T1_NO_SPLIT", false, 0},
+                  {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
+                  {"SAM3_LORA_TWO_PASS_GY", false, 0}};
+std::atomic<bool> g_knobs_loaded{false};
+void load_knobs() {
+    for (Knob& k : g_knobs) {
+        const char* v = getenv(k.name);
+        k.set = v && v[0];
+        k.value = k.set ? atoll(v) : 0;
+        if (k.set && k.value == 0 && v[0] != '0') k.value = 1;      // non-numeric text counts as "on"
+    }
+    g_knobs_loaded.store(true, std::memory_order_release);
+}
+const Knob* knob(const char* name) {
+    if (!g_knobs_loaded.load(std::memory_order_acquire)) load_knobs();
+    for (const Knob& k : g_knobs)
+        if (!strcmp(k.name, name)) return &k;
+    return nullptr;
+}
 bool env_flag(const char* name) {
-    const char* v = getenv(name);
-    return v && v[0] && v[0] != '0';
+    const Knob* k = knob(name);
+    return k && k->set && k->value != 0;
 }
 long long env_int(const char* name, long long dflt) {
-    const char* v = getenv(name);
-    return (v && v[0]) ? atoll(v) : dflt;
+    const Knob* k = knob(name);
+    return (k && k->set) ? k->value : dflt;
 }
 
 // strides of the canonical views A_c[in, r], B_c[r, out] inside the caller's tensors
@@ -1351,6 +1379,8 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
 extern "C" {
 
 int sam3_lora_abi_version(void) { return SAM3_LORA_ABI_VERSION; }
+
+void sam3_lora_debug_reload_knobs(void) { load_knobs(); }
 
 unsigned sam3_lora_debug_set_stages(unsigned mask) {
     const unsigned old = g_stages;

@@ -42,6 +42,22 @@ def _relmax(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
+def _reload_knobs():
+    """The library reads its tuning knobs from the environment once; tests that flip one re-read them."""
+    from sam3_lora_amd import _ffi
+    _ffi.load().sam3_lora_debug_reload_knobs()
+
+
+@pytest.fixture(autouse=True)
+def _knobs_back_to_environment():
+    yield
+    if torch.cuda.is_available():
+        import os
+        for k in ("SAM3_LORA_T3_GATHER", "SAM3_LORA_TWO_PASS_GY", "SAM3_LORA_T1_NO_SPLIT"):
+            os.environ.pop(k, None)
+        _reload_knobs()
+
+
 def _golden(golden_dir, name):
     return np.load(os.path.join(golden_dir, f"adapter_{name}.npz"))
 
@@ -136,6 +152,7 @@ def test_t3_transpose_read_equals_gather(gather, monkeypatch):
     outs = []
     for flag in ("0", gather):
         monkeypatch.setenv("SAM3_LORA_T3_GATHER", flag)
+        _reload_knobs()
         gA, gB = torch.zeros_like(A), torch.zeros_like(B)
         Fn.lora_bwd_(gy, x, None, A, B, None, gA, gB, c["scaling"], c["layout"])
         outs.append((gA.clone(), gB.clone()))
@@ -505,6 +522,7 @@ def test_one_pass_backward_matches_two_pass(shape, dtype, monkeypatch):
     for mode in ("one", "two"):
         if mode == "two":
             monkeypatch.setenv("SAM3_LORA_TWO_PASS_GY", "1")
+            _reload_knobs()
         y = torch.zeros(M, fout, device=DEV, dtype=td)
         tT = Fn.lora_fwd_(x, A, B, y, 2.0, cases.LAYOUT_ROOT, save_t=True)
         gx = torch.zeros(M, fin, device=DEV, dtype=td)
@@ -625,6 +643,7 @@ def test_small_m_split_k_row_reduction(M, K, drop, dtype, monkeypatch):
     for mode in ("split", "split2", "plain"):
         if mode == "plain":
             monkeypatch.setenv("SAM3_LORA_T1_NO_SPLIT", "1")
+            _reload_knobs()
         y = torch.zeros(M, 256, device=DEV, dtype=td)
         tT = Fn.lora_fwd_(x, A, B, y, 2.0, cases.LAYOUT_ROOT, save_t=True, drop_p=drop, seed=5)
         outs[mode] = (y.float().cpu().numpy(), tT.clone())

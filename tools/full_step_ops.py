@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""torch.profiler view of the whole training step: top operators by GPU time, grouped by input shapes (which PyTorch
+op, on which tensor, costs what).  Usage (GPU box): python tools/full_step_ops.py [--fp8]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+import bench
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fp8", action="store_true")
+    ap.add_argument("--rows", type=int, default=45)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if a.fp8:
+        from sam3_lora_amd.fp8 import enable_fp8_frozen
+        enable_fp8_frozen(True)
+    full = bench.FullStep(dev, 8, 16, 1, 0)
+    for _ in range(3):
+        full.step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(2):
+            full.step()
+        torch.cuda.synchronize()
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=a.rows,
+                                                              max_name_column_width=48, max_shapes_column_width=70))
+
+
+if __name__ == "__main__":
+    main()
