@@ -265,7 +265,10 @@ class TransformerEncoderFusion(nn.Module):
             def run(t, m, mkpm, qp, layer=layer):
                 return layer(t, m, memory_key_padding_mask=mkpm, query_pos=qp, **extra)
             out = _maybe_checkpoint(ckpt, run, out, memory_bf, prompt_key_padding_mask, query_pos)
-        return {"memory": out.transpose(0, 1), "padding_mask": None, "pos_embed": query_pos.transpose(0, 1),
+        # sequence-first and CONTIGUOUS: the decoder and the mask head feed these to Linears six times over; on a transposed
+        # view every such Linear runs as a 5184-batch bmm and every add as a strided elementwise kernel
+        return {"memory": out.transpose(0, 1).contiguous(), "padding_mask": None,
+                "pos_embed": query_pos.transpose(0, 1).contiguous(),
                 "memory_text": prompt, "level_start_index": level_start, "spatial_shapes": shapes,
                 "valid_ratios": valid_ratios}
 
@@ -304,7 +307,7 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, tgt_query_pos, memory_text, text_attention_mask, memory, memory_pos, cross_attn_mask,
                 presence_token=None, dac: bool = False, dac_use_selfatt_ln: bool = True, self_attn_mask=None,
-                memory_key_padding_mask=None, mask_has_presence_row: bool = False):
+                memory_key_padding_mask=None, mask_has_presence_row: bool = False, memory_key=None):
         """tgt / tgt_query_pos [Q, B, C]; memory [HW, B, C]; cross_attn_mask [B*heads, Q (+1), HW] additive
         (``mask_has_presence_row``: the caller already put the presence token's all-zero row in front)."""
         o2m = None
@@ -337,7 +340,9 @@ class TransformerDecoderLayer(nn.Module):
         if presence_token is not None and not mask_has_presence_row:
             # the presence token attends to the image without a position bias
             cross_attn_mask = torch.cat([torch.zeros_like(cross_attn_mask[:, :1, :]), cross_attn_mask], dim=1)
-        h = self.cross_attn(query=tgt + tgt_query_pos, key=memory + memory_pos, value=memory,
+        # memory_key: memory + memory_pos, the same for all layers -- computed once by the decoder
+        h = self.cross_attn(query=tgt + tgt_query_pos, key=memory + memory_pos if memory_key is None else memory_key,
+                            value=memory,
                             attn_mask=cross_attn_mask,
                             key_padding_mask=(memory_key_padding_mask.transpose(0, 1)
                                               if memory_key_padding_mask is not None else None))[0]
@@ -468,6 +473,7 @@ class TransformerDecoder(nn.Module):
         presence = self.presence_token.weight[None].expand(1, bs, -1) if self.presence_token is not None else None
         ckpt = self.training and self.use_act_checkpoint and torch.is_grad_enabled()
         ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[None, :].float()   # [1, B, levels, 4]
+        memory_key = memory + pos if pos is not None else memory                  # the cross-attention key of every layer
         feat_hw = None
         if self.boxRPB != "none":
             assert spatial_shapes.shape[0] == 1, "only single scale support implemented"
@@ -479,13 +485,13 @@ class TransformerDecoder(nn.Module):
                 memory_mask = self._get_rpb_matrix(reference_boxes, feat_hw, presence_row=presence is not None)
                 memory_mask = memory_mask.flatten(0, 1)                           # [B*heads, Q (+1), HW]
 
-            def run(out, qpos, mtext, tmask, mem, mpos, cmask, ptok, layer=layer):
+            def run(out, qpos, mtext, tmask, mem, mpos, cmask, ptok, mkey, layer=layer):
                 return layer(out, qpos, mtext, tmask, mem, mpos, cmask, presence_token=ptok, dac=apply_dac,
                              dac_use_selfatt_ln=self.dac_use_selfatt_ln, self_attn_mask=tgt_mask,
                              memory_key_padding_mask=memory_key_padding_mask,
-                             mask_has_presence_row=self.boxRPB != "none" and ptok is not None)
+                             mask_has_presence_row=self.boxRPB != "none" and ptok is not None, memory_key=mkey)
             output, presence = _maybe_checkpoint(ckpt, run, output, query_pos, memory_text, text_attention_mask, memory,
-                                                 pos, memory_mask, presence)
+                                                 pos, memory_mask, presence, memory_key)
             normed = self.norm(output)
             delta = self.bbox_embed(normed if self.use_normed_output_consistently else output).float()
             refined = (delta + inverse_sigmoid(reference_boxes)).sigmoid()

@@ -161,11 +161,17 @@ class Sam3Image(nn.Module):
     def _get_img_feats(self, backbone_out: Dict, img_ids: torch.Tensor):
         """Per-prompt image tokens: ``([HW, N, C] per level, position codes likewise, (H, W) per level)``."""
         assert "backbone_fpn" in backbone_out, "image features are computed once per batch in forward()"
+        cached = backbone_out.get("_token_cache")
+        if cached is not None and cached[0] is img_ids:
+            return (backbone_out,) + cached[1]
         feats = backbone_out["backbone_fpn"][-self.num_feature_levels:]
         codes = backbone_out["vision_pos_enc"][-self.num_feature_levels:]
         sizes = [c.shape[-2:] for c in codes]
-        tokens = [f[img_ids].flatten(2).permute(2, 0, 1) for f in feats]
-        token_pos = [c[img_ids].flatten(2).permute(2, 0, 1) for c in codes]
+        # contiguous [HW, N, C]: these feed LayerNorm / Linear / attention of the geometry and fusion encoders; as
+        # permuted views of [N, C, HW] every one of those would run on its strided slow path.  Built once per forward.
+        tokens = [f[img_ids].flatten(2).permute(2, 0, 1).contiguous() for f in feats]
+        token_pos = [c[img_ids].flatten(2).permute(2, 0, 1).contiguous() for c in codes]
+        backbone_out["_token_cache"] = (img_ids, (tokens, token_pos, sizes))
         return backbone_out, tokens, token_pos, sizes
 
     def _encode_prompt(self, backbone_out, find_input, geometric_prompt, encode_text: bool = True):
