@@ -176,7 +176,8 @@ class ResidualAttentionBlock(nn.Module):
     def __init__(self, d_model: int, n_head: int, mlp_ratio: float = 4.0, ls_init_value: Optional[float] = None,
                  act_layer: Callable[[], nn.Module] = nn.GELU, norm_layer: Callable[[int], nn.Module] = nn.LayerNorm):
         super().__init__()
-        self.attn = nn.MultiheadAttention(d_model, n_head, batch_first=True)
+        from .sam3_detr import MultiheadAttention      # same module, evaluated without transposed-view projections
+        self.attn = MultiheadAttention(d_model, n_head, batch_first=True)
         self.ln_1 = norm_layer(d_model)
         self.ln_2 = norm_layer(d_model)
         self.ls_1 = LayerScale(d_model, ls_init_value) if ls_init_value is not None else nn.Identity()

@@ -241,3 +241,63 @@ def test_bf16_training_layout_tracks_reference_curve(gold):
     ref = gold["losses"]
     rel = np.abs(np.array(losses) - ref) / np.abs(ref)
     assert rel.max() <= 2e-2, f"bf16 loss curve {losses} vs reference {ref.tolist()} (rel {rel})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch_first", [True, False])
+@pytest.mark.parametrize("case", ["self", "q_is_k", "k_is_v", "distinct"])
+@pytest.mark.parametrize("masking", ["none", "float3d", "float2d", "bool2d", "padding", "float3d+padding", "bool2d+padding"])
+def test_fast_multihead_attention_equals_the_stock_module(batch_first, case, masking):
+    """sam3_detr.MultiheadAttention.forward against nn.MultiheadAttention.forward on the same parameters: outputs and
+    gradients (inputs and parameters), fp32, every way the model calls it."""
+    import torch.nn as nn
+    from sam3_lora_amd.sam3_detr import MultiheadAttention
+    dev = "cuda:0"
+    torch.manual_seed(hash((batch_first, case, masking)) % 1000)
+    B, H, E, Lq = 3, 4, 64, 10
+    Lk = Lq if case in ("self", "q_is_k") else 17
+    fast = MultiheadAttention(E, H, batch_first=batch_first).to(dev)
+    stock = nn.MultiheadAttention(E, H, batch_first=batch_first).to(dev)
+    stock.load_state_dict(fast.state_dict())
+    shp = (lambda L: (B, L, E)) if batch_first else (lambda L: (L, B, E))
+
+    def inputs():
+        g = torch.Generator(device=dev).manual_seed(5)
+        a = torch.randn(shp(Lq), device=dev, generator=g).requires_grad_(True)
+        b = torch.randn(shp(Lk), device=dev, generator=g).requires_grad_(True)
+        c = torch.randn(shp(Lk), device=dev, generator=g).requires_grad_(True)
+        if case == "self":
+            return (a, a, a), [a]
+        if case == "q_is_k":
+            qk = a + 0.5
+            return (qk, qk, a), [a]
+        if case == "k_is_v":
+            return (a, b, b), [a, b]
+        return (a, b, c), [a, b, c]
+
+    g = torch.Generator(device=dev).manual_seed(7)
+    kw = {}
+    if "float3d" in masking:
+        kw["attn_mask"] = torch.randn(B * H, Lq, Lk, device=dev, generator=g)
+    if "float2d" in masking:
+        kw["attn_mask"] = torch.full((Lq, Lk), float("-inf"), device=dev).triu_(1) if Lq == Lk else torch.randn(Lq, Lk, device=dev, generator=g)
+    if "bool2d" in masking:
+        m = torch.rand(Lq, Lk, device=dev, generator=g) > 0.7
+        m[:, 0] = False
+        kw["attn_mask"] = m
+    if "padding" in masking:
+        pad = torch.zeros(B, Lk, dtype=torch.bool, device=dev)
+        pad[0, -3:] = True
+        pad[2, -1:] = True
+        kw["key_padding_mask"] = pad
+    outs = []
+    for mod in (fast, stock):
+        mod.zero_grad()
+        (q, k, v), leaves = inputs()
+        y = mod(q, k, v, need_weights=False, **kw)[0]
+        (y * torch.arange(y.numel(), device=dev).view_as(y).float().cos()).sum().backward()
+        outs.append((y.detach(), [t.grad.clone() for t in leaves], mod.in_proj_weight.grad.clone(), mod.out_proj.weight.grad.clone(),
+                     mod.in_proj_bias.grad.clone()))
+    (y0, gi0, gw0, go0, gb0), (y1, gi1, gw1, go1, gb1) = outs
+    close = lambda a, b: (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3)
+    assert close(y0, y1) and all(close(a, b) for a, b in zip(gi0, gi1)) and close(gw0, gw1) and close(go0, go1) and close(gb0, gb1)
