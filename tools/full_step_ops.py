@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--rows", type=int, default=45)
+    ap.add_argument("--ops", type=int, default=140)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -31,8 +32,17 @@ def main():
         for _ in range(2):
             full.step()
         torch.cuda.synchronize()
-    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=a.rows,
-                                                              max_name_column_width=48, max_shapes_column_width=70))
+    ka = prof.key_averages(group_by_input_shape=True)
+    print(ka.table(sort_by="self_cuda_time_total", row_limit=a.rows, max_name_column_width=48,
+                   max_shapes_column_width=70))
+    # every host-side operator (kernels themselves excluded) with its shapes: who launches the elementwise work
+    print("# operators by self GPU time per step (ms), 2 steps profiled")
+    ops = [e for e in ka if (e.key.startswith("aten::") or "Backward" in e.key or e.key.startswith("_"))
+           and e.self_device_time_total > 100.0]
+    ops.sort(key=lambda e: -e.self_device_time_total)
+    for e in ops[:a.ops]:
+        print("%9.3f  %5d  %-44s %s" % (e.self_device_time_total / 2e3, e.count // 2, e.key[:44],
+                                        str(e.input_shapes)[:150]))
 
 
 if __name__ == "__main__":
