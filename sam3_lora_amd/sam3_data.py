@@ -248,6 +248,9 @@ def collate_fn_api(batch: Sequence[Datapoint], dict_key, with_seg_masks: bool = 
         st.input_boxes = _pad_to_longest(st.input_boxes, 0)
         st.input_boxes_label = _pad_to_longest(st.input_boxes_label, 0)
         st.input_boxes_mask = _pad_to_longest(st.input_boxes_mask, 1)
+        # host-side note for the model (a plain attribute, not a field of the reference's record): every prompt reads
+        # its own image, in order -> the per-prompt gather of the feature maps is the identity and can be skipped
+        st.img_ids_are_arange = list(st.img_ids) == list(range(len(images)))
         _tensorise(st, _FIND_STAGE)
         _tensorise(tg, _FIND_TARGET)
         _tensorise(metas[i], _METADATA)

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import copy
 import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
@@ -496,8 +496,10 @@ class TransformerDecoder(nn.Module):
         wd = self.norm.weight.dtype
         bx = _maybe_checkpoint(ckpt, self.boxRPB_embed_x, dx.to(wd))           # [B, Q, W, heads]
         by = _maybe_checkpoint(ckpt, self.boxRPB_embed_y, dy.to(wd))           # [B, Q, H, heads]
-        by = by.permute(0, 3, 1, 2)                                            # [B, heads, Q, H]  (small)
-        bx = bx.permute(0, 3, 1, 2)                                            # [B, heads, Q, W]
+        # head-major COPIES of the two small terms: as permuted views the broadcast add below would inherit their
+        # heads-innermost strides and the flatten would then copy the full bias (a 53 MB round trip per layer)
+        by = by.permute(0, 3, 1, 2).contiguous()                               # [B, heads, Q, H]  (small)
+        bx = bx.permute(0, 3, 1, 2).contiguous()                               # [B, heads, Q, W]
         if presence_row:
             by, bx = F.pad(by, (0, 0, 1, 0)), F.pad(bx, (0, 0, 1, 0))
         return (by.unsqueeze(-1) + bx.unsqueeze(-2)).flatten(3)                # [B, heads, Q(+1), H*W], contiguous
@@ -505,7 +507,8 @@ class TransformerDecoder(nn.Module):
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, reference_boxes=None, level_start_index=None,
                 spatial_shapes=None, valid_ratios=None, memory_text=None, text_attention_mask=None,
-                apply_dac: Optional[bool] = None, is_instance_prompt: bool = False):
+                apply_dac: Optional[bool] = None, is_instance_prompt: bool = False,
+                feat_sizes: Optional[Sequence] = None):
         """Returns (hs [layers, Q, B, C], reference boxes per layer [layers, Q, B, 4], presence logits
         [layers, 1, B] or None, presence features [1, B, C] or None)."""
         if memory_mask is not None:
@@ -534,7 +537,11 @@ class TransformerDecoder(nn.Module):
         feat_hw = None
         if self.boxRPB != "none":
             assert spatial_shapes.shape[0] == 1, "only single scale support implemented"
-            feat_hw = tuple(int(v) for v in spatial_shapes[0].tolist())           # one host read per forward, not per layer
+            if feat_sizes is not None:      # the caller's host-side (H, W): no device read, the host keeps running ahead
+                assert len(feat_sizes) == 1
+                feat_hw = (int(feat_sizes[0][0]), int(feat_sizes[0][1]))
+            else:
+                feat_hw = tuple(int(v) for v in spatial_shapes[0].tolist())       # one host read per forward, not per layer
         for idx, layer in enumerate(self.layers):
             ref_in = reference_boxes[:, :, None] * ratios4                        # [Q, B, levels, 4]
             query_pos = self.ref_point_head(gen_sineembed_for_position(ref_in[:, :, 0, :], self.d_model).to(wd))

@@ -169,8 +169,9 @@ class Sam3Image(nn.Module):
         sizes = [c.shape[-2:] for c in codes]
         # contiguous [HW, N, C]: these feed LayerNorm / Linear / attention of the geometry and fusion encoders; as
         # permuted views of [N, C, HW] every one of those would run on its strided slow path.  Built once per forward.
-        tokens = [f[img_ids].flatten(2).permute(2, 0, 1).contiguous() for f in feats]
-        token_pos = [c[img_ids].flatten(2).permute(2, 0, 1).contiguous() for c in codes]
+        pick = (lambda t: t) if backbone_out.get("_img_ids_are_arange") else (lambda t: t[img_ids])
+        tokens = [pick(f).flatten(2).permute(2, 0, 1).contiguous() for f in feats]
+        token_pos = [pick(c).flatten(2).permute(2, 0, 1).contiguous() for c in codes]
         backbone_out["_token_cache"] = (img_ids, (tokens, token_pos, sizes))
         return backbone_out, tokens, token_pos, sizes
 
@@ -204,7 +205,8 @@ class Sam3Image(nn.Module):
             tgt=tgt, memory=memory, memory_key_padding_mask=encoder_out["padding_mask"], pos=encoder_out["pos_embed"],
             reference_boxes=None, level_start_index=encoder_out["level_start_index"],
             spatial_shapes=encoder_out["spatial_shapes"], valid_ratios=encoder_out["valid_ratios"], tgt_mask=None,
-            memory_text=prompt, text_attention_mask=prompt_mask, apply_dac=dec.dac and self.training)
+            memory_text=prompt, text_attention_mask=prompt_mask, apply_dac=dec.dac and self.training,
+            feat_sizes=encoder_out.get("vis_feat_sizes"))
         hs = hs.transpose(1, 2)                         # [layers, B, Q, C]
         ref_boxes = ref_boxes.transpose(1, 2)
         if presence is not None:
@@ -252,6 +254,8 @@ class Sam3Image(nn.Module):
         def run(feats, q, ids, enc, p, pm):
             return head(backbone_feats=feats, obj_queries=q, image_ids=ids, encoder_hidden_states=enc, prompt=p,
                         prompt_mask=pm)
+        if backbone_out.get("_img_ids_are_arange"):
+            img_ids = None                       # the head's per-prompt gather of the FPN levels is the identity
         args = (backbone_out["backbone_fpn"], queries, img_ids, encoder_hidden_states, prompt, prompt_mask)
         if self.training and self.use_act_checkpoint_seg_head and torch.is_grad_enabled():
             seg = checkpoint(run, *args, use_reentrant=False)
@@ -288,6 +292,8 @@ class Sam3Image(nn.Module):
         backbone_out.update(self.backbone.forward_text(input.find_text_batch, device=device))
         stages = SAM3Output(iter_mode=SAM3Output.IterMode.LAST_STEP_PER_STAGE)
         find_input, find_target = input.find_inputs[0], input.find_targets[0]
+        backbone_out["_img_ids_are_arange"] = (bool(getattr(find_input, "img_ids_are_arange", False))
+                                               and len(find_input.img_ids) == images.shape[0])
         if find_input.input_points is not None and find_input.input_points.numel() > 0:
             print("Warning: Point prompts are ignored in PCS.")
         prompt = Prompt(box_embeddings=find_input.input_boxes, box_mask=find_input.input_boxes_mask,

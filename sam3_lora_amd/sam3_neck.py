@@ -81,8 +81,16 @@ class PositionEmbeddingSine(nn.Module):
         return self.cache[key]
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.table(x.shape[-2], x.shape[-1], x.device)[None].expand(x.shape[0], -1, -1, -1)
+    def forward(self, x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """[B, C, h, w] as a stride-0 batch expansion of the cached table (cast, when asked, BEFORE the expansion: the
+        cast of an expanded tensor would write B full copies -- 340 MB at the 288^2 level)."""
+        t = self.table(x.shape[-2], x.shape[-1], x.device)
+        if dtype is not None and dtype != t.dtype:
+            key = (x.shape[-2], x.shape[-1], str(x.device), dtype)
+            if key not in self.cache:
+                self.cache[key] = t.to(dtype)
+            t = self.cache[key]
+        return t[None].expand(x.shape[0], -1, -1, -1)
 
 
 class Sam3DualViTDetNeck(nn.Module):
@@ -127,7 +135,7 @@ class Sam3DualViTDetNeck(nn.Module):
         x = self.trunk(images)[-1]
         stages = list(self.convs)[:len(self.convs) - self.skip_coarsest]
         feats = [stage(x) for stage in stages]
-        pos = [self.position_encoding(f).to(f.dtype) for f in feats]
+        pos = [self.position_encoding(f, dtype=f.dtype) for f in feats]
         return feats, pos, None, None
 
 

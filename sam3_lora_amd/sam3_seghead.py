@@ -84,13 +84,16 @@ class UniversalSegmentationHead(nn.Module):
     def _embed_pixels(self, backbone_feats: List[torch.Tensor], image_ids, encoder_hidden_states: torch.Tensor):
         """FPN levels (per image when the batch has several prompts per image) with the coarsest level replaced by
         the encoder's output tokens reshaped to its map."""
-        if backbone_feats[0].shape[0] > 1:
-            levels = [f[image_ids.to(f.device), ...] for f in backbone_feats]
-        else:
-            levels = [f.clone() for f in backbone_feats]
+        finer = backbone_feats[:-1]                  # the coarsest level is replaced below: never gathered
+        if image_ids is None:                        # caller knows prompt i reads image i (sam3_data.collate_fn_api)
+            levels = list(finer)
+        elif backbone_feats[0].shape[0] > 1:
+            levels = [f[image_ids.to(f.device), ...] for f in finer]
+        else:                                        # one image: broadcasting does the per-prompt copy
+            levels = list(finer)
         hw = math.prod(backbone_feats[-1].shape[-2:])
         tokens = encoder_hidden_states.permute(1, 2, 0)[..., :hw]
-        levels[-1] = tokens.reshape(-1, *backbone_feats[-1].shape[1:])
+        levels.append(tokens.reshape(-1, *backbone_feats[-1].shape[1:]))
         if self.act_ckpt and torch.is_grad_enabled():
             return checkpoint(self.pixel_decoder, levels, use_reentrant=False)
         return self.pixel_decoder(levels)
