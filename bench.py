@@ -568,6 +568,8 @@ class FullStep:
         enable_direct_grad_accumulation(True)    # the kernels add straight into the reducer's flat buffer
         self.opt = torch.optim.AdamW(self.params, lr=5e-5, weight_decay=0.01)
         self.matcher, self.wrapper = build_criterion("global" if world > 1 else "local")
+        if match_once:
+            self.model.set_prefetch_matcher(self.matcher)
         ds = SyntheticSegmentDataset(2 * batch * world, resolution=res, source=src)
         self.batches = []
         for k in range(2):          # two resident batches, alternated

@@ -12,7 +12,7 @@ The native CLI constructs it as ``BinaryHungarianMatcherV2(cost_class=2.0, cost_
 focal=True)`` (``train_sam3_lora_native.py:743-745``).
 """
 from __future__ import annotations
-
+from typing import Dict, List, Optional, Sequence, Tuple
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -101,31 +101,54 @@ class BinaryHungarianMatcherV2(nn.Module):
     def forward(self, outputs: Dict[str, torch.Tensor], batched_targets: Dict[str, torch.Tensor], repeats: int = 1,
                 repeat_batch: int = 1, out_is_valid: Optional[torch.Tensor] = None,
                 target_is_valid_padded: Optional[torch.Tensor] = None):
-        num_queries = outputs["pred_logits"].shape[1]
+        return self.collect(self.launch([outputs], batched_targets, repeats=repeats, repeat_batch=repeat_batch,
+                                        out_is_valid=out_is_valid, target_is_valid_padded=target_is_valid_padded))[0]
+
+    @torch.no_grad()
+    def launch(self, outputs_list: Sequence[Dict[str, torch.Tensor]], batched_targets: Dict[str, torch.Tensor],
+               repeats: int = 1, repeat_batch: int = 1, out_is_valid: Optional[torch.Tensor] = None,
+               target_is_valid_padded: Optional[torch.Tensor] = None) -> Dict:
+        """First half of matching ``len(outputs_list)`` outputs (a decoder's final + auxiliary ones) against the same
+        targets: the cost of ALL of them as one batched fp32 expression on the device and ONE device->host copy,
+        asynchronous on a GPU (pinned buffer + event).  Nothing here waits for the device when the targets carry their
+        box counts on the host (``num_boxes_host``, sam3_data.collate_fn_api), so the caller can keep queueing device
+        work -- the mask head -- and ``collect`` later."""
+        L = len(outputs_list)
+        num_queries = outputs_list[0]["pred_logits"].shape[1]
         # the cost is an fp32 expression whatever the model's output dtype (bf16 heads in the MI355X layout);
         # numpy has no bfloat16 and the assignment must not depend on the activation dtype
-        score = outputs["pred_logits"].squeeze(-1).float()
-        boxes = outputs["pred_boxes"].float()
+        score = torch.cat([o["pred_logits"].squeeze(-1).float() for o in outputs_list], 0)
+        boxes = torch.cat([o["pred_boxes"].float() for o in outputs_list], 0)
         device = score.device
-        num_boxes = batched_targets["num_boxes"].cpu()
+        host_counts = batched_targets.get("num_boxes_host")
+        num_boxes = (torch.as_tensor(list(host_counts), dtype=torch.long) if host_counts is not None
+                     else batched_targets["num_boxes"].cpu())
         tgt = batched_targets["boxes_padded"].float()
         keep = None
         if self.remove_samples_with_0_gt:
             keep = num_boxes > 0
-            num_boxes, tgt = num_boxes[keep], tgt[keep]
+            if bool(keep.all()):
+                keep_dev = None
+            else:
+                keep_dev = keep.to(device)
+                tgt = tgt[keep_dev]
+            num_boxes = num_boxes[keep]
+            if target_is_valid_padded is not None and keep_dev is not None:
+                target_is_valid_padded = target_is_valid_padded[keep_dev]
+        reps = repeat_batch * L         # final + auxiliary outputs concatenated along the batch
+        if reps > 1:
+            num_boxes = num_boxes.repeat(reps)
+            tgt = tgt.repeat(reps, 1, 1)
             if target_is_valid_padded is not None:
-                target_is_valid_padded = target_is_valid_padded[keep]
-        if repeat_batch > 1:        # final + auxiliary outputs concatenated along the batch
-            num_boxes = num_boxes.repeat(repeat_batch)
-            tgt = tgt.repeat(repeat_batch, 1, 1)
-            if target_is_valid_padded is not None:
-                target_is_valid_padded = target_is_valid_padded.repeat(repeat_batch, 1)
+                target_is_valid_padded = target_is_valid_padded.repeat(reps, 1)
         if self.remove_samples_with_0_gt:
-            if repeat_batch > 1:
-                keep = keep.repeat(repeat_batch)
-            score, boxes = score[keep], boxes[keep]
-            if out_is_valid is not None:
-                out_is_valid = out_is_valid[keep]
+            if reps > 1:
+                keep = keep.repeat(reps)
+            if keep_dev is not None:
+                kd = keep.to(device)
+                score, boxes = score[kd], boxes[kd]
+                if out_is_valid is not None:
+                    out_is_valid = out_is_valid[kd]
         assert boxes.shape[0] == tgt.shape[0] == num_boxes.shape[0]
 
         C = self.cost_matrix(score, boxes, tgt)
@@ -134,26 +157,49 @@ class BinaryHungarianMatcherV2(nn.Module):
             C = torch.where(out_is_valid[:, :, None], C, INVALID_COST)
         if target_is_valid_padded is not None:
             C = torch.where(target_is_valid_padded[:, None, :], C, INVALID_COST)
-        C = C.cpu().numpy()                                          # the one device->host crossing
+        event = None
+        if C.is_cuda:                                                # the one device->host crossing
+            C_host = torch.empty(C.shape, dtype=C.dtype, pin_memory=True)
+            C_host.copy_(C, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(device))
+        else:
+            C_host = C
+        return dict(cost=C_host, event=event, num_boxes=num_boxes, keep=keep, L=L, repeats=repeats,
+                    filtering=filtering, num_queries=num_queries, device=device)
+
+    @torch.no_grad()
+    def collect(self, handle: Dict) -> List[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]]:
+        """Second half: wait for the cost copy, solve every image on the host, return one index triple per output."""
+        if handle["event"] is not None:
+            handle["event"].synchronize()
+        C = handle["cost"].numpy()
+        L, repeats, filtering, device = handle["L"], handle["repeats"], handle["filtering"], handle["device"]
+        num_boxes, keep = handle["num_boxes"], handle["keep"]
         counts = num_boxes.tolist()
         per_image = [C[i, :, :n] for i, n in enumerate(counts)]
-        want_tgt = filtering or bool(torch.any(num_queries < num_boxes * max(repeats, 1)).item())
-
-        if not per_image:
-            src_lists = []
-            tgt_idx = torch.zeros(0, dtype=torch.long, device=device) if want_tgt else None
-        elif want_tgt:
-            solved = [_solve(c, repeats, True, filtering) for c in per_image]
-            src_lists = [s for s, _ in solved]
-            offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
-            tgt_idx = torch.from_numpy(np.concatenate([t + o for (_, t), o in zip(solved, offsets)])).long().to(device)
-        else:
-            src_lists = [_solve(c, repeats, False, filtering) for c in per_image]
-            tgt_idx = None
-
-        image_ids = keep.nonzero().squeeze(1).tolist() if self.remove_samples_with_0_gt else list(range(len(src_lists)))
-        batch_idx = torch.as_tensor([image_ids[i] for i, s in enumerate(src_lists) for _ in range(len(s))],
-                                    dtype=torch.long, device=device)
-        src_idx = (torch.from_numpy(np.concatenate(src_lists)).long().to(device) if src_lists
-                   else torch.empty(0, dtype=torch.long, device=device))
-        return batch_idx, src_idx, tgt_idx
+        want_tgt = filtering or bool(torch.any(handle["num_queries"] < num_boxes * max(repeats, 1)).item())
+        solved = [_solve(c, repeats, want_tgt, filtering) for c in per_image]
+        image_ids_all = keep.nonzero().squeeze(1).tolist() if self.remove_samples_with_0_gt else list(range(len(solved)))
+        n_img = len(solved) // L                 # rows per output (images kept x repeat_batch)
+        total_rows = (len(keep) // L) if keep is not None else n_img
+        results = []
+        for l in range(L):
+            rows = solved[l * n_img:(l + 1) * n_img]
+            cnt = counts[l * n_img:(l + 1) * n_img]
+            ids = [i - l * total_rows for i in image_ids_all[l * n_img:(l + 1) * n_img]]
+            if not rows:
+                src_lists = []
+                tgt_idx = torch.zeros(0, dtype=torch.long, device=device) if want_tgt else None
+            elif want_tgt:
+                src_lists = [s for s, _ in rows]
+                offsets = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+                tgt_idx = torch.from_numpy(np.concatenate([t + o for (_, t), o in zip(rows, offsets)])).long().to(device)
+            else:
+                src_lists, tgt_idx = rows, None
+            batch_idx = torch.as_tensor([ids[i] for i, s in enumerate(src_lists) for _ in range(len(s))],
+                                        dtype=torch.long, device=device)
+            src_idx = (torch.from_numpy(np.concatenate(src_lists)).long().to(device) if src_lists
+                       else torch.empty(0, dtype=torch.long, device=device))
+            results.append((batch_idx, src_idx, tgt_idx))
+        return results

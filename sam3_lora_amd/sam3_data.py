@@ -252,6 +252,7 @@ def collate_fn_api(batch: Sequence[Datapoint], dict_key, with_seg_masks: bool = 
         # its own image, in order -> the per-prompt gather of the feature maps is the identity and can be skipped
         st.img_ids_are_arange = list(st.img_ids) == list(range(len(images)))
         _tensorise(st, _FIND_STAGE)
+        tg.num_boxes_host = tuple(int(n) for n in tg.num_boxes)       # same kind of note: box counts, host side
         _tensorise(tg, _FIND_TARGET)
         _tensorise(metas[i], _METADATA)
         tg.boxes_padded = _packed_to_padded(tg.boxes.view(-1, 4), tg.num_boxes)

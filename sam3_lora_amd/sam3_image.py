@@ -144,6 +144,9 @@ class Sam3Image(nn.Module):
         self.use_act_checkpoint_seg_head = use_act_checkpoint_seg_head
         self.matcher = matcher
         self.match_in_forward = match_in_forward
+        # set by the training loop to ITS matcher (trainer.match_all_steps collects): the matching of the final + auxiliary
+        # outputs then starts right after the decoder, before the mask head is queued.  Not a sub-module (plain attribute).
+        object.__setattr__(self, "prefetch_matcher", None)
         self.num_interactive_steps_val = 0
         self.supervise_joint_box_scores = supervise_joint_box_scores
         self.detach_presence_in_joint_score = detach_presence_in_joint_score
@@ -156,6 +159,11 @@ class Sam3Image(nn.Module):
     @property
     def device(self):
         return next(self.parameters()).device
+
+    def set_prefetch_matcher(self, matcher) -> None:
+        """Start the training loop's matching inside ``forward`` right after the decoder (``matcher.launch``); the loop's
+        ``match_all_steps`` collects.  ``None`` switches it off."""
+        object.__setattr__(self, "prefetch_matcher", matcher)
 
     # ----------------------------------------------------------------------------------------------- pieces --
     def _get_img_feats(self, backbone_out: Dict, img_ids: torch.Tensor):
@@ -276,6 +284,11 @@ class Sam3Image(nn.Module):
         out = {"encoder_hidden_states": encoder_out["encoder_hidden_states"],
                "prev_encoder_out": {"encoder_out": encoder_out, "backbone_out": backbone_out}}
         out, hs = self._run_decoder(out, encoder_out, prompt, prompt_mask)
+        if self.training and self.prefetch_matcher is not None and find_target is not None:
+            # scores and boxes are final here: start the matcher's cost + device->host copy now, so that the host-side
+            # assignment later overlaps with the mask head's device work instead of following it
+            m = self.prefetch_matcher
+            out["_match_handle"] = (m, m.launch([out] + list(out.get("aux_outputs", ())), self.back_convert(find_target)))
         self._run_segmentation_heads(out, backbone_out, find_input.img_ids, out["encoder_hidden_states"], prompt,
                                      prompt_mask, hs)
         if self.training and self.match_in_forward and self.matcher is not None:
@@ -308,11 +321,15 @@ class Sam3Image(nn.Module):
 
     def back_convert(self, targets) -> Dict:
         boxes = targets.boxes.view(-1, 4)
-        return {"boxes": boxes, "boxes_xyxy": box_cxcywh_to_xyxy(boxes), "boxes_padded": targets.boxes_padded,
-                "positive_map": targets.boxes.new_ones(len(targets.boxes), 1), "num_boxes": targets.num_boxes,
-                "masks": targets.segments, "semantic_masks": targets.semantic_segments,
-                "is_valid_mask": targets.is_valid_segment, "is_exhaustive": targets.is_exhaustive,
-                "object_ids_packed": targets.object_ids, "object_ids_padded": targets.object_ids_padded}
+        out = {"boxes": boxes, "boxes_xyxy": box_cxcywh_to_xyxy(boxes), "boxes_padded": targets.boxes_padded,
+               "positive_map": targets.boxes.new_ones(len(targets.boxes), 1), "num_boxes": targets.num_boxes,
+               "masks": targets.segments, "semantic_masks": targets.semantic_segments,
+               "is_valid_mask": targets.is_valid_segment, "is_exhaustive": targets.is_exhaustive,
+               "object_ids_packed": targets.object_ids, "object_ids_padded": targets.object_ids_padded}
+        host_counts = getattr(targets, "num_boxes_host", None)     # the collator's host copy: matching needs the counts
+        if host_counts is not None and len(host_counts) == len(targets.num_boxes):     # on the host, without a device read
+            out["num_boxes_host"] = tuple(host_counts)
+        return out
 
 
 # ===================================================================================================== builder ==

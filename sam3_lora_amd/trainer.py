@@ -155,9 +155,15 @@ def match_all_steps(matcher, stage_outputs: Sequence, stage_targets: Sequence[Di
     """``outputs["indices"]`` for every step of every stage and each of its aux outputs (:914-927)."""
     for stage, targets in zip(stage_outputs, stage_targets):
         for outputs in _steps(stage):
-            outputs["indices"] = matcher(outputs, targets)
-            for aux in outputs.get("aux_outputs", ()):
-                aux["indices"] = matcher(aux, targets)
+            pending = outputs.pop("_match_handle", None) if isinstance(outputs, dict) else None
+            aux_outputs = list(outputs.get("aux_outputs", ()))
+            if pending is not None and pending[0] is matcher and pending[1]["L"] == 1 + len(aux_outputs):
+                found = matcher.collect(pending[1])             # started inside the model's forward (prefetch_matcher)
+            else:
+                found = matcher.collect(matcher.launch([outputs] + aux_outputs, targets))
+            outputs["indices"] = found[0]
+            for aux, idx in zip(aux_outputs, found[1:]):
+                aux["indices"] = idx
 
 
 class SAM3TrainerNative:
@@ -214,6 +220,10 @@ class SAM3TrainerNative:
             from .functional import enable_direct_grad_accumulation
             enable_direct_grad_accumulation(True)
         self.matcher, self.loss_wrapper = build_criterion("global" if self.world_size > 1 else "local")
+        # engine.match_once: the loop's matching starts inside the forward, right after the decoder, and its host part
+        # overlaps with the mask head's device work (Sam3Image.set_prefetch_matcher); same indices either way
+        if (self.config.get("engine") or {}).get("match_once", False) and hasattr(self.model, "set_prefetch_matcher"):
+            self.model.set_prefetch_matcher(self.matcher)
 
     # ------------------------------------------------------------------------------------------------
     def _say(self, msg: str) -> None:

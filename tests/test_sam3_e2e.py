@@ -133,6 +133,37 @@ def test_eval_and_training_forward_match_reference_cpu(gold):
     check_outputs(gold, "train", out2, 2e-5, indices=False)
 
 
+def test_matching_started_inside_forward_gives_the_reference_indices(gold):
+    """engine.match_once: the loop's matcher is launched right after the decoder (one batched cost for the final + aux
+    outputs, Sam3Image.set_prefetch_matcher) and collected by match_all_steps -- same indices as the reference's
+    per-output matching, and as this build's own per-output calls."""
+    from sam3_lora_amd.trainer import match_all_steps
+    matcher, _ = _criterion()
+    batch = make_batch()
+    assert batch.find_targets[0].num_boxes_host == tuple(batch.find_targets[0].num_boxes.tolist())
+    assert batch.find_inputs[0].img_ids_are_arange
+    model = build(gold, act_checkpoint=False, match_in_forward=False)
+    model.train()
+    model.set_prefetch_matcher(matcher)
+    out = model(batch)
+    assert "_match_handle" in out[0] and "indices" not in out[0]
+    targets = [model.back_convert(t) for t in batch.find_targets]
+    assert "num_boxes_host" in targets[0]
+    match_all_steps(matcher, out.output, targets)
+    stage = out[0]
+    assert "_match_handle" not in stage
+    check_outputs(gold, "train", stage, 2e-5, indices=True)
+    for o in [stage] + list(stage["aux_outputs"]):
+        alone = matcher(o, targets[0])
+        for a, b in zip(o["indices"], alone):
+            assert (a is None and b is None) or torch.equal(a, b)
+    # the handle of another matcher instance is ignored, not misused
+    other, _ = _criterion()
+    out = model(batch)
+    match_all_steps(other, out.output, targets)
+    check_outputs(gold, "train", out[0], 2e-5, indices=True)
+
+
 # ------------------------------------------------------------------------------------------------------- GPU --
 def _inject(model, gold):
     import contextlib, io
