@@ -1,0 +1,352 @@
+// sam3_lora_amd -- GroupNorm (+ ReLU) on channels-last feature maps (gfx950): C-ABI of include/sam3_seg_amd.h.
+//
+// The pixel decoder of the mask head (sam3/model/maskformer_segmentation.py:205-222) normalises [8, 256, 288, 288] and
+// [8, 256, 144, 144] maps between MIOpen convolutions that all run channels-last.  Per (image, group) the statistics run
+// over HW x C/G elements (2.65 M at the 288^2 level); ATen gives that one workgroup per (image, group).  Here:
+//
+//   k_gn_stats     grid (pixel chunks, N): every workgroup streams its pixels' full channel rows (16-byte vectors, a
+//                  thread's vector lies inside one group), reduces in LDS in fixed order and writes one
+//                  (count, mean, M2) triple per group;
+//   k_gn_finalize  one thread per (image, group): Chan's pairwise combination of the chunk triples in chunk order
+//                  -> (mean, rstd);
+//   k_gn_apply     y = act(x * (rstd gamma) + (beta - mean rstd gamma)), channels-last in and out;
+//   k_gn_bwd_stats / k_gn_bwd_finalize / k_gn_bwd_apply   the input gradient for frozen gamma / beta in the same three
+//                  steps (a = sum g', b = sum g' xhat per (image, group); the ReLU mask is recomputed from x).
+//
+// HBM-bound elementwise work: forward reads x twice and writes y once (the second read mostly hits the 256 MB
+// Infinity Cache at these sizes), backward reads x and gy twice and writes gx.  No atomics anywhere.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "sam3_seg_amd.h"
+
+typedef unsigned short bf16_t;
+
+namespace {
+thread_local char g_err[256] = "";
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+constexpr int EINVAL_ = -22, ENOTSUP_ = -95, ENOMEM_ = -12, EIO_ = -5;
+
+__host__ __device__ inline int chunks_of(long long HW) {
+    long long c = (HW + 255) / 256;
+    return (int)(c < 1 ? 1 : (c > 256 ? 256 : c));
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- 16-byte vectors --
+template <typename T> struct V16;
+template <> struct V16<bf16_t> {
+    static constexpr int N = 8;
+    typedef uint4 raw;
+    static __device__ __forceinline__ void unpack(const raw& r, float* f) {
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ unsigned pk(float a, float b) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 t = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, t);
+    }
+    static __device__ __forceinline__ raw pack(const float* f) {
+        raw r;
+        r.x = pk(f[0], f[1]); r.y = pk(f[2], f[3]); r.z = pk(f[4], f[5]); r.w = pk(f[6], f[7]);
+        return r;
+    }
+};
+template <> struct V16<float> {
+    static constexpr int N = 4;
+    typedef float4 raw;
+    static __device__ __forceinline__ void unpack(const raw& r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+    static __device__ __forceinline__ raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+
+// thread geometry shared by every kernel: TPP threads cover one pixel's C channels, PPB = 256 / TPP pixels per sweep
+struct Geo {
+    int tp, pr, TPP, PPB, c0, g;
+    long long p0, p1;
+};
+template <typename T>
+__device__ __forceinline__ Geo geo_of(int C, int G, long long HW, int chunks) {
+    Geo q;
+    q.TPP = C / V16<T>::N;
+    q.PPB = 256 / q.TPP;
+    q.tp = threadIdx.x % q.TPP;
+    q.pr = threadIdx.x / q.TPP;
+    q.c0 = q.tp * V16<T>::N;
+    q.g = q.c0 / (C / G);
+    const long long per = (HW + chunks - 1) / chunks;
+    q.p0 = (long long)blockIdx.x * per;
+    q.p1 = q.p0 + per < HW ? q.p0 + per : HW;
+    return q;
+}
+
+// fixed-order sum, per group, of two per-thread values over the workgroup; result valid in threads g < G
+template <typename T>
+__device__ __forceinline__ void group_reduce(float& a, float& b, const Geo& q, int C, int G, float (*sm)[2]) {
+    sm[threadIdx.x][0] = a;
+    sm[threadIdx.x][1] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+        const int TPG = q.TPP / G;          // threads of one pixel that belong to one group
+        float sa = 0.f, sb = 0.f;
+        for (int pr = 0; pr < q.PPB; ++pr)
+            for (int j = 0; j < TPG; ++j) {
+                const int t = pr * q.TPP + threadIdx.x * TPG + j;
+                sa += sm[t][0];
+                sb += sm[t][1];
+            }
+        a = sa;
+        b = sb;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------- forward --
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_stats(const T* __restrict__ x, float* __restrict__ part, long long HW, int C,
+                                                  int G, int chunks) {
+    __shared__ float sm[256][2];
+    const Geo q = geo_of<T>(C, G, HW, chunks);
+    const int n = blockIdx.y;
+    const T* xb = x + (long long)n * HW * C + q.c0;
+    float s = 0.f, ss = 0.f;
+    for (long long p = q.p0 + q.pr; p < q.p1; p += q.PPB) {
+        float f[V16<T>::N];
+        V16<T>::unpack(*reinterpret_cast<const typename V16<T>::raw*>(xb + p * C), f);
+#pragma unroll
+        for (int i = 0; i < V16<T>::N; ++i) { s += f[i]; ss += f[i] * f[i]; }
+    }
+    group_reduce<T>(s, ss, q, C, G, sm);
+    if ((int)threadIdx.x < G) {
+        const float cnt = (float)((q.p1 > q.p0 ? q.p1 - q.p0 : 0) * (C / G));
+        const float mean = cnt > 0.f ? s / cnt : 0.f;
+        float m2 = ss - s * mean;
+        m2 = m2 > 0.f ? m2 : 0.f;
+        float* o = part + (((long long)n * chunks + blockIdx.x) * G + threadIdx.x) * 3;
+        o[0] = cnt; o[1] = mean; o[2] = m2;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ part, float* __restrict__ stats, int NG, int G,
+                                                    int chunks, float eps) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= NG) return;
+    const int n = i / G, g = i % G;
+    float na = 0.f, mean = 0.f, m2 = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        const float* p = part + (((long long)n * chunks + c) * G + g) * 3;
+        const float nb = p[0];
+        if (nb <= 0.f) continue;
+        const float d = p[1] - mean, nt = na + nb;
+        mean += d * (nb / nt);
+        m2 += p[2] + d * d * (na * nb / nt);
+        na = nt;
+    }
+    const float var = na > 0.f ? m2 / na : 0.f;
+    stats[2 * i] = mean;
+    stats[2 * i + 1] = rsqrtf(var + eps);
+}
+
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ stats,
+                                                  T* __restrict__ y, long long HW, int C, int G, int chunks) {
+    const Geo q = geo_of<T>(C, G, HW, chunks);
+    const int n = blockIdx.y;
+    const float mean = stats[2 * (n * G + q.g)], rstd = stats[2 * (n * G + q.g) + 1];
+    float sc[V16<T>::N], sh[V16<T>::N];
+#pragma unroll
+    for (int i = 0; i < V16<T>::N; ++i) {
+        sc[i] = rstd * gamma[q.c0 + i];
+        sh[i] = beta[q.c0 + i] - mean * sc[i];
+    }
+    const long long base = (long long)n * HW * C + q.c0;
+    for (long long p = q.p0 + q.pr; p < q.p1; p += q.PPB) {
+        float f[V16<T>::N];
+        V16<T>::unpack(*reinterpret_cast<const typename V16<T>::raw*>(x + base + p * C), f);
+#pragma unroll
+        for (int i = 0; i < V16<T>::N; ++i) {
+            f[i] = f[i] * sc[i] + sh[i];
+            if (RELU) f[i] = f[i] > 0.f ? f[i] : 0.f;
+        }
+        *reinterpret_cast<typename V16<T>::raw*>(y + base + p * C) = V16<T>::pack(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward --
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void k_gn_bwd_stats(const T* __restrict__ x, const T* __restrict__ gy,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ stats, float* __restrict__ part,
+                                                      long long HW, int C, int G, int chunks) {
+    __shared__ float sm[256][2];
+    const Geo q = geo_of<T>(C, G, HW, chunks);
+    const int n = blockIdx.y;
+    const float mean = stats[2 * (n * G + q.g)], rstd = stats[2 * (n * G + q.g) + 1];
+    float gm[V16<T>::N], sc[V16<T>::N], sh[V16<T>::N];
+#pragma unroll
+    for (int i = 0; i < V16<T>::N; ++i) {
+        gm[i] = gamma[q.c0 + i];
+        sc[i] = rstd * gm[i];
+        sh[i] = beta[q.c0 + i] - mean * sc[i];
+    }
+    const long long base = (long long)n * HW * C + q.c0;
+    float a = 0.f, b = 0.f;
+    for (long long p = q.p0 + q.pr; p < q.p1; p += q.PPB) {
+        float f[V16<T>::N], d[V16<T>::N];
+        V16<T>::unpack(*reinterpret_cast<const typename V16<T>::raw*>(x + base + p * C), f);
+        V16<T>::unpack(*reinterpret_cast<const typename V16<T>::raw*>(gy + base + p * C), d);
+#pragma unroll
+        for (int i = 0; i < V16<T>::N; ++i) {
+            float gp = d[i] * gm[i];
+            if (RELU && !(f[i] * sc[i] + sh[i] > 0.f)) gp = 0.f;
+            a += gp;
+            b += gp * ((f[i] - mean) * rstd);
+        }
+    }
+    group_reduce<T>(a, b, q, C, G, sm);
+    if ((int)threadIdx.x < G) {
+        float* o = part + (((long long)n * chunks + blockIdx.x) * G + threadIdx.x) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_gn_bwd_finalize(const float* __restrict__ part, float* __restrict__ ab, int NG, int G,
+                                                        int chunks, float inv_m) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= NG) return;
+    const int n = i / G, g = i % G;
+    float a = 0.f, b = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        const float* p = part + (((long long)n * chunks + c) * G + g) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    ab[2 * i] = a * inv_m;
+    ab[2 * i + 1] = b * inv_m;
+}
+
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ x, const T* __restrict__ gy,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ stats, const float* __restrict__ ab,
+                                                      T* __restrict__ gx, long long HW, int C, int G, int chunks) {
+    const Geo q = geo_of<T>(C, G, HW, chunks);
+    const int n = blockIdx.y;
+    const float mean = stats[2 * (n * G + q.g)], rstd = stats[2 * (n * G + q.g) + 1];
+    const float am = ab[2 * (n * G + q.g)], bm = ab[2 * (n * G + q.g) + 1];
+    float gm[V16<T>::N], sc[V16<T>::N], sh[V16<T>::N];
+#pragma unroll
+    for (int i = 0; i < V16<T>::N; ++i) {
+        gm[i] = gamma[q.c0 + i];
+        sc[i] = rstd * gm[i];
+        sh[i] = beta[q.c0 + i] - mean * sc[i];
+    }
+    const long long base = (long long)n * HW * C + q.c0;
+    for (long long p = q.p0 + q.pr; p < q.p1; p += q.PPB) {
+        float f[V16<T>::N], d[V16<T>::N];
+        V16<T>::unpack(*reinterpret_cast<const typename V16<T>::raw*>(x + base + p * C), f);
+        V16<T>::unpack(*reinterpret_cast<const typename V16<T>::raw*>(gy + base + p * C), d);
+#pragma unroll
+        for (int i = 0; i < V16<T>::N; ++i) {
+            float gp = d[i] * gm[i];
+            if (RELU && !(f[i] * sc[i] + sh[i] > 0.f)) gp = 0.f;
+            const float xh = (f[i] - mean) * rstd;
+            d[i] = rstd * (gp - am - xh * bm);
+        }
+        *reinterpret_cast<typename V16<T>::raw*>(gx + base + p * C) = V16<T>::pack(d);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------- host --
+namespace {
+int check(int N, long long HW, int C, int G, int dtype) {
+    if (N < 0 || HW < 0 || C <= 0 || G <= 0 || C % G) return fail(EINVAL_, "bad sizes N=%d HW=%lld C=%d G=%d", N, HW, C, G);
+    if (dtype != 0 && dtype != 1) return fail(EINVAL_, "dtype must be 0 (bf16) or 1 (fp32), got %d", dtype);
+    const int vec = dtype == 0 ? 8 : 4;
+    const int tpp = C / vec;
+    if (C % vec || (C / G) % vec || tpp > 256 || (tpp & (tpp - 1)) || G > 256)
+        return fail(ENOTSUP_, "GroupNorm kernels need C/G a multiple of %d and C/%d a power of two <= 256 (C=%d, G=%d)", vec, vec, C, G);
+    return 0;
+}
+size_t ws_bytes(int N, long long HW, int G) {
+    return ((size_t)N * chunks_of(HW) * G * 3 + (size_t)N * G * 2) * sizeof(float);
+}
+int launched(const char* what) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(EIO_, "%s launch failed: %s", what, hipGetErrorString(e));
+}
+}  // namespace
+
+extern "C" {
+
+const char* sam3_seg_last_error(void) { return g_err; }
+
+int sam3_gn_nhwc_supported(int C, int G, int dtype) { return check(1, 1, C, G, dtype); }
+
+size_t sam3_gn_nhwc_workspace_bytes(int N, int64_t HW, int C, int G) {
+    (void)C;
+    return N > 0 && HW > 0 && G > 0 ? ws_bytes(N, HW, G) : 0;
+}
+
+int sam3_gn_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int N, int64_t HW,
+                     int C, int G, float eps, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    g_err[0] = 0;
+    if (int rc = check(N, HW, C, G, dtype)) return rc;
+    if (N == 0 || HW == 0) return 0;
+    if (!x || !gamma || !beta || !y || !stats) return fail(EINVAL_, "null pointer");
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(EINVAL_, "x / y must be 16-byte aligned");
+    if (!workspace || workspace_bytes < ws_bytes(N, HW, G))
+        return fail(ENOMEM_, "workspace too small: %zu < %zu", workspace_bytes, ws_bytes(N, HW, G));
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = chunks_of(HW);
+    float* part = (float*)workspace;
+    dim3 grid(chunks, N);
+    if (dtype == 0) hipLaunchKernelGGL(k_gn_stats<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, part, (long long)HW, C, G, chunks);
+    else hipLaunchKernelGGL(k_gn_stats<float>, grid, dim3(256), 0, st, (const float*)x, part, (long long)HW, C, G, chunks);
+    hipLaunchKernelGGL(k_gn_finalize, dim3((N * G + 63) / 64), dim3(64), 0, st, (const float*)part, stats, N * G, G, chunks, eps);
+#define APPLY(T, R) hipLaunchKernelGGL((k_gn_apply<T, R>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (const float*)stats, (T*)y, (long long)HW, C, G, chunks)
+    if (dtype == 0) { if (relu) APPLY(bf16_t, true); else APPLY(bf16_t, false); }
+    else { if (relu) APPLY(float, true); else APPLY(float, false); }
+#undef APPLY
+    return launched("sam3_gn_nhwc_fwd");
+}
+
+int sam3_gn_nhwc_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* stats, void* gx,
+                     int N, int64_t HW, int C, int G, int relu, int dtype, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    g_err[0] = 0;
+    if (int rc = check(N, HW, C, G, dtype)) return rc;
+    if (N == 0 || HW == 0) return 0;
+    if (!x || !gy || !gamma || !beta || !stats || !gx) return fail(EINVAL_, "null pointer");
+    if (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx) & 15) return fail(EINVAL_, "x / gy / gx must be 16-byte aligned");
+    if (!workspace || workspace_bytes < ws_bytes(N, HW, G))
+        return fail(ENOMEM_, "workspace too small: %zu < %zu", workspace_bytes, ws_bytes(N, HW, G));
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = chunks_of(HW);
+    float* part = (float*)workspace;
+    float* ab = part + (size_t)N * chunks * G * 3;
+    const float inv_m = 1.f / ((float)HW * (float)(C / G));
+    dim3 grid(chunks, N);
+#define BSTATS(T, R) hipLaunchKernelGGL((k_gn_bwd_stats<T, R>), grid, dim3(256), 0, st, (const T*)x, (const T*)gy, gamma, beta, stats, part, (long long)HW, C, G, chunks)
+#define BAPPLY(T, R) hipLaunchKernelGGL((k_gn_bwd_apply<T, R>), grid, dim3(256), 0, st, (const T*)x, (const T*)gy, gamma, beta, stats, (const float*)ab, (T*)gx, (long long)HW, C, G, chunks)
+    if (dtype == 0) { if (relu) BSTATS(bf16_t, true); else BSTATS(bf16_t, false); }
+    else { if (relu) BSTATS(float, true); else BSTATS(float, false); }
+    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((N * G + 63) / 64), dim3(64), 0, st, (const float*)part, ab, N * G, G, chunks, inv_m);
+    if (dtype == 0) { if (relu) BAPPLY(bf16_t, true); else BAPPLY(bf16_t, false); }
+    else { if (relu) BAPPLY(float, true); else BAPPLY(float, false); }
+#undef BSTATS
+#undef BAPPLY
+    return launched("sam3_gn_nhwc_bwd");
+}
+
+}  // extern "C"

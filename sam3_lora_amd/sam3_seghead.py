@@ -22,7 +22,117 @@ from torch.utils.checkpoint import checkpoint
 
 from .sam3_detr import MLP
 
-__all__ = ["MaskPredictor", "PixelDecoder", "UniversalSegmentationHead"]
+__all__ = ["MaskPredictor", "PixelDecoder", "UniversalSegmentationHead", "group_norm_relu", "gn_kernels_support"]
+
+
+# ------------------------------------------------------------------ channels-last GroupNorm (+ ReLU), HIP kernels --
+def gn_kernels_support(x: torch.Tensor, gn: nn.GroupNorm) -> bool:
+    """The ``sam3_gn_nhwc_*`` kernels (include/sam3_seg_amd.h) apply: GPU map in bf16 / fp32, frozen affine parameters,
+    a channel count the 16-byte vector geometry covers."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and gn.affine):
+        return False
+    if gn.weight.requires_grad or gn.bias.requires_grad or torch.is_autocast_enabled():
+        return False
+    from . import _ffi
+    return _ffi.load().sam3_gn_nhwc_supported(x.shape[1], gn.num_groups, 0 if x.dtype == torch.bfloat16 else 1) == 0
+
+
+def _seg_check(lib, rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib.sam3_seg_last_error().decode()}")
+
+
+class _GroupNormNHWC(torch.autograd.Function):
+    """``act(group_norm(x))`` on a channels-last map, frozen gamma / beta (fp32 copies); C-ABI ``sam3_gn_nhwc_fwd/bwd``.
+    Input and output keep the channels-last memory the surrounding MIOpen convolutions use."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        x = x.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = x.shape
+        dt = 0 if x.dtype == torch.bfloat16 else 1
+        y = torch.empty_like(x)                                   # preserves the channels-last strides
+        stats = torch.empty(N, groups, 2, device=x.device, dtype=torch.float32)
+        ws = torch.empty(max(lib.sam3_gn_nhwc_workspace_bytes(N, H * W, C, groups), 16), device=x.device, dtype=torch.uint8)
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _seg_check(lib, lib.sam3_gn_nhwc_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                             N, H * W, C, groups, eps, int(relu), dt, ws.data_ptr(), ws.numel(), st),
+                   "sam3_gn_nhwc_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.meta = (groups, relu, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        x, gamma, beta, stats = ctx.saved_tensors
+        groups, relu, dt = ctx.meta
+        N, C, H, W = x.shape
+        gy = gy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x)
+        ws = torch.empty(max(lib.sam3_gn_nhwc_workspace_bytes(N, H * W, C, groups), 16), device=x.device, dtype=torch.uint8)
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _seg_check(lib, lib.sam3_gn_nhwc_bwd(x.data_ptr(), gy.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             stats.data_ptr(), gx.data_ptr(), N, H * W, C, groups, int(relu), dt,
+                                             ws.data_ptr(), ws.numel(), st), "sam3_gn_nhwc_bwd")
+        return gx, None, None, None, None, None
+
+
+def _affine_f32(gn: nn.GroupNorm):
+    """fp32 copies of the frozen gamma / beta, refreshed when the parameters change (load_state_dict, .to())."""
+    key = (gn.weight.data_ptr(), gn.weight._version, gn.bias.data_ptr(), gn.bias._version, gn.weight.device)
+    held = gn.__dict__.get("_sam3_affine_f32")
+    if held is None or held[0] != key:
+        held = (key, gn.weight.detach().float().contiguous(), gn.bias.detach().float().contiguous())
+        gn.__dict__["_sam3_affine_f32"] = held
+    return held[1], held[2]
+
+
+def group_norm_relu(x: torch.Tensor, gn: nn.GroupNorm, relu: bool = True) -> torch.Tensor:
+    """``relu(gn(x))``: through the channels-last kernels where they apply, else the PyTorch operators."""
+    if gn_kernels_support(x, gn):
+        gamma, beta = _affine_f32(gn)
+        return _GroupNormNHWC.apply(x, gamma, beta, gn.num_groups, float(gn.eps), relu)
+    y = gn(x)
+    return F.relu(y) if relu else y
+
+
+class _MaskDot(torch.autograd.Function):
+    """``einsum("...bqc,bchw->...bqhw")`` for a channels-last pixel embedding: the pixel gradient leaves as
+    ``g^T q`` straight into channels-last memory (autograd's own formula writes it NCHW and the convolution before it
+    converts 340 MB back)."""
+
+    @staticmethod
+    def forward(ctx, q, pix):
+        B, C, H, W = pix.shape
+        pv = pix.permute(0, 2, 3, 1).reshape(B, H * W, C)                  # a view of the channels-last memory
+        lead = q.shape[:-3]
+        q3 = q.reshape(-1, *q.shape[-3:]) if lead else q.unsqueeze(0)      # [L, B, Q, C]
+        L, _, Q, _ = q3.shape
+        qb = q3.permute(1, 0, 2, 3).reshape(B, L * Q, C)
+        out = torch.bmm(qb, pv.transpose(1, 2))                            # [B, L*Q, HW]
+        ctx.save_for_backward(qb, pv)
+        ctx.dims = (L, Q, B, C, H, W, tuple(q.shape))
+        out = out.reshape(B, L, Q, H, W).permute(1, 0, 2, 3, 4)
+        return out.reshape(*q.shape[:-1], H, W) if L > 1 or lead else out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        qb, pv = ctx.saved_tensors
+        L, Q, B, C, H, W, qshape = ctx.dims
+        g3 = g.reshape(L, B, Q, H * W).permute(1, 0, 2, 3).reshape(B, L * Q, H * W)
+        gq = gpix = None
+        if ctx.needs_input_grad[0]:
+            gq = torch.bmm(g3, pv).reshape(B, L, Q, C).permute(1, 0, 2, 3).reshape(qshape)
+        if ctx.needs_input_grad[1]:
+            gp = torch.bmm(g3.transpose(1, 2), qb)                         # [B, HW, C]: channels-last memory
+            gpix = gp.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return gq, gpix
 
 
 class MaskPredictor(nn.Module):
@@ -35,6 +145,10 @@ class MaskPredictor(nn.Module):
         q = self.mask_embed(obj_queries)
         lead = "l" if obj_queries.dim() == 4 else ""
         pix = "chw" if pixel_embed.ndim == 3 else "bchw"
+        if (pixel_embed.ndim == 4 and pixel_embed.is_cuda and not pixel_embed.is_contiguous()
+                and pixel_embed.is_contiguous(memory_format=torch.channels_last) and q.dtype == pixel_embed.dtype
+                and q.shape[-3] == pixel_embed.shape[0]):
+            return _MaskDot.apply(q, pixel_embed)
         return torch.einsum(f"{lead}bqc,{pix}->{lead}bqhw", q, pixel_embed)
 
 
@@ -57,7 +171,7 @@ class PixelDecoder(nn.Module):
         for i, finer in enumerate(reversed(backbone_feats[:-1])):
             k = 0 if self.shared_conv else i
             x = finer + F.interpolate(x, size=finer.shape[-2:], mode=self.interpolation_mode)
-            x = F.relu(self.norms[k](self.conv_layers[k](x)))
+            x = group_norm_relu(self.conv_layers[k](x), self.norms[k])
         return x
 
 
@@ -93,7 +207,10 @@ class UniversalSegmentationHead(nn.Module):
             levels = list(finer)
         hw = math.prod(backbone_feats[-1].shape[-2:])
         tokens = encoder_hidden_states.permute(1, 2, 0)[..., :hw]
-        levels.append(tokens.reshape(-1, *backbone_feats[-1].shape[1:]))
+        coarse = tokens.reshape(-1, *backbone_feats[-1].shape[1:])
+        if coarse.is_cuda:      # [HW, B, C] memory seen as [B, C, H, W]: make it the channels-last map the FPN levels are
+            coarse = coarse.contiguous(memory_format=torch.channels_last)
+        levels.append(coarse)
         if self.act_ckpt and torch.is_grad_enabled():
             return checkpoint(self.pixel_decoder, levels, use_reentrant=False)
         return self.pixel_decoder(levels)

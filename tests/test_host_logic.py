@@ -233,9 +233,12 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     fp8_hdr = open(os.path.join(build.INCLUDE, "sam3_fp8_amd.h")).read()
     fp8_declared = set(re.findall(r"\b(sam3_fp8_[a-z_]+)\s*\(", fp8_hdr))
     assert fp8_declared == set(_ffi.FP8_EXPORTS), fp8_declared ^ set(_ffi.FP8_EXPORTS)
+    seg_hdr = open(os.path.join(build.INCLUDE, "sam3_seg_amd.h")).read()
+    seg_declared = set(re.findall(r"\b(sam3_(?:seg|gn)_[a-z_]+)\s*\(", seg_hdr))
+    assert seg_declared == set(_ffi.SEG_EXPORTS), seg_declared ^ set(_ffi.SEG_EXPORTS)
     assert lib_has_packed_sizes()
     lib = ctypes.CDLL(path)
-    for sym in declared | vit_declared | loss_declared | fp8_declared:
+    for sym in declared | vit_declared | loss_declared | fp8_declared | seg_declared:
         assert hasattr(lib, sym), sym
     lib2 = _ffi.load()
     assert lib2.sam3_lora_abi_version() == 2
