@@ -43,14 +43,14 @@ def test_group_norm_relu_kernels_match_torch(dtype, shape, relu):
     x0 = (torch.randn(shape, generator=g) * 1.5 + 0.4).to(dev, dtype)
     gy0 = torch.randn(shape, generator=g).to(dev, dtype)
     for fmt in (torch.channels_last, torch.contiguous_format):
-        x = x0.contiguous(memory_format=fmt).requires_grad_(True)
+        x = x0.detach().clone(memory_format=fmt).requires_grad_(True)
         assert gn_kernels_support(x, gn)
         y = group_norm_relu(x, gn, relu=relu)
         assert y.shape == x.shape and y.dtype == dtype
         assert y.is_contiguous(memory_format=torch.channels_last)
         y.backward(gy0.contiguous(memory_format=fmt))
         # reference: the same expression in fp32 on the same (rounded) input
-        xr = x0.float().requires_grad_(True)
+        xr = x0.detach().float().clone().requires_grad_(True)
         yr = F.group_norm(xr, G, gn.weight.float(), gn.bias.float(), gn.eps)
         yr = F.relu(yr) if relu else yr
         yr.backward(gy0.float())
@@ -67,7 +67,7 @@ def test_pixel_decoder_on_channels_last_levels_matches_the_pytorch_form():
     dev, dt = "cuda", torch.bfloat16
     torch.manual_seed(0)
     dec = PixelDecoder(64, 2).to(dev, dt).requires_grad_(False)
-    feats = [torch.randn(2, 64, s, s, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    feats = [torch.randn(2, 64, s, s, device=dev, dtype=dt).clone(memory_format=torch.channels_last).requires_grad_(True)
              for s in (32, 16, 8)]
     out = dec(feats)
     out.float().square().mean().backward()
@@ -93,7 +93,7 @@ def test_channels_last_mask_dot_equals_einsum(lead):
     pix0 = torch.randn(B, C, H, W, generator=g).to(dev, dt)
     q0 = torch.randn(*((3,) if lead else ()), B, Q, C, generator=g).to(dev, dt)
     go = torch.randn(*((3,) if lead else ()), B, Q, H, W, generator=g).to(dev, dt)
-    pix = pix0.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pix = pix0.clone(memory_format=torch.channels_last).requires_grad_(True)
     q = q0.clone().requires_grad_(True)
     out = _MaskDot.apply(q, pix)
     out.backward(go)

@@ -22,6 +22,9 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n
 
 
+import sys
+P_DROP = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0      # attention-probability dropout (the model trains with 0.1)
+print(f"dropout_p = {P_DROP}")
 for name, (B, H, Lq, Lk, D, bias) in {"encoder self   [8,8,5184,32]": (8, 8, 5184, 5184, 32, False),
                                       "encoder self   pad d=64": (8, 8, 5184, 5184, 64, False),
                                       "decoder cross  [8,8,401x5184,32]+bias": (8, 8, 401, 5184, 32, True),
@@ -35,12 +38,12 @@ for name, (B, H, Lq, Lk, D, bias) in {"encoder self   [8,8,5184,32]": (8, 8, 518
         try:
             with sdpa_kernel(be):
                 def run():
-                    o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, scale=scale)
+                    o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, scale=scale, dropout_p=P_DROP)
                     o.backward(o)
 
                 def fwd():
                     with torch.no_grad():
-                        F.scaled_dot_product_attention(q, k, v, attn_mask=m, scale=scale)
+                        F.scaled_dot_product_attention(q, k, v, attn_mask=m, scale=scale, dropout_p=P_DROP)
                 tf, tb = timeit(fwd), timeit(run)
                 print(f"{name:40s} {be.name:20s} fwd {tf:7.3f} ms   fwd+bwd {tb:7.3f} ms")
         except Exception as e:
