@@ -53,6 +53,16 @@ int sam3_mask_loss_fwd(const void* src, const void* tgt, float* sums, int N, int
 int sam3_mask_loss_bwd(const void* src, const void* tgt, const float* coef, void* gsrc, int N, int h, int w, int H, int W,
                        float alpha, float gamma, int dtype, int grad_dtype, void* stream);
 
+/*
+ * Matched box pairs (sam3/train/loss/loss_fns.py:345-400 "Boxes", :410-470 the IoU-aware targets of "IABCEMdetr"; the
+ * arithmetic of sam3/model/box_ops.py:generalized_box_iou on the diagonal): a[i], b[i] are xyxy fp32 boxes, [T, 4].
+ *   out[i]  = ( IoU(a[i], b[i]),  GIoU(a[i], b[i]) )                                   fp32 [T, 2]
+ *   ga[i]   = coef[i][0] * dIoU/da[i] + coef[i][1] * dGIoU/da[i]                       fp32 [T, 4]  (b is a target)
+ * One launch each instead of ~35 small elementwise operators (and as many autograd nodes) per decoder output.
+ */
+int sam3_box_pair_fwd(const float* a, const float* b, float* out, int T, void* stream);
+int sam3_box_pair_bwd(const float* a, const float* b, const float* coef, float* ga, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

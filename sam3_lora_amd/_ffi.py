@@ -35,7 +35,7 @@ VIT_EXPORTS = ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd", "sam3_vit_qkv_r
                "sam3_vit_qkv_rope_win_bwd", "sam3_vit_win_residual", "sam3_vit_layernorm_fwd",
                "sam3_vit_layernorm_bwd", "sam3_vit_layernorm_bwd_add")      # include/sam3_vit_amd.h
 LOSS_EXPORTS = ("sam3_loss_last_error", "sam3_mask_loss_workspace_bytes", "sam3_mask_loss_fwd",
-                "sam3_mask_loss_bwd")                                          # include/sam3_loss_amd.h
+                "sam3_mask_loss_bwd", "sam3_box_pair_fwd", "sam3_box_pair_bwd")                                          # include/sam3_loss_amd.h
 FP8_EXPORTS = ("sam3_fp8_last_error", "sam3_fp8_quantize")                 # include/sam3_fp8_amd.h
 SEG_EXPORTS = ("sam3_seg_last_error", "sam3_gn_nhwc_supported", "sam3_gn_nhwc_workspace_bytes", "sam3_gn_nhwc_fwd",
                "sam3_gn_nhwc_bwd")                                             # include/sam3_seg_amd.h
@@ -133,6 +133,10 @@ def _declare(lib):
     lib.sam3_mask_loss_bwd.restype = c_int
     lib.sam3_mask_loss_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_float, c_int, c_int, c_void_p]
+    lib.sam3_box_pair_fwd.restype = c_int
+    lib.sam3_box_pair_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+    lib.sam3_box_pair_bwd.restype = c_int
+    lib.sam3_box_pair_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
     lib.sam3_fp8_last_error.restype = c_char_p
     lib.sam3_fp8_last_error.argtypes = []
     lib.sam3_fp8_quantize.restype = c_int

@@ -238,6 +238,70 @@ __global__ __launch_bounds__(128) void k_mask_bwd(const ST* __restrict__ src, co
     st_grad(gsrc + ((long long)n * h + i) * w + j, acc);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// matched box pairs: IoU and generalised IoU of a[i] (prediction, xyxy) with b[i] (target, xyxy), and the gradient of
+// any function of the two with respect to a.  One thread per pair; stands in for ~35 tiny elementwise operators per
+// decoder output (loss_fns.py "Boxes" :345-400 through box_ops.generalized_box_iou's diagonal), which cost host time,
+// not device time.  Sub-gradients follow autograd's: clamp(min=0) passes the gradient at 0, min / max split it at ties.
+// ------------------------------------------------------------------------------------------------------------------
+struct PairTerms {
+    float iw, ih, hw, hh, inter, uni, hull, area_a;
+};
+__device__ __forceinline__ PairTerms pair_terms(const float4 a, const float4 b) {
+    PairTerms t;
+    t.area_a = (a.z - a.x) * (a.w - a.y);
+    const float area_b = (b.z - b.x) * (b.w - b.y);
+    t.iw = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
+    t.ih = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
+    t.hw = fmaxf(fmaxf(a.z, b.z) - fminf(a.x, b.x), 0.f);
+    t.hh = fmaxf(fmaxf(a.w, b.w) - fminf(a.y, b.y), 0.f);
+    t.inter = t.iw * t.ih;
+    t.hull = t.hw * t.hh;
+    t.uni = t.area_a + area_b - t.inter;
+    return t;
+}
+
+__global__ __launch_bounds__(64) void k_box_pair_fwd(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                     float2* __restrict__ out, int T) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= T) return;
+    const PairTerms t = pair_terms(a[i], b[i]);
+    const float iou = t.inter / t.uni;
+    out[i] = make_float2(iou, iou - (t.hull - t.uni) / t.hull);
+}
+
+// weight of `x` in min(x, y) / max(x, y): 1 when it is the selected operand, 1/2 at a tie, 0 otherwise
+__device__ __forceinline__ float sel_min(float x, float y) { return x < y ? 1.f : (x == y ? 0.5f : 0.f); }
+__device__ __forceinline__ float sel_max(float x, float y) { return x > y ? 1.f : (x == y ? 0.5f : 0.f); }
+
+__global__ __launch_bounds__(64) void k_box_pair_bwd(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                     const float2* __restrict__ coef, float4* __restrict__ ga, int T) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= T) return;
+    const float4 A = a[i], B = b[i];
+    const PairTerms t = pair_terms(A, B);
+    const float c_iou = coef[i].x, c_giou = coef[i].y;
+    // out = c_iou * iou + c_giou * (iou - 1 + uni / hull); iou = inter / uni
+    const float k = c_iou + c_giou;
+    const float g_inter_direct = k / t.uni;                                   // d/d inter at fixed uni
+    const float g_uni = -k * t.inter / (t.uni * t.uni) + c_giou / t.hull;       // d/d uni
+    const float g_hull = -c_giou * t.uni / (t.hull * t.hull);
+    const float g_inter = g_inter_direct - g_uni;                             // uni = area_a + area_b - inter
+    const float g_area = g_uni;
+    // inter = iw * ih, iw = clamp(min(a.z, b.z) - max(a.x, b.x), 0)
+    const float riw = fminf(A.z, B.z) - fmaxf(A.x, B.x), rih = fminf(A.w, B.w) - fmaxf(A.y, B.y);
+    const float g_iw = riw >= 0.f ? g_inter * t.ih : 0.f, g_ih = rih >= 0.f ? g_inter * t.iw : 0.f;
+    const float rhw = fmaxf(A.z, B.z) - fminf(A.x, B.x), rhh = fmaxf(A.w, B.w) - fminf(A.y, B.y);
+    const float g_hw = rhw >= 0.f ? g_hull * t.hh : 0.f, g_hh = rhh >= 0.f ? g_hull * t.hw : 0.f;
+    const float wa = A.z - A.x, ha = A.w - A.y;
+    float4 g;
+    g.x = -g_area * ha - g_iw * sel_max(A.x, B.x) - g_hw * sel_min(A.x, B.x);
+    g.y = -g_area * wa - g_ih * sel_max(A.y, B.y) - g_hh * sel_min(A.y, B.y);
+    g.z = g_area * ha + g_iw * sel_min(A.z, B.z) + g_hw * sel_max(A.z, B.z);
+    g.w = g_area * wa + g_ih * sel_min(A.w, B.w) + g_hh * sel_max(A.w, B.w);
+    ga[i] = g;
+}
+
 extern "C" {
 
 const char* sam3_loss_last_error(void) { return g_err; }
@@ -301,6 +365,30 @@ int sam3_mask_loss_bwd(const void* src, const void* tgt, const float* coef, void
 #undef L
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-5, "sam3_mask_loss_bwd: %s", hipGetErrorString(e));
+}
+
+int sam3_box_pair_fwd(const float* a, const float* b, float* out, int T, void* stream) {
+    g_err[0] = 0;
+    if (T < 0) return fail(-22, "bad pair count %d", T);
+    if (T == 0) return 0;
+    if (!a || !b || !out) return fail(-22, "NULL pointer");
+    if (((uintptr_t)a | (uintptr_t)b) & 15 || ((uintptr_t)out & 7)) return fail(-22, "boxes must be 16-byte aligned");
+    hipLaunchKernelGGL(k_box_pair_fwd, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const float4*)a,
+                       (const float4*)b, (float2*)out, T);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(-5, "sam3_box_pair_fwd: %s", hipGetErrorString(e));
+}
+
+int sam3_box_pair_bwd(const float* a, const float* b, const float* coef, float* ga, int T, void* stream) {
+    g_err[0] = 0;
+    if (T < 0) return fail(-22, "bad pair count %d", T);
+    if (T == 0) return 0;
+    if (!a || !b || !coef || !ga) return fail(-22, "NULL pointer");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 15 || ((uintptr_t)coef & 7)) return fail(-22, "boxes must be 16-byte aligned");
+    hipLaunchKernelGGL(k_box_pair_bwd, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const float4*)a,
+                       (const float4*)b, (const float2*)coef, (float4*)ga, T);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(-5, "sam3_box_pair_bwd: %s", hipGetErrorString(e));
 }
 
 }  // extern "C"

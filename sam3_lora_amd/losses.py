@@ -26,8 +26,49 @@ __all__ = ["CORE_LOSS_KEY", "sigmoid_focal_loss", "dice_loss", "Boxes", "IABCEMd
 
 
 # ------------------------------------------------------------------------------------------------ box utils --
+class _BoxPair(torch.autograd.Function):
+    """(IoU, GIoU) of matched xyxy pairs a[T,4] (predictions), b[T,4] (targets) -> [T,2]; gradient with respect to a.
+    C-ABI ``sam3_box_pair_fwd/bwd`` (include/sam3_loss_amd.h): one launch per direction instead of ~35 elementwise
+    operators and autograd nodes per decoder output -- host time, which is what the loss phase is made of."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty(a.shape[0], 2, device=a.device, dtype=torch.float32)
+        rc = lib.sam3_box_pair_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0],
+                                   ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_box_pair_fwd failed ({rc}): {lib.sam3_loss_last_error().decode()}")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        a, b = ctx.saved_tensors
+        g = g.contiguous().float()
+        ga = torch.empty_like(a)
+        rc = lib.sam3_box_pair_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), ga.data_ptr(), a.shape[0],
+                                   ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_box_pair_bwd failed ({rc}): {lib.sam3_loss_last_error().decode()}")
+        return ga, None
+
+
+def _box_pair_kernel(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and a.shape == b.shape
+            and a.shape[-1] == 4 and a.shape[0] > 0 and not b.requires_grad)
+
+
 def diag_box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Element-wise IoU of matched xyxy boxes a[N,4], b[N,4]."""
+    if _box_pair_kernel(a, b):
+        return _BoxPair.apply(a, b)[:, 0]
     area_a = (a[:, 2:] - a[:, :2]).prod(-1)
     area_b = (b[:, 2:] - b[:, :2]).prod(-1)
     inter = (torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0).prod(-1)
@@ -35,6 +76,8 @@ def diag_box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def diag_generalized_box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    if _box_pair_kernel(a, b):
+        return _BoxPair.apply(a, b)[:, 1]
     area_a = (a[:, 2:] - a[:, :2]).prod(-1)
     area_b = (b[:, 2:] - b[:, :2]).prod(-1)
     inter = (torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0).prod(-1)

@@ -228,7 +228,7 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     vit_declared = set(re.findall(r"\b(sam3_vit_[a-z_]+)\s*\(", vit_hdr))
     assert vit_declared == set(_ffi.VIT_EXPORTS), vit_declared ^ set(_ffi.VIT_EXPORTS)
     loss_hdr = open(os.path.join(build.INCLUDE, "sam3_loss_amd.h")).read()
-    loss_declared = set(re.findall(r"\b(sam3_(?:loss|mask_loss)_[a-z_]+)\s*\(", loss_hdr))
+    loss_declared = set(re.findall(r"\b(sam3_(?:loss|mask_loss|box_pair)_[a-z_]+)\s*\(", loss_hdr))
     assert loss_declared == set(_ffi.LOSS_EXPORTS), loss_declared ^ set(_ffi.LOSS_EXPORTS)
     fp8_hdr = open(os.path.join(build.INCLUDE, "sam3_fp8_amd.h")).read()
     fp8_declared = set(re.findall(r"\b(sam3_fp8_[a-z_]+)\s*\(", fp8_hdr))

@@ -127,3 +127,35 @@ def test_masks_loss_kernel_and_pytorch_paths_agree_in_the_loss_stack(golden_dir)
     for k in ("loss_mask", "loss_dice", LS.CORE_LOSS_KEY):
         assert abs(float(res[0][0][k]) - float(res[1][0][k])) <= 2e-5 * abs(float(res[1][0][k]))
     assert (res[0][1] - res[1][1]).abs().max() <= 2e-4 * res[1][1].abs().max()
+
+
+@pytest.mark.gpu
+def test_box_pair_kernels_match_the_elementwise_formulation():
+    """sam3_box_pair_fwd / _bwd behind diag_box_iou / diag_generalized_box_iou on the GPU against the operator-by-operator
+    expressions (the CPU path of the same functions) in fp64: values and the gradient with respect to the predictions,
+    for overlapping, nested, disjoint, touching and identical (tie) boxes."""
+    from sam3_lora_amd.losses import diag_box_iou, diag_generalized_box_iou
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(64, 2, generator=g) * 0.6
+    wh = torch.rand(64, 2, generator=g) * 0.35 + 0.02
+    a = torch.cat([xy, xy + wh], 1)
+    xy2 = torch.rand(64, 2, generator=g) * 0.6
+    wh2 = torch.rand(64, 2, generator=g) * 0.35 + 0.02
+    b = torch.cat([xy2, xy2 + wh2], 1)
+    b[:4] = a[:4]                                                     # identical boxes: every min / max is a tie
+    b[4:8] = torch.tensor([0.30, 0.30, 0.40, 0.40]); a[4:8] = torch.tensor([0.10, 0.10, 0.90, 0.80])    # nested
+    a[8:12] = torch.tensor([0.05, 0.05, 0.15, 0.15]); b[8:12] = torch.tensor([0.50, 0.60, 0.90, 0.95])  # disjoint
+    a[12:14] = torch.tensor([0.10, 0.10, 0.30, 0.30]); b[12:14] = torch.tensor([0.30, 0.10, 0.50, 0.30])  # touching edge
+    w = torch.randn(64, 2, generator=g)
+    ad = a.double().requires_grad_(True)
+    ref = (diag_box_iou(ad, b.double()) * w[:, 0].double() + diag_generalized_box_iou(ad, b.double()) * w[:, 1].double())
+    ref.sum().backward()
+    ac = a.cuda().requires_grad_(True)
+    got = diag_box_iou(ac, b.cuda()) * w[:, 0].cuda() + diag_generalized_box_iou(ac, b.cuda()) * w[:, 1].cuda()
+    assert "BoxPair" in type(diag_box_iou(ac, b.cuda()).grad_fn.next_functions[0][0]).__name__      # the kernel path ran
+    got.sum().backward()
+    assert torch.allclose(got.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ac.grad.cpu().double(), ad.grad, rtol=1e-4, atol=1e-5)
+    # empty match lists stay on the operator path
+    e = torch.zeros(0, 4, device="cuda")
+    assert diag_generalized_box_iou(e, e).shape == (0,)
