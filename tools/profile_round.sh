@@ -20,6 +20,7 @@ cd "$R"
 db() { find "$1" -name '*.db' | head -1; }
 python tools/rocpd_summary.py stats "$(db /tmp/p_stats)" > "$OUT/${TAG}_kernel_stats.txt"
 python tools/rocpd_summary.py stats_all "$(db /tmp/p_full)" 60 naive_conv > "$OUT/${TAG}_fullstep_kernel_stats.txt"
+python tools/rocpd_summary.py gaps "$(db /tmp/p_full)" naive_conv > "$OUT/${TAG}_fullstep_idle.txt"
 python tools/rocpd_summary.py pmc "$(db /tmp/p_fetch)" > "$OUT/${TAG}_pmc_fetch.txt"
 python tools/rocpd_summary.py pmc "$(db /tmp/p_write)" > "$OUT/${TAG}_pmc_write.txt"
 python tools/rocpd_summary.py traffic "$(db /tmp/p_fetch)" "$(db /tmp/p_write)" > "$OUT/${TAG}_traffic.json"

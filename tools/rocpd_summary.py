@@ -71,6 +71,39 @@ def stats_all(db, top=45, after=None):
         print(f"{k:112s} {len(d):6d} {sum(d) / 1e3:12.1f} {sum(d) / len(d) / 1e3:10.2f} {100 * sum(d) / tot:6.2f}")
 
 
+def gaps(db, after=None, min_us=20, top=30):
+    """Where the GPU waits for the host in a whole-model step: idle intervals between consecutive kernels (one stream's
+    worth of work: the end of everything dispatched so far -> the next start), attributed to the kernel that ENDS the
+    wait and bucketed by step phase markers; steady state only when `after` is given (as in stats_all)."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    if after:
+        hits = [st for name, st, _ in rows if after in name]
+        if hits:
+            rows = [r for r in rows if r[1] > max(hits)]
+    busy_end, idle_total, busy = rows[0][2], 0, 0
+    by_next, big = {}, []
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
+        busy_end = max(busy_end, e0)
+        g = s1 - busy_end
+        if g > 0:
+            idle_total += g
+            if g >= float(min_us) * 1e3:
+                k = short(n1, 80)
+                a = by_next.setdefault(k, [0, 0])
+                a[0] += g; a[1] += 1
+                big.append((g, short(n0, 60), k))
+    span = rows[-1][2] - rows[0][1]
+    print(f"# GPU idle between kernels: {idle_total / 1e6:.2f} ms of a {span / 1e6:.2f} ms span "
+          f"({100 * idle_total / span:.1f} %), {len(rows)} dispatches")
+    print(f"# idle intervals >= {min_us} us by the kernel that ends them (total ms, count):")
+    for k, (t, c) in sorted(by_next.items(), key=lambda kv: -kv[1][0])[:int(top)]:
+        print(f"{t / 1e6:9.3f} {c:6d}  {k}")
+    print("# the 25 longest waits (ms): previous kernel -> next kernel")
+    for g, a, b in sorted(big, reverse=True)[:25]:
+        print(f"{g / 1e6:9.3f}  {a}  ->  {b}")
+
+
 def pmc(db):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, grid_size_x, grid_size_y, workgroup_size_x, counter_name, value "
@@ -113,4 +146,4 @@ def traffic(db_fetch, db_write):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "stats_all": stats_all, "pmc": pmc, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "stats_all": stats_all, "gaps": gaps, "pmc": pmc, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
