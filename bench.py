@@ -569,7 +569,7 @@ class FullStep:
         self.opt = torch.optim.AdamW(self.params, lr=5e-5, weight_decay=0.01)
         self.matcher, self.wrapper = build_criterion("global" if world > 1 else "local")
         if match_once:
-            self.model.set_prefetch_matcher(self.matcher)
+            self.model.set_prefetch_matcher(self.wrapper)
         ds = SyntheticSegmentDataset(2 * batch * world, resolution=res, source=src)
         self.batches = []
         for k in range(2):          # two resident batches, alternated
@@ -597,7 +597,7 @@ class FullStep:
         out = self.model(b)
         mark("forward")
         targets = [self.model.back_convert(t) for t in b.find_targets]
-        match_all_steps(self.matcher, out.output, targets)
+        match_all_steps(self.wrapper, out.output, targets)
         mark("matching (host LSAP)")
         loss = self.wrapper(out, targets)["core_loss"]
         mark("loss")

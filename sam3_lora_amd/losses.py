@@ -239,7 +239,7 @@ class IABCEMdetr(LossWithWeights):
         b, s, t = indices
         with torch.no_grad():
             hard = torch.zeros(logits.shape[:2], dtype=torch.float, device=logits.device)
-            hard[(b, s)] = 1
+            hard[(b, s)] = hard.new_ones(())             # a device scalar: a python 1 is copied host -> device, blocking
             tgt_xyxy = targets["boxes_xyxy"][t] if t is not None else targets["boxes_xyxy"]
             iou = diag_box_iou(outputs["pred_boxes_xyxy"][(b, s)], tgt_xyxy)
             soft_val = torch.clamp(prob[(b, s)] ** self.alpha * iou ** (1 - self.alpha), 0.01).detach()
@@ -338,6 +338,14 @@ class BinaryOneToManyMatcher(nn.Module):
     @torch.no_grad()
     def forward(self, outputs, batched_targets, repeats=1, repeat_batch=1, out_is_valid=None,
                 target_is_valid_padded=None):
+        return self.collect(self.launch(outputs, batched_targets, repeats, repeat_batch, out_is_valid,
+                                        target_is_valid_padded))
+
+    @torch.no_grad()
+    def launch(self, outputs, batched_targets, repeats=1, repeat_batch=1, out_is_valid=None,
+               target_is_valid_padded=None) -> Dict:
+        """The match mask on the device and its asynchronous copy to the host (pinned buffer + event); ``collect`` lists
+        the matches there.  ``torch.nonzero`` on the device would make the host wait for everything queued before it."""
         assert repeats <= 1 and repeat_batch <= 1
         bs, nq = outputs["pred_logits"].shape[:2]
         prob = outputs["pred_logits"].float().sigmoid().squeeze(-1)      # fp32: torch.quantile rejects bf16
@@ -346,8 +354,7 @@ class BinaryOneToManyMatcher(nn.Module):
         assert len(tgt) == bs
         nt = tgt.shape[1]
         if nt == 0:
-            e = torch.empty(0, dtype=torch.long, device=prob.device)
-            return e, e.clone(), e.clone()
+            return dict(mask=None, device=prob.device)
         iou, _ = box_iou(box_cxcywh_to_xyxy(outputs["pred_boxes"].float()), box_cxcywh_to_xyxy(tgt))
         C = self.alpha * prob.unsqueeze(-1) + (1 - self.alpha) * iou
         if out_is_valid is not None:
@@ -360,9 +367,37 @@ class BinaryOneToManyMatcher(nn.Module):
         if target_is_valid_padded is not None:
             m = m & target_is_valid_padded[:, None, :]
         m = m & (torch.arange(nt, device=num_boxes.device)[None] < num_boxes[:, None]).unsqueeze(1)
-        bi, si, ti = torch.nonzero(m, as_tuple=True)
-        offs = torch.cat([torch.zeros(1, dtype=num_boxes.dtype, device=num_boxes.device), num_boxes.cumsum(-1)[:-1]])
-        return bi, si, ti + offs[bi]
+        host_counts = batched_targets.get("num_boxes_host")
+        event = None
+        if m.is_cuda:
+            m_host = torch.empty(m.shape, dtype=torch.bool, pin_memory=True)
+            m_host.copy_(m, non_blocking=True)
+            if host_counts is None:
+                n_host = torch.empty(num_boxes.shape, dtype=num_boxes.dtype, pin_memory=True)
+                n_host.copy_(num_boxes, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(m.device))
+        else:
+            m_host, n_host = m, num_boxes
+        if host_counts is not None:
+            n_host = torch.as_tensor(list(host_counts), dtype=torch.long)
+        return dict(mask=m_host, counts=n_host, event=event, device=m.device)
+
+    @torch.no_grad()
+    def collect(self, handle: Dict):
+        device = handle["device"]
+        if handle["mask"] is None:
+            e = torch.empty(0, dtype=torch.long, device=device)
+            return e, e.clone(), e.clone()
+        if handle["event"] is not None:
+            handle["event"].synchronize()
+        bi, si, ti = torch.nonzero(handle["mask"], as_tuple=True)          # host side, row-major like the device's
+        counts = handle["counts"].long()
+        offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(-1)[:-1]])
+        found = torch.stack((bi, si, ti + offs[bi]))
+        if device.type == "cuda":
+            found = found.pin_memory().to(device, non_blocking=True)
+        return found[0], found[1], found[2]
 
 
 # --------------------------------------------------------------------------------------------------- wrapper --
@@ -392,6 +427,43 @@ class Sam3LossWrapper(nn.Module):
             return torch.clamp(n, min=1)
         return 1
 
+    # ---- all the matching of one decoder output (final + auxiliary, one-to-one + one-to-many) in two halves ---------
+    @staticmethod
+    def _o2m_view(out: Dict) -> Optional[Dict]:
+        return {k[:-4]: v for k, v in out.items() if k.endswith("_o2m")} if "pred_logits_o2m" in out else None
+
+    @torch.no_grad()
+    def launch_matching(self, nested_out: Dict, targets: Dict) -> Optional[Dict]:
+        """Everything ``compute_loss`` and the training loop match for this output -- the Hungarian matching of the final
+        and auxiliary outputs, of the auxiliaries' one-to-many twins, the greedy one-to-many matching of the final output --
+        as ONE batched cost expression plus one mask, copied to the host asynchronously.  Needs only scores and boxes, so
+        it can be started right after the decoder; ``collect_matching`` finishes it on the host."""
+        if nested_out.get("o2m_out_is_valid") is not None or nested_out.get("o2m_target_is_valid_padded") is not None:
+            return None
+        outs = [nested_out] + list(nested_out.get("aux_outputs", ()))
+        hung, o2m_jobs = list(outs), []
+        for i, o in enumerate(outs):
+            view = self._o2m_view(o)
+            if view is None:
+                continue
+            if self.use_o2m_matcher_on_o2m_aux or i == 0:
+                o2m_jobs.append((i, self.o2m_matcher.launch(view, targets)))
+            else:
+                o2m_jobs.append((i, len(hung)))
+                hung.append(view)
+        return dict(n=len(outs), hungarian=self.matcher.launch(hung, targets), o2m=o2m_jobs, owner=self)
+
+    @torch.no_grad()
+    def collect_matching(self, handle: Dict, nested_out: Dict) -> None:
+        """Sets ``indices`` (and ``indices_o2m``) on the output and its auxiliaries."""
+        outs = [nested_out] + list(nested_out.get("aux_outputs", ()))
+        assert handle["n"] == len(outs)
+        found = self.matcher.collect(handle["hungarian"])
+        for o, idx in zip(outs, found):
+            o["indices"] = idx
+        for i, job in handle["o2m"]:
+            outs[i]["indices_o2m"] = found[job] if isinstance(job, int) else self.o2m_matcher.collect(job)
+
     def compute_loss(self, nested_out: Dict, targets: Dict) -> Dict[str, torch.Tensor]:
         num_boxes = self._num_boxes(targets)
         ov, tv = nested_out.get("o2m_out_is_valid"), nested_out.get("o2m_target_is_valid_padded")
@@ -405,8 +477,10 @@ class Sam3LossWrapper(nn.Module):
             indices = out["indices"]
             o2m_out = {k[:-4]: v for k, v in out.items() if k.endswith("_o2m")} if "pred_logits_o2m" in out else None
             if o2m_out is not None:
-                mt = self.o2m_matcher if (self.use_o2m_matcher_on_o2m_aux or not is_aux) else self.matcher
-                o2m_idx = mt(o2m_out, targets, out_is_valid=ov, target_is_valid_padded=tv)
+                o2m_idx = out.get("indices_o2m")            # matched beforehand (launch_matching / collect_matching)
+                if o2m_idx is None:
+                    mt = self.o2m_matcher if (self.use_o2m_matcher_on_o2m_aux or not is_aux) else self.matcher
+                    o2m_idx = mt(o2m_out, targets, out_is_valid=ov, target_is_valid_padded=tv)
             for fn in self.loss_fns_find:
                 d = fn(outputs=out, targets=targets, indices=indices, num_boxes=num_boxes, is_aux=is_aux)
                 total = total + d.pop(CORE_LOSS_KEY)

@@ -183,23 +183,31 @@ class BinaryHungarianMatcherV2(nn.Module):
         image_ids_all = keep.nonzero().squeeze(1).tolist() if self.remove_samples_with_0_gt else list(range(len(solved)))
         n_img = len(solved) // L                 # rows per output (images kept x repeat_batch)
         total_rows = (len(keep) // L) if keep is not None else n_img
-        results = []
+        results, upload = [], []
         for l in range(L):
             rows = solved[l * n_img:(l + 1) * n_img]
             cnt = counts[l * n_img:(l + 1) * n_img]
             ids = [i - l * total_rows for i in image_ids_all[l * n_img:(l + 1) * n_img]]
+            empty = np.zeros(0, dtype=np.int64)
             if not rows:
-                src_lists = []
-                tgt_idx = torch.zeros(0, dtype=torch.long, device=device) if want_tgt else None
+                src_lists, tgt_idx = [], (empty if want_tgt else None)
             elif want_tgt:
                 src_lists = [s for s, _ in rows]
                 offsets = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
-                tgt_idx = torch.from_numpy(np.concatenate([t + o for (_, t), o in zip(rows, offsets)])).long().to(device)
+                tgt_idx = np.concatenate([t + o for (_, t), o in zip(rows, offsets)]).astype(np.int64)
             else:
                 src_lists, tgt_idx = rows, None
-            batch_idx = torch.as_tensor([ids[i] for i, s in enumerate(src_lists) for _ in range(len(s))],
-                                        dtype=torch.long, device=device)
-            src_idx = (torch.from_numpy(np.concatenate(src_lists)).long().to(device) if src_lists
-                       else torch.empty(0, dtype=torch.long, device=device))
-            results.append((batch_idx, src_idx, tgt_idx))
+            batch_idx = np.asarray([ids[i] for i, s in enumerate(src_lists) for _ in range(len(s))], dtype=np.int64)
+            src_idx = np.concatenate(src_lists).astype(np.int64) if src_lists else empty
+            upload.append((batch_idx, src_idx, tgt_idx))
+        # ONE host -> device transfer for every index list of every output (pinned, asynchronous on a GPU: a pageable
+        # copy would block the host until the stream -- with the mask head queued on it -- has drained)
+        flat = [a for trip in upload for a in trip if a is not None]
+        sizes = [len(a) for a in flat]
+        packed = torch.from_numpy(np.concatenate(flat) if flat else np.zeros(0, dtype=np.int64))
+        if device.type == "cuda":
+            packed = packed.pin_memory().to(device, non_blocking=True)
+        parts = iter(packed.split(sizes)) if flat else iter(())
+        for b_, s_, t_ in upload:
+            results.append((next(parts), next(parts), None if t_ is None else next(parts)))
         return results

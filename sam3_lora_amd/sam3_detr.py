@@ -172,7 +172,10 @@ class DotProductScoring(nn.Module):
         if self.prompt_mlp is not None:
             prompt = self.prompt_mlp(prompt)
         pooled = self.prompt_proj(masked_mean(prompt, prompt_mask))
-        scores = torch.matmul(self.hs_proj(hs), pooled.unsqueeze(-1)).float() * self.scale
+        # [layers, B, Q, C] . [B, C]: written as a multiply + row sum in fp32, not as a batched matrix-VECTOR product --
+        # rocBLAS' path for the N = 1 batched GEMM of its backward ([48, 256, 400] x [48, 400, 1]) spends 12.7 ms on the
+        # host per call with the device idle (profiles/r02g_hostops.txt)
+        scores = (self.hs_proj(hs).float() * pooled.float()[None, :, None, :]).sum(-1, keepdim=True) * self.scale
         if self.clamp_logits:
             scores = scores.clamp(min=-self.clamp_max_val, max=self.clamp_max_val)
         return scores

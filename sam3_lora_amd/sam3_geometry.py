@@ -117,6 +117,8 @@ def roi_align(feats: torch.Tensor, boxes: Sequence[torch.Tensor], output_size: i
     S = output_size
     out = []
     for b, per_image in enumerate(boxes):
+        if per_image.shape[0] == 0:         # text-only prompts (the training path): nothing to read back from the device
+            continue
         fm = feats[b]
         for box in per_image.tolist():
             x1, y1, x2, y2 = box
@@ -216,7 +218,8 @@ class SequenceGeometryEncoder(nn.Module):
             parts.append(self.boxes_direct_project(boxes.to(wd)))
         if self.boxes_pool_project is not None:
             H, W = img_nchw.shape[-2:]
-            px = box_cxcywh_to_xyxy(boxes) * torch.tensor([W, H, W, H], dtype=boxes.dtype, device=boxes.device)
+            xyxy = box_cxcywh_to_xyxy(boxes)        # to feature-map pixels; python scalars, no host -> device copy
+            px = torch.stack((xyxy[..., 0] * W, xyxy[..., 1] * H, xyxy[..., 2] * W, xyxy[..., 3] * H), dim=-1)
             pooled = roi_align(img_nchw, px.float().transpose(0, 1).unbind(0), self.roi_size)
             parts.append(self.boxes_pool_project(pooled).view(bs, n, self.d_model).transpose(0, 1))
         if self.boxes_pos_enc_project is not None:

@@ -161,8 +161,9 @@ class Sam3Image(nn.Module):
         return next(self.parameters()).device
 
     def set_prefetch_matcher(self, matcher) -> None:
-        """Start the training loop's matching inside ``forward`` right after the decoder (``matcher.launch``); the loop's
-        ``match_all_steps`` collects.  ``None`` switches it off."""
+        """Start the training loop's matching inside ``forward`` right after the decoder (``matcher.launch``, or the loss
+        wrapper's ``launch_matching`` which covers the one-to-many indices too); the loop's ``match_all_steps`` -- called
+        with the same object -- collects.  ``None`` switches it off."""
         object.__setattr__(self, "prefetch_matcher", matcher)
 
     # ----------------------------------------------------------------------------------------------- pieces --
@@ -288,7 +289,9 @@ class Sam3Image(nn.Module):
             # scores and boxes are final here: start the matcher's cost + device->host copy now, so that the host-side
             # assignment later overlaps with the mask head's device work instead of following it
             m = self.prefetch_matcher
-            out["_match_handle"] = (m, m.launch([out] + list(out.get("aux_outputs", ())), self.back_convert(find_target)))
+            tg = self.back_convert(find_target)
+            out["_match_handle"] = (m, m.launch_matching(out, tg) if hasattr(m, "launch_matching")
+                                    else m.launch([out] + list(out.get("aux_outputs", ())), tg))
         self._run_segmentation_heads(out, backbone_out, find_input.img_ids, out["encoder_hidden_states"], prompt,
                                      prompt_mask, hs)
         if self.training and self.match_in_forward and self.matcher is not None:

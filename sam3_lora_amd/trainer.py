@@ -152,15 +152,28 @@ def _steps(stage) -> List[Dict]:
 
 
 def match_all_steps(matcher, stage_outputs: Sequence, stage_targets: Sequence[Dict]) -> None:
-    """``outputs["indices"]`` for every step of every stage and each of its aux outputs (:914-927)."""
+    """``outputs["indices"]`` for every step of every stage and each of its aux outputs (:914-927).  ``matcher`` is the
+    Hungarian matcher -- or the loss wrapper, which then also prepares the one-to-many indices its ``compute_loss`` would
+    otherwise match one by one (``Sam3LossWrapper.launch_matching``): one batched cost, one device->host copy.  A handle
+    left by the model's forward (``Sam3Image.set_prefetch_matcher``) is collected instead of starting over."""
+    whole = hasattr(matcher, "launch_matching")
     for stage, targets in zip(stage_outputs, stage_targets):
         for outputs in _steps(stage):
             pending = outputs.pop("_match_handle", None) if isinstance(outputs, dict) else None
             aux_outputs = list(outputs.get("aux_outputs", ()))
-            if pending is not None and pending[0] is matcher and pending[1]["L"] == 1 + len(aux_outputs):
-                found = matcher.collect(pending[1])             # started inside the model's forward (prefetch_matcher)
+            mine = pending is not None and pending[0] is matcher and pending[1] is not None
+            if whole:
+                handle = pending[1] if mine else matcher.launch_matching(outputs, targets)
+                if handle is not None:
+                    matcher.collect_matching(handle, outputs)
+                    continue
+                hungarian, mine = matcher.matcher, False        # validity masks present: the plain per-output path
             else:
-                found = matcher.collect(matcher.launch([outputs] + aux_outputs, targets))
+                hungarian = matcher
+            if mine and pending[1]["L"] == 1 + len(aux_outputs):
+                found = hungarian.collect(pending[1])           # started inside the model's forward
+            else:
+                found = hungarian.collect(hungarian.launch([outputs] + aux_outputs, targets))
             outputs["indices"] = found[0]
             for aux, idx in zip(aux_outputs, found[1:]):
                 aux["indices"] = idx
@@ -223,7 +236,7 @@ class SAM3TrainerNative:
         # engine.match_once: the loop's matching starts inside the forward, right after the decoder, and its host part
         # overlaps with the mask head's device work (Sam3Image.set_prefetch_matcher); same indices either way
         if (self.config.get("engine") or {}).get("match_once", False) and hasattr(self.model, "set_prefetch_matcher"):
-            self.model.set_prefetch_matcher(self.matcher)
+            self.model.set_prefetch_matcher(self.loss_wrapper)
 
     # ------------------------------------------------------------------------------------------------
     def _say(self, msg: str) -> None:
@@ -236,7 +249,7 @@ class SAM3TrainerNative:
         outputs = self.model(input_batch)
         targets = [self.model.back_convert(t) for t in input_batch.find_targets]
         targets = [move_to_device(t, self.device) for t in targets]
-        match_all_steps(self.matcher, outputs, targets)
+        match_all_steps(self.loss_wrapper, outputs, targets)
         return self.loss_wrapper(outputs, targets)[CORE_LOSS_KEY]
 
     def train_step(self, batch) -> float:

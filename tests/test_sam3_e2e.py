@@ -162,6 +162,30 @@ def test_matching_started_inside_forward_gives_the_reference_indices(gold):
     out = model(batch)
     match_all_steps(other, out.output, targets)
     check_outputs(gold, "train", out[0], 2e-5, indices=True)
+    # the loss wrapper as the prefetcher: also the one-to-many indices its compute_loss would match one by one
+    matcher2, wrapper = _criterion()
+    model.set_prefetch_matcher(wrapper)
+    out = model(batch)
+    assert out[0]["_match_handle"][0] is wrapper
+    match_all_steps(wrapper, out.output, targets)
+    stage = out[0]
+    check_outputs(gold, "train", stage, 2e-5, indices=True)
+    assert "indices_o2m" in stage and all("indices_o2m" in a for a in stage["aux_outputs"])
+    o2m = lambda o: {k[:-4]: v for k, v in o.items() if k.endswith("_o2m")}
+    for a, b in zip(stage["indices_o2m"], wrapper.o2m_matcher(o2m(stage), targets[0])):
+        assert torch.equal(a, b)
+    for aux in stage["aux_outputs"]:
+        for a, b in zip(aux["indices_o2m"], matcher2(o2m(aux), targets[0])):
+            assert (a is None and b is None) or torch.equal(a, b)
+    with_pre = wrapper(out, targets)
+    model.set_prefetch_matcher(None)
+    out2 = model(batch)
+    match_all_steps(matcher2, out2.output, targets)                 # the plain path: compute_loss matches the twins itself
+    assert "indices_o2m" not in out2[0]
+    plain = wrapper(out2, targets)
+    assert set(plain) == set(with_pre)
+    for k in plain:
+        assert torch.equal(plain[k].detach(), with_pre[k].detach()), k
 
 
 # ------------------------------------------------------------------------------------------------------- GPU --

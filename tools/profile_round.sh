@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 A="python $R/bench.py --adapter-only --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
-F="python $R/bench.py --full-only --steps 4 --warmup 2 --no-fp8"
+F="python $R/bench.py --full-only --steps 4 --warmup 2 --no-fp8 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o bench -- $A > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/p_full -o bench -- $F > "$OUT/full.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -o bench -- $A > "$OUT/fetch.log" 2>&1
@@ -20,7 +20,7 @@ cd "$R"
 db() { find "$1" -name '*.db' | head -1; }
 python tools/rocpd_summary.py stats "$(db /tmp/p_stats)" > "$OUT/${TAG}_kernel_stats.txt"
 python tools/rocpd_summary.py stats_all "$(db /tmp/p_full)" 60 naive_conv > "$OUT/${TAG}_fullstep_kernel_stats.txt"
-python tools/rocpd_summary.py gaps "$(db /tmp/p_full)" naive_conv > "$OUT/${TAG}_fullstep_idle.txt"
+python tools/rocpd_summary.py gaps "$(db /tmp/p_full)" > "$OUT/${TAG}_fullstep_idle.txt"
 python tools/rocpd_summary.py pmc "$(db /tmp/p_fetch)" > "$OUT/${TAG}_pmc_fetch.txt"
 python tools/rocpd_summary.py pmc "$(db /tmp/p_write)" > "$OUT/${TAG}_pmc_write.txt"
 python tools/rocpd_summary.py traffic "$(db /tmp/p_fetch)" "$(db /tmp/p_write)" > "$OUT/${TAG}_traffic.json"

@@ -71,37 +71,52 @@ def stats_all(db, top=45, after=None):
         print(f"{k:112s} {len(d):6d} {sum(d) / 1e3:12.1f} {sum(d) / len(d) / 1e3:10.2f} {100 * sum(d) / tot:6.2f}")
 
 
-def gaps(db, after=None, min_us=20, top=30):
-    """Where the GPU waits for the host in a whole-model step: idle intervals between consecutive kernels (one stream's
-    worth of work: the end of everything dispatched so far -> the next start), attributed to the kernel that ENDS the
-    wait and bucketed by step phase markers; steady state only when `after` is given (as in stats_all)."""
+def gaps(db, delim="k_pack", min_us=20, top=30):
+    """Where the GPU waits for the host in a whole-model step.  The trace is cut into steps at every dispatch of
+    `delim` (one per optimizer step: the batched operand repack); only the steps within 5 % of the shortest one are
+    analysed (the timed, unsynchronised steps -- warm-up, phase timing and profiling steps of bench.py are longer).
+    Idle = intervals with nothing running (end of everything dispatched so far -> next start), attributed to the
+    kernel that ENDS the wait."""
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-    if after:
-        hits = [st for name, st, _ in rows if after in name]
-        if hits:
-            rows = [r for r in rows if r[1] > max(hits)]
-    busy_end, idle_total, busy = rows[0][2], 0, 0
-    by_next, big = {}, []
-    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
-        busy_end = max(busy_end, e0)
-        g = s1 - busy_end
-        if g > 0:
-            idle_total += g
-            if g >= float(min_us) * 1e3:
-                k = short(n1, 80)
-                a = by_next.setdefault(k, [0, 0])
-                a[0] += g; a[1] += 1
-                big.append((g, short(n0, 60), k))
-    span = rows[-1][2] - rows[0][1]
-    print(f"# GPU idle between kernels: {idle_total / 1e6:.2f} ms of a {span / 1e6:.2f} ms span "
-          f"({100 * idle_total / span:.1f} %), {len(rows)} dispatches")
-    print(f"# idle intervals >= {min_us} us by the kernel that ends them (total ms, count):")
+    marks = [i for i, r in enumerate(rows) if short(r[0]).startswith(delim)]
+    steps = [(a, b) for a, b in zip(marks, marks[1:]) if b - a > 100]
+    durs = [rows[b][1] - rows[a][1] for a, b in steps]
+    keep = [sb for sb, d in zip(steps, durs) if d <= 1.05 * min(durs)]
+    by_next, big, idle_total, busy_total, ctx_rows = {}, [], 0, 0, []
+    for a, b in keep:
+        busy_end = rows[a][2]
+        for (n0, s0, e0), (n1, s1, e1) in zip(rows[a:b], rows[a + 1:b + 1]):
+            busy_end = max(busy_end, e0)
+            g = s1 - busy_end
+            if g > 0:
+                idle_total += g
+                if g >= float(min_us) * 1e3:
+                    k = short(n1, 80)
+                    acc = by_next.setdefault(k, [0, 0])
+                    acc[0] += g; acc[1] += 1
+                    big.append((g, short(n0, 60), k))
+                    ctx_rows.append((g, s1))
+    n = max(len(keep), 1)
+    span = sum(rows[b][1] - rows[a][1] for a, b in keep)
+    print(f"# {len(steps)} steps between '{delim}' dispatches, {len(keep)} steady ones analysed "
+          f"({span / n / 1e6:.2f} ms each): GPU idle {idle_total / n / 1e6:.2f} ms per step ({100 * idle_total / max(span, 1):.1f} %)")
+    print(f"# idle intervals >= {min_us} us by the kernel that ends them (ms per step, count per step):")
     for k, (t, c) in sorted(by_next.items(), key=lambda kv: -kv[1][0])[:int(top)]:
-        print(f"{t / 1e6:9.3f} {c:6d}  {k}")
-    print("# the 25 longest waits (ms): previous kernel -> next kernel")
-    for g, a, b in sorted(big, reverse=True)[:25]:
-        print(f"{g / 1e6:9.3f}  {a}  ->  {b}")
+        print(f"{t / n / 1e6:9.3f} {c / n:7.1f}  {k}")
+    print("# the 20 longest waits (ms): previous kernel -> next kernel")
+    for g, a_, b_ in sorted(big, reverse=True)[:20]:
+        print(f"{g / 1e6:9.3f}  {a_}  ->  {b_}")
+    print("# context of the 6 longest waits: 4 kernels before | 6 kernels after")
+    starts = [r[1] for r in rows]
+    import bisect
+    for g, s1 in sorted(ctx_rows, reverse=True)[:6]:
+        i = bisect.bisect_left(starts, s1)
+        print(f"{g / 1e6:9.3f} ms")
+        for r in rows[max(i - 4, 0):i]:
+            print(f"             before  {short(r[0], 100)}")
+        for r in rows[i:i + 6]:
+            print(f"             after   {short(r[0], 100)}")
 
 
 def pmc(db):
