@@ -231,6 +231,9 @@ def test_training_step_through_hip_adapters_matches_reference(gold, ckpt):
     layers = _inject(model, gold)
     model.to(dev).train()
     matcher, wrapper = _criterion()
+    if not ckpt:        # the production schedule: all matching launched inside the forward, collected here
+        model.set_prefetch_matcher(wrapper)
+        matcher = wrapper
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.LR, weight_decay=D.WD)
     batch = move_to_device(make_batch(), dev)
     losses = []
