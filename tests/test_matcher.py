@@ -46,3 +46,36 @@ def test_giou_properties():
     g = generalized_box_iou(x, x)
     assert torch.allclose(torch.diag(g), torch.ones(2), atol=1e-6)
     assert g[0, 1] < 0 and torch.allclose(g, g.t())
+
+
+def _batched_equals_one_by_one(device):
+    """launch / collect over several outputs (a decoder's final + auxiliary ones) = the per-output calls, also with images
+    without targets (removed from the cost), with a target-index list (more targets than queries) and with the host copy of
+    the box counts the collator provides."""
+    g = torch.Generator().manual_seed(7)
+    for B, Q, counts, L in ((3, 12, [2, 0, 4], 4), (2, 3, [5, 1], 3), (4, 10, [1, 1, 1, 1], 6), (2, 6, [0, 0], 2)):
+        T = max(max(counts), 1)
+        cxcy = torch.rand(B, T, 2, generator=g) * 0.6 + 0.2
+        tgt = torch.cat([cxcy, torch.rand(B, T, 2, generator=g) * 0.3 + 0.05], -1).to(device)
+        outs = [{"pred_logits": torch.randn(B, Q, 1, generator=g).to(device),
+                 "pred_boxes": torch.cat([torch.rand(B, Q, 2, generator=g) * 0.6 + 0.2,
+                                          torch.rand(B, Q, 2, generator=g) * 0.3 + 0.05], -1).to(device)} for _ in range(L)]
+        nb = torch.tensor(counts, dtype=torch.long, device=device)
+        m = BinaryHungarianMatcherV2(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0, focal=True)
+        for targets in ({"num_boxes": nb, "boxes_padded": tgt},
+                        {"num_boxes": nb, "boxes_padded": tgt, "num_boxes_host": tuple(counts)}):
+            together = m.collect(m.launch(outs, targets))
+            assert len(together) == L
+            for o, got in zip(outs, together):
+                alone = m(o, {"num_boxes": nb, "boxes_padded": tgt})
+                for a, b in zip(got, alone):
+                    assert (a is None and b is None) or (a.dtype == torch.int64 and torch.equal(a, b))
+
+
+def test_batched_matching_equals_one_by_one_cpu():
+    _batched_equals_one_by_one("cpu")
+
+
+@pytest.mark.gpu
+def test_batched_matching_equals_one_by_one_gpu():
+    _batched_equals_one_by_one("cuda:0")
