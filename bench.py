@@ -111,7 +111,16 @@ class Workload:
         from sam3_lora_amd.functional import lora_bwd_, lora_fwd_, pack_operands
         s, L, dp = self.scaling, 0, self.dropout
         prepack = os.environ.get("BENCH_PREPACK", "1") != "0"
+        dbg = os.environ.get("BENCH_DEBUG_TIMING") == "1"
+        marks = []
+
+        def mark(name):
+            if dbg:
+                torch.cuda.synchronize()
+                marks.append((name, time.perf_counter()))
+        mark("start")
         self.reducer.zero_grad()
+        mark("zero_grad")
         with torch.no_grad():
             if prepack:         # A/B changed at the optimizer step: pack ALL adapters once (4 launches for 64 of them);
                                 # forward, checkpoint recompute and backward of the step use these images
@@ -127,6 +136,7 @@ class Workload:
                 t2 = lora_fwd_(self.h[k], self.A2[b], self.B2[b], self.y2[k], s, L, save_t=not recompute, drop_p=dp,
                                seed=2 * b + 1, packed=p2)
                 self.tT1[b], self.tT2[b] = t1, t2
+            mark("pack + forward")
             for b in reversed(range(self.blocks)):             # per-block recompute, then backward
                 k = b & 1
                 p1, p2 = (self.P1[b], self.P2[b]) if prepack else (None, None)
@@ -143,7 +153,12 @@ class Workload:
                           self.A1[b].grad, self.B1[b].grad, s, L, accumulate=True, drop_p=dp, seed=2 * b, packed=p1)
                 for p in (self.A1[b], self.B1[b], self.A2[b], self.B2[b]):
                     self.reducer.notify(p)
+        mark("recompute + backward")
         self.reducer.finish()
+        mark("exchange")
+        if dbg:
+            print("[adapter step] " + ", ".join(f"{n} {1e3 * (t - marks[i][1]):.1f} ms" for i, (n, t) in enumerate(marks[1:])),
+                  file=sys.stderr, flush=True)
 
 
 def time_events(fn, iters, warm=3, reps=5):
