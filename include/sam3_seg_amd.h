@@ -1,5 +1,6 @@
 /*
- * sam3_lora_amd -- C-ABI of the mask head's normalisation kernels (gfx950): GroupNorm (+ ReLU) on channels-last maps.
+ * sam3_lora_amd -- C-ABI of two helpers of the model around the adapter path (gfx950): GroupNorm (+ ReLU) on
+ * channels-last maps for the mask head, and the decoder's box-relative position bias.
  *
  * Host helper of the model around the adapter path (the pixel decoder that produces
  * the mask logits the mask loss reads).  Replaces, for frozen affine parameters,
@@ -46,6 +47,17 @@ int sam3_gn_nhwc_fwd(const void* x, const float* gamma, const float* beta, void*
 int sam3_gn_nhwc_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* stats, void* gx,
                      int N, int64_t HW, int C, int G, int relu, int dtype, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/*
+ * Decoder: box-relative position bias of the image cross-attention (sam3/model/decoder.py:357-407, boxRPB "log" or the
+ * plain offsets).  Forward only: the reference boxes are detached and the two MLPs frozen in LoRA training.
+ *   boxes  fp32 [Q, B, 4] cxcywh in [0, 1];  mlp_x / mlp_y: {W1 [hidden, 2], b1 [hidden], W2 [heads, hidden], b2 [heads]}
+ *   in the layer dtype (bf16 / fp32);  out [B, heads, Q + presence_row, H * W] in the layer dtype, written once:
+ *   out[b, h, q, y * W + x] = mlp_y(offsets of row y / H to the box's y-edges)[h] + mlp_x(offsets of column x / W)[h],
+ *   an all-zero row first when presence_row != 0.  Offsets are log-scaled (sign(8 d) log2(|8 d| + 1) / 3) when log_scale.
+ */
+int sam3_rpb_bias_fwd(const float* boxes, const void* const* mlp_x, const void* const* mlp_y, void* out, int B, int Q, int H,
+                      int W, int hidden, int heads, int presence_row, int log_scale, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

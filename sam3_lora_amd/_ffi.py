@@ -38,7 +38,7 @@ LOSS_EXPORTS = ("sam3_loss_last_error", "sam3_mask_loss_workspace_bytes", "sam3_
                 "sam3_mask_loss_bwd", "sam3_box_pair_fwd", "sam3_box_pair_bwd")                                          # include/sam3_loss_amd.h
 FP8_EXPORTS = ("sam3_fp8_last_error", "sam3_fp8_quantize")                 # include/sam3_fp8_amd.h
 SEG_EXPORTS = ("sam3_seg_last_error", "sam3_gn_nhwc_supported", "sam3_gn_nhwc_workspace_bytes", "sam3_gn_nhwc_fwd",
-               "sam3_gn_nhwc_bwd")                                             # include/sam3_seg_amd.h
+               "sam3_gn_nhwc_bwd", "sam3_rpb_bias_fwd")                                             # include/sam3_seg_amd.h
 FP8_E4M3, FP8_E5M2 = 0, 1
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
@@ -153,6 +153,8 @@ def _declare(lib):
     lib.sam3_gn_nhwc_bwd.restype = c_int
     lib.sam3_gn_nhwc_bwd.argtypes = [c_void_p] * 6 + [c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                      c_void_p]
+    lib.sam3_rpb_bias_fwd.restype = c_int
+    lib.sam3_rpb_bias_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]

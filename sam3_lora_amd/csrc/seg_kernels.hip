@@ -287,6 +287,91 @@ int launched(const char* what) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// decoder: box-relative position bias of the image cross-attention (sam3/model/decoder.py:357-407, "boxRPB = log").
+// For every query box and every token row / column: the signed log-scaled offsets to the box's two edges go through a
+// two-layer MLP per axis (2 -> hidden -> heads, ReLU); the bias of token (y, x) is the sum of its row and column terms.
+// The reference builds this from ~75 small operators per decoder layer (K = 2 batched GEMMs, broadcast adds over
+// [B, Q, 72, 256], a 26 MB permute + copy); the boxes are detached and the MLPs frozen, so no gradient is needed:
+// one workgroup per (image, query) evaluates both MLPs into LDS and writes its [heads, H*W] slab once, head-major.
+// Roundings follow the layer dtype where the operator chain rounds: MLP input, hidden activation, MLP output, the sum.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float rnd(float v);
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<bf16_t>(float v) {
+    const float f[2] = {v, 0.f};
+    return __uint_as_float(V16<bf16_t>::pk(f[0], f[1]) << 16);
+}
+template <typename T> __device__ __forceinline__ float ldw(const T* p, long long i);
+template <> __device__ __forceinline__ float ldw<float>(const float* p, long long i) { return p[i]; }
+template <> __device__ __forceinline__ float ldw<bf16_t>(const bf16_t* p, long long i) { return __uint_as_float((unsigned)p[i] << 16); }
+template <typename T> __device__ __forceinline__ void stw(T* p, long long i, float v);
+template <> __device__ __forceinline__ void stw<float>(float* p, long long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stw<bf16_t>(bf16_t* p, long long i, float v) {
+    p[i] = (bf16_t)(V16<bf16_t>::pk(v, 0.f) & 0xffffu);
+}
+
+struct RpbMlp {            // one axis: W1 [hidden, 2], b1 [hidden], W2 [heads, hidden], b2 [heads] in the layer dtype
+    const void *w1, *b1, *w2, *b2;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rpb_bias(const float* __restrict__ boxes /* [Q, B, 4] cxcywh */, RpbMlp mx, RpbMlp my,
+                                                  T* __restrict__ out /* [B, heads, Q + pr, H * W] */, int B, int Q, int H,
+                                                  int W, int hidden, int heads, int presence_row, int log_scale) {
+    extern __shared__ float sm[];
+    float* term = sm;                                   // [(H + W)][heads]: rows first, then columns
+    const int b = blockIdx.y, qo = blockIdx.x;           // qo: output row (0 = presence row when presence_row)
+    const int QO = Q + presence_row;
+    const long long HW = (long long)H * W;
+    T* ob = out + ((long long)b * heads * QO + qo) * HW;  // + h * QO * HW per head
+    if (presence_row && qo == 0) {
+        for (int h = 0; h < heads; ++h)
+            for (long long p = threadIdx.x; p < HW; p += 256) stw<T>(ob + (long long)h * QO * HW, p, 0.f);
+        return;
+    }
+    const int q = qo - presence_row;
+    const float* bx = boxes + ((long long)q * B + b) * 4;
+    const float cx = bx[0], cy = bx[1], w = bx[2], hh = bx[3];
+    const float x0 = cx - 0.5f * w, y0 = cy - 0.5f * hh, x1 = cx + 0.5f * w, y1 = cy + 0.5f * hh;
+    for (int item = threadIdx.x; item < H + W; item += 256) {
+        const bool row = item < H;
+        const RpbMlp m = row ? my : mx;
+        const int i = row ? item : item - H;
+        const float c = row ? (float)i / (float)H : (float)i / (float)W;
+        float d0 = c - (row ? y0 : x0), d1 = c - (row ? y1 : x1);
+        if (log_scale) {
+            d0 *= 8.f; d1 *= 8.f;
+            d0 = (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f)) * log2f(fabsf(d0) + 1.f) / 3.f;
+            d1 = (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f)) * log2f(fabsf(d1) + 1.f) / 3.f;
+        }
+        d0 = rnd<T>(d0); d1 = rnd<T>(d1);
+        float acc[16];                       // fully unrolled with a predicate: stays in registers for any heads <= 16
+#pragma unroll
+        for (int h = 0; h < 16; ++h) acc[h] = 0.f;
+        const T *w1 = (const T*)m.w1, *b1 = (const T*)m.b1, *w2 = (const T*)m.w2, *b2 = (const T*)m.b2;
+        for (int j = 0; j < hidden; ++j) {
+            float hid = ldw<T>(w1, 2 * j) * d0 + ldw<T>(w1, 2 * j + 1) * d1 + ldw<T>(b1, j);
+            hid = rnd<T>(hid);
+            hid = hid > 0.f ? hid : 0.f;
+#pragma unroll
+            for (int h = 0; h < 16; ++h)
+                if (h < heads) acc[h] += ldw<T>(w2, (long long)h * hidden + j) * hid;
+        }
+#pragma unroll
+        for (int h = 0; h < 16; ++h)
+            if (h < heads) term[item * heads + h] = rnd<T>(acc[h] + ldw<T>(b2, h));
+    }
+    __syncthreads();
+    for (int h = 0; h < heads; ++h) {
+        T* oh = ob + (long long)h * QO * HW;
+        for (long long p = threadIdx.x; p < HW; p += 256) {
+            const int y = (int)(p / W), x = (int)(p % W);
+            stw<T>(oh, p, term[y * heads + h] + term[(H + x) * heads + h]);
+        }
+    }
+}
+
 extern "C" {
 
 const char* sam3_seg_last_error(void) { return g_err; }
@@ -347,6 +432,30 @@ int sam3_gn_nhwc_bwd(const void* x, const void* gy, const float* gamma, const fl
 #undef BSTATS
 #undef BAPPLY
     return launched("sam3_gn_nhwc_bwd");
+}
+
+int sam3_rpb_bias_fwd(const float* boxes, const void* const* mlp_x, const void* const* mlp_y, void* out, int B, int Q, int H,
+                      int W, int hidden, int heads, int presence_row, int log_scale, int dtype, void* stream) {
+    g_err[0] = 0;
+    if (B < 0 || Q < 0 || H <= 0 || W <= 0 || hidden <= 0 || heads <= 0) return fail(EINVAL_, "bad sizes");
+    if (heads > 16) return fail(ENOTSUP_, "at most 16 heads (got %d)", heads);
+    if (dtype != 0 && dtype != 1) return fail(EINVAL_, "dtype must be 0 (bf16) or 1 (fp32), got %d", dtype);
+    if ((size_t)(H + W) * heads * sizeof(float) > 60 * 1024) return fail(ENOTSUP_, "feature map too large for the LDS terms");
+    if (B == 0 || Q + presence_row == 0) return 0;
+    if (!boxes || !mlp_x || !mlp_y || !out) return fail(EINVAL_, "null pointer");
+    for (int i = 0; i < 4; ++i)
+        if (!mlp_x[i] || !mlp_y[i]) return fail(EINVAL_, "null MLP tensor");
+    RpbMlp mx{mlp_x[0], mlp_x[1], mlp_x[2], mlp_x[3]}, my{mlp_y[0], mlp_y[1], mlp_y[2], mlp_y[3]};
+    dim3 grid((unsigned)(Q + presence_row), (unsigned)B);
+    const size_t lds = (size_t)(H + W) * heads * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_rpb_bias<bf16_t>, grid, dim3(256), lds, st, boxes, mx, my, (bf16_t*)out, B, Q, H, W, hidden, heads,
+                           presence_row, log_scale);
+    else
+        hipLaunchKernelGGL(k_rpb_bias<float>, grid, dim3(256), lds, st, boxes, mx, my, (float*)out, B, Q, H, W, hidden, heads,
+                           presence_row, log_scale);
+    return launched("sam3_rpb_bias_fwd");
 }
 
 }  // extern "C"

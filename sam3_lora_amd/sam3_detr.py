@@ -482,6 +482,8 @@ class TransformerDecoder(nn.Module):
         broadcast add of the two small per-axis terms already laid out head-major -- the reference builds it query-major,
         permutes + copies it, and concatenates the presence row with another full copy (decoder.py:395-407, :147-151)."""
         H, W = int(feat_size[0]), int(feat_size[1])
+        if self._rpb_kernel_applies(reference_boxes):
+            return self._rpb_kernel(reference_boxes, H, W, presence_row)
         xyxy = box_cxcywh_to_xyxy(reference_boxes.float()).transpose(0, 1)      # [B, Q, 4]
         ys, xs = self._grid(H, W, reference_boxes.device)
         dy = ys.view(1, 1, H, 1) - xyxy[:, :, None, 1::2]                       # [B, Q, H, 2] (to y0, y1)
@@ -506,6 +508,48 @@ class TransformerDecoder(nn.Module):
         if presence_row:
             by, bx = F.pad(by, (0, 0, 1, 0)), F.pad(bx, (0, 0, 1, 0))
         return (by.unsqueeze(-1) + bx.unsqueeze(-2)).flatten(3)                # [B, heads, Q(+1), H*W], contiguous
+
+    def _rpb_kernel_applies(self, reference_boxes: torch.Tensor) -> bool:
+        """``sam3_rpb_bias_fwd`` (include/sam3_seg_amd.h) covers the training path: boxes detached (they are, between
+        decoder layers), the two per-axis MLPs frozen plain 2 -> hidden -> heads stacks in bf16 / fp32, log or plain
+        offsets.  Anything else (trainable or adapted MLPs, "both", autocast, CPU) keeps the operator formulation."""
+        if not reference_boxes.is_cuda or reference_boxes.requires_grad or self.boxRPB not in ("log", "linear"):
+            return False
+        if torch.is_autocast_enabled():
+            return False
+        for mlp in (self.boxRPB_embed_x, self.boxRPB_embed_y):
+            if not (isinstance(mlp, MLP) and len(mlp.layers) == 2 and not mlp.residual
+                    and isinstance(mlp.drop, nn.Identity) and isinstance(mlp.out_norm, nn.Identity)):
+                return False
+            l1, l2 = mlp.layers
+            if type(l1) is not nn.Linear or type(l2) is not nn.Linear or l1.in_features != 2 or l2.out_features > 16:
+                return False
+            ps = (l1.weight, l1.bias, l2.weight, l2.bias)
+            if any(p is None or p.requires_grad or p.dtype != l1.weight.dtype or not p.is_cuda for p in ps):
+                return False
+            if l1.weight.dtype not in (torch.bfloat16, torch.float32):
+                return False
+        return self.boxRPB_embed_x.layers[0].weight.dtype == self.boxRPB_embed_y.layers[0].weight.dtype == self.norm.weight.dtype
+
+    def _rpb_kernel(self, reference_boxes: torch.Tensor, H: int, W: int, presence_row: bool) -> torch.Tensor:
+        import ctypes
+        from . import _ffi
+        lib = _ffi.load()
+        boxes = reference_boxes.detach().float().contiguous()                   # [Q, B, 4]
+        Q, B = boxes.shape[:2]
+        lx, ly = self.boxRPB_embed_x.layers, self.boxRPB_embed_y.layers
+        heads, hidden = lx[1].out_features, lx[0].out_features
+        wd = lx[0].weight.dtype
+        out = torch.empty(B, heads, Q + int(presence_row), H * W, device=boxes.device, dtype=wd)
+        keep = [t.detach().contiguous() for l in (lx, ly) for t in (l[0].weight, l[0].bias, l[1].weight, l[1].bias)]
+        ptrs_x = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in keep[:4]])
+        ptrs_y = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in keep[4:]])
+        rc = lib.sam3_rpb_bias_fwd(boxes.data_ptr(), ptrs_x, ptrs_y, out.data_ptr(), B, Q, H, W, hidden, heads,
+                                   int(presence_row), int(self.boxRPB == "log"), 0 if wd == torch.bfloat16 else 1,
+                                   ctypes.c_void_p(torch.cuda.current_stream(boxes.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sam3_rpb_bias_fwd failed ({rc}): {lib.sam3_seg_last_error().decode()}")
+        return out
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, reference_boxes=None, level_start_index=None,

@@ -234,7 +234,7 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     fp8_declared = set(re.findall(r"\b(sam3_fp8_[a-z_]+)\s*\(", fp8_hdr))
     assert fp8_declared == set(_ffi.FP8_EXPORTS), fp8_declared ^ set(_ffi.FP8_EXPORTS)
     seg_hdr = open(os.path.join(build.INCLUDE, "sam3_seg_amd.h")).read()
-    seg_declared = set(re.findall(r"\b(sam3_(?:seg|gn)_[a-z_]+)\s*\(", seg_hdr))
+    seg_declared = set(re.findall(r"\b(sam3_(?:seg|gn|rpb)_[a-z_]+)\s*\(", seg_hdr))
     assert seg_declared == set(_ffi.SEG_EXPORTS), seg_declared ^ set(_ffi.SEG_EXPORTS)
     assert lib_has_packed_sizes()
     lib = ctypes.CDLL(path)

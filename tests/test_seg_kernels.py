@@ -109,3 +109,41 @@ def test_channels_last_mask_dot_equals_einsum(lead):
     a = mp(q0, pix0.contiguous(memory_format=torch.channels_last))
     b = mp(q0, pix0)
     assert rel(a, b.float()) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("mode", ["log", "linear"])
+@pytest.mark.parametrize("presence_row", [True, False])
+def test_rpb_bias_kernel_matches_the_operator_formulation(dtype, mode, presence_row):
+    """sam3_rpb_bias_fwd (box-relative position bias of the decoder's image cross-attention) against the operator chain
+    of TransformerDecoder._get_rpb_matrix on the same weights: fp32 to rounding noise, bf16 to one bf16 step of the
+    output (both round at the same places; the GEMMs accumulate in a different order)."""
+    from sam3_lora_amd.sam3_image import TINY_CONFIG, build_sam3_image_model
+    model = build_sam3_image_model(device="cpu", eval_mode=False, config=dict(TINY_CONFIG, d_model=64, heads=8, ffn=64),
+                                   match_in_forward=False, seed=3)
+    dec = model.transformer.decoder
+    dec.boxRPB = mode
+    dec.requires_grad_(False).to("cuda", dtype)
+    g = torch.Generator().manual_seed(5)
+    Q, B, H, W = 23, 3, 18, 24
+    cxcy = torch.rand(Q, B, 2, generator=g)
+    wh = torch.rand(Q, B, 2, generator=g) * 0.5 + 0.01
+    boxes = torch.cat([cxcy, wh], -1).cuda()
+    assert dec._rpb_kernel_applies(boxes)
+    got = dec._get_rpb_matrix(boxes, (H, W), presence_row=presence_row)
+    assert got.shape == (B, 8, Q + int(presence_row), H * W) and got.dtype == dtype and got.is_contiguous()
+    dec._rpb_kernel_applies = lambda rb: False                       # the operator formulation of the same method
+    ref = dec._get_rpb_matrix(boxes, (H, W), presence_row=presence_row)
+    assert ref.shape == got.shape
+    if presence_row:
+        assert torch.equal(got[:, :, 0], torch.zeros_like(got[:, :, 0]))
+    err = (got.float() - ref.float()).abs().max().item()
+    scale = ref.float().abs().max().item()
+    assert err <= (2e-2 if dtype == torch.bfloat16 else 2e-6) * max(scale, 1e-3), (err, scale)
+    # trainable MLP weights or boxes with a gradient keep the differentiable operator chain
+    del dec._rpb_kernel_applies
+    dec.boxRPB_embed_x.layers[0].weight.requires_grad_(True)
+    assert not dec._rpb_kernel_applies(boxes)
+    dec.boxRPB_embed_x.layers[0].weight.requires_grad_(False)
+    assert not dec._rpb_kernel_applies(boxes.clone().requires_grad_(True))
