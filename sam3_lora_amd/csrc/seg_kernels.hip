@@ -311,63 +311,133 @@ template <> __device__ __forceinline__ void stw<bf16_t>(bf16_t* p, long long i, 
     p[i] = (bf16_t)(V16<bf16_t>::pk(v, 0.f) & 0xffffu);
 }
 
+template <typename T> __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d);     // p: 4-element aligned
+template <> __device__ __forceinline__ void st4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(V16<bf16_t>::pk(a, b), V16<bf16_t>::pk(c, d));
+}
+
 struct RpbMlp {            // one axis: W1 [hidden, 2], b1 [hidden], W2 [heads, hidden], b2 [heads] in the layer dtype
     const void *w1, *b1, *w2, *b2;
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_rpb_bias(const float* __restrict__ boxes /* [Q, B, 4] cxcywh */, RpbMlp mx, RpbMlp my,
+__global__ __launch_bounds__(512) void k_rpb_bias(const float* __restrict__ boxes /* [Q, B, 4] cxcywh */, RpbMlp mx, RpbMlp my,
                                                   T* __restrict__ out /* [B, heads, Q + pr, H * W] */, int B, int Q, int H,
                                                   int W, int hidden, int heads, int presence_row, int log_scale) {
-    extern __shared__ float sm[];
-    float* term = sm;                                   // [(H + W)][heads]: rows first, then columns
+    // LDS: term [heads][H + W] | per axis (x then y): first layer [hidden] x (w1[j][0], w1[j][1], b1[j], -), second layer
+    //      transposed [hidden][groups] 16-byte words (heads padded to a multiple of 4) | partial sums [nsplit][H + W][4 groups]
+    extern __shared__ float4 sm4[];
+    const int items = H + W, groups = (heads + 3) / 4, NT = blockDim.x;
+    float* term = reinterpret_cast<float*>(sm4);
+    float4* l1 = sm4 + (items * heads + 3) / 4;          // [2][hidden]
+    float4* l2 = l1 + 2 * hidden;                        // [2][hidden][groups]
+    float4* part = l2 + 2 * hidden * groups;             // [nsplit][items][groups]
     const int b = blockIdx.y, qo = blockIdx.x;           // qo: output row (0 = presence row when presence_row)
     const int QO = Q + presence_row;
     const long long HW = (long long)H * W;
     T* ob = out + ((long long)b * heads * QO + qo) * HW;  // + h * QO * HW per head
     if (presence_row && qo == 0) {
         for (int h = 0; h < heads; ++h)
-            for (long long p = threadIdx.x; p < HW; p += 256) stw<T>(ob + (long long)h * QO * HW, p, 0.f);
+            for (long long p = threadIdx.x; p < HW; p += NT) stw<T>(ob + (long long)h * QO * HW, p, 0.f);
         return;
     }
+    for (int e = threadIdx.x; e < 2 * hidden; e += NT) {
+        const RpbMlp m = e < hidden ? mx : my;
+        const int jj = e < hidden ? e : e - hidden;
+        const T *w1 = (const T*)m.w1, *b1 = (const T*)m.b1, *w2 = (const T*)m.w2;
+        l1[e] = make_float4(ldw<T>(w1, 2 * jj), ldw<T>(w1, 2 * jj + 1), ldw<T>(b1, jj), 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < groups) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = 4 * k + u < heads ? ldw<T>(w2, (long long)(4 * k + u) * hidden + jj) : 0.f;
+                l2[e * groups + k] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+    __syncthreads();
     const int q = qo - presence_row;
     const float* bx = boxes + ((long long)q * B + b) * 4;
     const float cx = bx[0], cy = bx[1], w = bx[2], hh = bx[3];
     const float x0 = cx - 0.5f * w, y0 = cy - 0.5f * hh, x1 = cx + 0.5f * w, y1 = cy + 0.5f * hh;
-    for (int item = threadIdx.x; item < H + W; item += 256) {
-        const bool row = item < H;
-        const RpbMlp m = row ? my : mx;
-        const int i = row ? item : item - H;
-        const float c = row ? (float)i / (float)H : (float)i / (float)W;
-        float d0 = c - (row ? y0 : x0), d1 = c - (row ? y1 : x1);
-        if (log_scale) {
-            d0 *= 8.f; d1 *= 8.f;
-            d0 = (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f)) * log2f(fabsf(d0) + 1.f) / 3.f;
-            d1 = (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f)) * log2f(fabsf(d1) + 1.f) / 3.f;
+    // nsplit threads share one (row | column): each takes every nsplit-th hidden unit, partial sums meet in LDS
+    int nsplit = NT / items;
+    nsplit = nsplit < 1 ? 1 : (nsplit > 4 ? 4 : nsplit);
+    for (int base = 0; base < items; base += NT) {        // (more rows + columns than threads: several sweeps, nsplit = 1)
+        const int split = nsplit > 1 ? (int)threadIdx.x / items : 0;
+        const int item = nsplit > 1 ? (int)threadIdx.x % items : base + (int)threadIdx.x;
+        if (item < items && split < nsplit) {
+            const bool row = item < H;
+            const int i = row ? item : item - H;
+            const float c = row ? (float)i / (float)H : (float)i / (float)W;
+            float d0 = c - (row ? y0 : x0), d1 = c - (row ? y1 : x1);
+            if (log_scale) {
+                d0 *= 8.f; d1 *= 8.f;
+                d0 = (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f)) * log2f(fabsf(d0) + 1.f) / 3.f;
+                d1 = (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f)) * log2f(fabsf(d1) + 1.f) / 3.f;
+            }
+            d0 = rnd<T>(d0); d1 = rnd<T>(d1);
+            float4 acc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* a1 = l1 + (row ? hidden : 0);
+            const float4* a2 = l2 + (row ? hidden : 0) * groups;
+            for (int j = split; j < hidden; j += nsplit) {
+                const float4 f = a1[j];
+                float hid = rnd<T>(f.x * d0 + f.y * d1 + f.z);
+                hid = hid > 0.f ? hid : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < groups) {
+                        const float4 wv = a2[j * groups + k];
+                        acc[k].x += wv.x * hid; acc[k].y += wv.y * hid; acc[k].z += wv.z * hid; acc[k].w += wv.w * hid;
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < groups) part[(split * items + item) * groups + k] = acc[k];
         }
-        d0 = rnd<T>(d0); d1 = rnd<T>(d1);
-        float acc[16];                       // fully unrolled with a predicate: stays in registers for any heads <= 16
-#pragma unroll
-        for (int h = 0; h < 16; ++h) acc[h] = 0.f;
-        const T *w1 = (const T*)m.w1, *b1 = (const T*)m.b1, *w2 = (const T*)m.w2, *b2 = (const T*)m.b2;
-        for (int j = 0; j < hidden; ++j) {
-            float hid = ldw<T>(w1, 2 * j) * d0 + ldw<T>(w1, 2 * j + 1) * d1 + ldw<T>(b1, j);
-            hid = rnd<T>(hid);
-            hid = hid > 0.f ? hid : 0.f;
-#pragma unroll
-            for (int h = 0; h < 16; ++h)
-                if (h < heads) acc[h] += ldw<T>(w2, (long long)h * hidden + j) * hid;
-        }
-#pragma unroll
-        for (int h = 0; h < 16; ++h)
-            if (h < heads) term[item * heads + h] = rnd<T>(acc[h] + ldw<T>(b2, h));
+        if (nsplit > 1) break;
     }
     __syncthreads();
-    for (int h = 0; h < heads; ++h) {
-        T* oh = ob + (long long)h * QO * HW;
-        for (long long p = threadIdx.x; p < HW; p += 256) {
-            const int y = (int)(p / W), x = (int)(p % W);
-            stw<T>(oh, p, term[y * heads + h] + term[(H + x) * heads + h]);
+    for (int e = threadIdx.x; e < items * heads; e += NT) {            // fixed-order sum of the partials, bias, rounding
+        const int item = e / heads, h = e % heads;
+        const T* b2 = (const T*)(item < H ? my.b2 : mx.b2);
+        float v = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) v += reinterpret_cast<const float*>(part + (sp * items + item) * groups)[h];
+        term[h * items + item] = rnd<T>(v + ldw<T>(b2, h));           // head-major: conflict-free reads below
+    }
+    __syncthreads();
+    // write the slab: a thread owns QUADS of neighbouring columns of one row (8-byte stores in bf16, 16-byte in fp32);
+    // its (row, quad) position advances by blockDim quads per step without divisions
+    const int HWI = items;
+    if (W % 4 == 0 && H % 4 == 0) {                        // (then every 16-byte LDS word below is aligned too)
+        const int qpr = W / 4;                              // quads per row
+        const int dy = NT / qpr, dxq = NT % qpr;
+        for (int h = 0; h < heads; ++h) {
+            T* oh = ob + (long long)h * QO * HW;
+            const float* ty = term + h * HWI;
+            const float* tx = ty + H;
+            int y = (int)threadIdx.x / qpr, xq = (int)threadIdx.x % qpr;
+            while (y < H) {
+                const float r = ty[y];
+                const int x = 4 * xq;
+                const float4 c = *reinterpret_cast<const float4*>(tx + x);
+                st4<T>(oh + (long long)y * W + x, r + c.x, r + c.y, r + c.z, r + c.w);
+                y += dy; xq += dxq;
+                if (xq >= qpr) { xq -= qpr; ++y; }
+            }
+        }
+    } else {
+        for (int h = 0; h < heads; ++h) {
+            T* oh = ob + (long long)h * QO * HW;
+            for (long long p = threadIdx.x; p < HW; p += NT) {
+                const int y = (int)(p / W), x = (int)(p % W);
+                stw<T>(oh, p, term[h * HWI + y] + term[h * HWI + H + x]);
+            }
         }
     }
 }
@@ -440,20 +510,26 @@ int sam3_rpb_bias_fwd(const float* boxes, const void* const* mlp_x, const void* 
     if (B < 0 || Q < 0 || H <= 0 || W <= 0 || hidden <= 0 || heads <= 0) return fail(EINVAL_, "bad sizes");
     if (heads > 16) return fail(ENOTSUP_, "at most 16 heads (got %d)", heads);
     if (dtype != 0 && dtype != 1) return fail(EINVAL_, "dtype must be 0 (bf16) or 1 (fp32), got %d", dtype);
-    if ((size_t)(H + W) * heads * sizeof(float) > 60 * 1024) return fail(ENOTSUP_, "feature map too large for the LDS terms");
+    const int items = H + W, groups = (heads + 3) / 4;
+    int threads = ((2 * items + 63) / 64) * 64;          // two threads per row / column when that fits a workgroup
+    threads = threads < 256 ? 256 : (threads > 512 ? 512 : threads);
+    int nsplit = threads / items;
+    nsplit = nsplit < 1 ? 1 : (nsplit > 4 ? 4 : nsplit);
+    const size_t lds = ((size_t)((items * heads + 3) / 4) + (size_t)2 * hidden * (1 + groups)
+                        + (size_t)nsplit * items * groups) * sizeof(float4);
+    if (lds > 60 * 1024) return fail(ENOTSUP_, "feature map / hidden width too large for the LDS staging (%zu bytes)", lds);
     if (B == 0 || Q + presence_row == 0) return 0;
     if (!boxes || !mlp_x || !mlp_y || !out) return fail(EINVAL_, "null pointer");
     for (int i = 0; i < 4; ++i)
         if (!mlp_x[i] || !mlp_y[i]) return fail(EINVAL_, "null MLP tensor");
     RpbMlp mx{mlp_x[0], mlp_x[1], mlp_x[2], mlp_x[3]}, my{mlp_y[0], mlp_y[1], mlp_y[2], mlp_y[3]};
     dim3 grid((unsigned)(Q + presence_row), (unsigned)B);
-    const size_t lds = (size_t)(H + W) * heads * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        hipLaunchKernelGGL(k_rpb_bias<bf16_t>, grid, dim3(256), lds, st, boxes, mx, my, (bf16_t*)out, B, Q, H, W, hidden, heads,
+        hipLaunchKernelGGL(k_rpb_bias<bf16_t>, grid, dim3(threads), lds, st, boxes, mx, my, (bf16_t*)out, B, Q, H, W, hidden, heads,
                            presence_row, log_scale);
     else
-        hipLaunchKernelGGL(k_rpb_bias<float>, grid, dim3(256), lds, st, boxes, mx, my, (float*)out, B, Q, H, W, hidden, heads,
+        hipLaunchKernelGGL(k_rpb_bias<float>, grid, dim3(threads), lds, st, boxes, mx, my, (float*)out, B, Q, H, W, hidden, heads,
                            presence_row, log_scale);
     return launched("sam3_rpb_bias_fwd");
 }
