@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -514,6 +515,8 @@ class TransformerDecoder(nn.Module):
         decoder layers), the two per-axis MLPs frozen plain 2 -> hidden -> heads stacks in bf16 / fp32, log or plain
         offsets.  Anything else (trainable or adapted MLPs, "both", autocast, CPU) keeps the operator formulation."""
         if not reference_boxes.is_cuda or reference_boxes.requires_grad or self.boxRPB not in ("log", "linear"):
+            return False
+        if os.environ.get("SAM3_RPB_KERNEL", "1") == "0":         # validation aid: keep the operator chain
             return False
         if torch.is_autocast_enabled():
             return False
