@@ -1,3 +1,8 @@
+"""Why smoke()'s oracle side runs on the CPU: the whole tiny-model step with the adapters in HIP form and in reference form
+(plain torch autograd), both on the GPU, with the decoder's position-bias kernel on and off.  Finding (MI355X, ROCm 7.2,
+torch 2.10): the bias agrees to 2.4e-7 and every forward output to < 1e-6 either way; the HIP form's A/B gradients move by
+7.9e-7 -- the GPU reference form's by 4.2e-3 with a bit-identical loss: some fp32 library kernel in ITS backward changes
+precision with the allocator's state.  Against the CPU fp32 reference form both settings agree to 2e-6."""
 import os, sys, io, contextlib
 sys.path.insert(0, os.getcwd())
 import torch
