@@ -196,23 +196,29 @@ class TransformerWrapper(nn.Module):
                 nn.init.xavier_uniform_(p)
 
 
+_SINE_FREQ: Dict[Tuple, torch.Tensor] = {}
+
+
 def gen_sineembed_for_position(pos: torch.Tensor, num_feats: int = 256) -> torch.Tensor:
-    """[Q, B, 2|4] normalised (x, y[, w, h]) -> [Q, B, 2|4 x num_feats/2] sine code ordered (y, x, w, h)."""
+    """[Q, B, 2|4] normalised (x, y[, w, h]) -> [Q, B, 2|4 x num_feats/2] sine code ordered (y, x, w, h).
+    All coordinates go through one set of operators (the decoder calls this once per layer: operator count is host
+    time there); the frequency table is built once per device."""
     assert num_feats % 2 == 0
     half = num_feats // 2
-    k = torch.arange(half, dtype=torch.float32, device=pos.device)
-    freq = 10000 ** (2 * torch.div(k, 2, rounding_mode="floor") / half)
-
-    def code(v):
-        a = (v * (2 * math.pi))[:, :, None] / freq
-        return torch.stack((a[:, :, 0::2].sin(), a[:, :, 1::2].cos()), dim=3).flatten(2)
-
-    parts = [code(pos[:, :, 1]), code(pos[:, :, 0])]
-    if pos.size(-1) == 4:
-        parts += [code(pos[:, :, 2]), code(pos[:, :, 3])]
-    elif pos.size(-1) != 2:
-        raise ValueError(f"Unknown pos_tensor shape(-1):{pos.size(-1)}")
-    return torch.cat(parts, dim=2)
+    key = (half, str(pos.device))
+    freq = _SINE_FREQ.get(key)
+    if freq is None:
+        k = torch.arange(half, dtype=torch.float32, device=pos.device)
+        freq = _SINE_FREQ[key] = 10000 ** (2 * torch.div(k, 2, rounding_mode="floor") / half)
+    n = pos.size(-1)
+    if n == 4:
+        ordered = torch.stack((pos[:, :, 1], pos[:, :, 0], pos[:, :, 2], pos[:, :, 3]), dim=2)
+    elif n == 2:
+        ordered = torch.stack((pos[:, :, 1], pos[:, :, 0]), dim=2)
+    else:
+        raise ValueError(f"Unknown pos_tensor shape(-1):{n}")
+    a = (ordered * (2 * math.pi))[..., None] / freq                                  # [Q, B, n, half]
+    return torch.stack((a[..., 0::2].sin(), a[..., 1::2].cos()), dim=4).flatten(2)
 
 
 # ===================================================================================================== encoder ==
