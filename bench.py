@@ -51,6 +51,9 @@ def parse():
                     help="activation dtype (f32 = the reference's un-autocast precision; contracted as bf16 on the MFMAs)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0,
+                    help="cpu_baseline by SURVEY 8(d)'s c1 protocol in full: 1 warm-up + N timed B=2 CPU steps (minutes); "
+                         "default 0 = bounded sample")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--trunk", action="store_true", help="also time the ViT trunk alone (with / without recompute)")
     ap.add_argument("--trunk-steps", type=int, default=3)
@@ -455,13 +458,19 @@ def model_setup(kind):
     return dict(SAM3_CONFIG), 1008, 1024
 
 
-def cpu_baseline(kind="sam3", seconds_budget=45.0):
-    """SURVEY section 8(d) "CPU baseline beside it": the reference's own training step -- configs[0]: minimal LoRA
-    (rank 4 on the ViT MLPs, vision encoder only), fp32, CPU -- re-enacted by the oracle-side restatement: this
-    library's PyTorch host model (sam3_image) with the adapters written as the reference writes them
-    (oracle/lora_torch_cpu.py: base + ((x @ A) @ B) * s, torch autograd), matcher, loss wrapper, AdamW.
-    Bounded sample: a probe step on a depth-reduced trunk predicts the cost of the whole step; the whole step (1 image)
-    is timed when it fits the budget, otherwise the figure is the extrapolation from the probe -- `sample` says which."""
+def cpu_baseline(kind="sam3", seconds_budget=120.0, timed_steps=0):
+    """SURVEY section 8(d) "CPU baseline beside it": the reference's own training step -- configs[0] = c1: minimal LoRA
+    (rank 4 on the ViT MLPs, vision encoder only), B = 2 images, fp32, CPU, `torch.set_num_threads(physical cores)` --
+    re-enacted by the oracle-side restatement: this library's PyTorch host model (sam3_image) with the adapters written as
+    the reference writes them (oracle/lora_torch_cpu.py: base + ((x @ A) @ B) * s, torch autograd), matcher (twice per
+    step, as the reference), loss wrapper, AdamW, per-block activation recompute.
+
+    Protocol: c1 asks for 1 warm-up + >= 2 timed steps.  `timed_steps` > 0 (bench.py --cpu-steps N) runs exactly that.
+    By default the sample is BOUNDED so that the bench line still arrives within minutes: a probe (the whole step on a
+    trunk cut to 1 windowed + 1 global block, plus one more block of each kind timed alone) predicts the cost of a B = 2
+    step; when warm-up + 2 timed steps fit `seconds_budget` they are run, otherwise ONE B = 2 step is timed (no warm-up:
+    a CPU step of ~1.5 minutes is not first-touch dominated), otherwise the figure is the probe's extrapolation --
+    `sample` says which."""
     from oracle.lora_torch_cpu import apply_reference_form_lora
     from sam3_lora_amd.sam3_data import SyntheticSegmentDataset, collate_fn_api
     from sam3_lora_amd.sam3_image import build_sam3_image_model
@@ -469,8 +478,9 @@ def cpu_baseline(kind="sam3", seconds_budget=45.0):
     threads, phys = host_cores()
     torch.set_num_threads(phys)
     SAM3_CONFIG, res, src = model_setup(kind)
-    ds = SyntheticSegmentDataset(2, resolution=res, source=src)
-    batch = collate_fn_api([ds[0]], dict_key="input", with_seg_masks=True)["input"]
+    B = 2
+    ds = SyntheticSegmentDataset(2 * B, resolution=res, source=src)
+    batches = [collate_fn_api([ds[k * B + i] for i in range(B)], dict_key="input", with_seg_masks=True)["input"] for k in range(2)]
 
     torch.manual_seed(0)
     model = build_sam3_image_model(device="cpu", eval_mode=False, config=SAM3_CONFIG, match_in_forward=True)
@@ -482,11 +492,12 @@ def cpu_baseline(kind="sam3", seconds_budget=45.0):
     all_blocks, all_global = list(trunk.blocks), list(trunk.full_attn_ids)
     windowed = [i for i in range(len(all_blocks)) if i not in all_global]
 
-    def one_step(block_ids):
+    def one_step(block_ids, k=0):
         """The whole step with the trunk reduced to ``block_ids`` (None = all blocks)."""
         ids = list(range(len(all_blocks))) if block_ids is None else list(block_ids)
         trunk.blocks = torch.nn.ModuleList([all_blocks[i] for i in ids])
-        trunk.full_attn_ids = [len(ids) - 1]            # the feature map leaves after the last kept block
+        trunk.full_attn_ids = [len(ids) - 1] if block_ids is not None else all_global
+        batch = batches[k & 1]
         t0 = time.perf_counter()
         out = model(batch)
         targets = [model.back_convert(t) for t in batch.find_targets]
@@ -499,14 +510,26 @@ def cpu_baseline(kind="sam3", seconds_budget=45.0):
         trunk.blocks, trunk.full_attn_ids = torch.nn.ModuleList(all_blocks), all_global
         return dt, loss.item()
 
-    # bounded sample: ONE step of the whole model with the trunk cut to (1 windowed + 1 global) block, plus the cost
-    # of one more windowed / global block measured on the block alone (forward, recompute, backward -- the
-    # per-block activation checkpointing of the reference)
+    what = (f"{'full 840M-parameter' if kind == 'sam3' else 'TINY-width (contract test)'} model, B = {B} synthetic images @ "
+            f"{res}^2 (configs[0]), {n_adapted} rank-4 adapters in reference form, fwd + 2x matching + loss + bwd (per-block "
+            f"recompute) + AdamW, fp32, {phys} threads")
+    if timed_steps > 0:
+        t_warm, _ = one_step(None, 0)
+        ts = [one_step(None, 1 + i) for i in range(timed_steps)]
+        t_full = sum(t for t, _ in ts) / len(ts)
+        sample = (f"c1 protocol: 1 warm-up ({t_warm:.1f}s) + {timed_steps} timed steps ({', '.join(f'{t:.1f}s' for t, _ in ts)}); "
+                  f"{what}; loss {ts[-1][1]:.2f}")
+        torch.set_num_threads(threads)
+        return dict(value=round(B / t_full, 5), unit="images/s", cores=phys, kind="port", s_per_step=round(t_full, 2),
+                    batch=B, sample=sample)
+
+    # bounded sample: the whole model with the trunk cut to (1 windowed + 1 global) block, plus the cost of one more
+    # windowed / global block measured on the block alone (forward, recompute, backward -- the reference's checkpointing)
     from torch.utils.checkpoint import checkpoint as _ckpt
     w0, g0 = windowed[0], all_global[0]
     t_11, _ = one_step([w0, g0])
     side = res // SAM3_CONFIG["vit"]["patch_size"]
-    probe_x = torch.randn(1, side, side, SAM3_CONFIG["vit"]["embed_dim"])
+    probe_x = torch.randn(B, side, side, SAM3_CONFIG["vit"]["embed_dim"])
 
     def block_alone(i):
         x = probe_x.clone().requires_grad_(True)
@@ -514,23 +537,26 @@ def cpu_baseline(kind="sam3", seconds_budget=45.0):
         _ckpt(all_blocks[i], x, use_reentrant=False).sum().backward()
         return time.perf_counter() - t0
     Tw, Tg = block_alone(w0), block_alone(g0)
-    R = t_11
     predicted = t_11 + (len(windowed) - 1) * Tw + (len(all_global) - 1) * Tg
-    if predicted <= seconds_budget:
+    if 3 * predicted <= seconds_budget:
+        t_warm, _ = one_step(None, 0)
+        ts = [one_step(None, 1 + i) for i in range(2)]
+        t_full = sum(t for t, _ in ts) / 2
+        sample = (f"c1 protocol: 1 warm-up ({t_warm:.1f}s) + 2 timed steps ({ts[0][0]:.1f}s, {ts[1][0]:.1f}s); {what}; "
+                  f"loss {ts[-1][1]:.2f}")
+    elif predicted <= seconds_budget:
         t_full, loss = one_step(None)
-        sample = (f"whole CPU training step timed once: 1 synthetic image @ {res}^2 (configs[0] has 2), "
-                  f"{'full 840M-parameter' if kind == 'sam3' else 'TINY-width (contract test)'} "
-                  f"model, {n_adapted} rank-4 adapters in reference form, fwd + 2x matching + loss + bwd (per-block "
-                  f"recompute) + AdamW, fp32; loss {loss:.2f}; {t_full:.1f}s of CPU work (predicted {predicted:.1f}s)")
+        sample = (f"ONE whole CPU training step timed, no warm-up (warm-up + 2 timed steps were predicted at {3 * predicted:.0f}s, over "
+                  f"the {seconds_budget:.0f}s budget of a default bench run; `bench.py --cpu-steps 2` runs the c1 protocol in full): "
+                  f"{what}; loss {loss:.2f}; {t_full:.1f}s of CPU work (predicted {predicted:.1f}s)")
     else:
         t_full = predicted
         sample = (f"extrapolated: one CPU training step of the whole model with the trunk cut to 1 windowed + 1 global block "
-                  f"took {t_11:.1f}s for 1 synthetic image @ {res}^2; one more windowed / global block (forward + recompute + "
-                  f"backward, timed alone) costs {Tw:.2f}s / {Tg:.2f}s -> {predicted:.1f}s for the {len(all_blocks)}-block step "
-                  f"(over the {seconds_budget:.0f}s budget, not run whole); "
-                  f"{n_adapted} rank-4 adapters in reference form, fp32, fwd + 2x matching + loss + bwd (recompute) + AdamW")
+                  f"took {t_11:.1f}s; one more windowed / global block (forward + recompute + backward, timed alone) costs "
+                  f"{Tw:.2f}s / {Tg:.2f}s -> {predicted:.1f}s for the {len(all_blocks)}-block step (over the {seconds_budget:.0f}s "
+                  f"budget, not run whole); {what}")
     torch.set_num_threads(threads)
-    return dict(value=round(1.0 / t_full, 5), unit="images/s", cores=phys, kind="port", s_per_step=round(t_full, 2),
+    return dict(value=round(B / t_full, 5), unit="images/s", cores=phys, kind="port", s_per_step=round(t_full, 2), batch=B,
                 sample=sample)
 
 
@@ -579,8 +605,8 @@ class FullStep:
             self.ckpt = V.set_activation_checkpointing(self.model, mode, batch=batch)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.reducer = LoRAGradReducer(self.params, bucket_bytes=8 << 20)
-        from sam3_lora_amd.functional import enable_direct_grad_accumulation
-        enable_direct_grad_accumulation(True)    # the kernels add straight into the reducer's flat buffer
+        from sam3_lora_amd.functional import direct_grad_accumulation
+        self._direct = direct_grad_accumulation      # the kernels add straight into the reducer's flat buffer (scoped to backward)
         self.opt = torch.optim.AdamW(self.params, lr=5e-5, weight_decay=0.01)
         self.matcher, self.wrapper = build_criterion("global" if world > 1 else "local")
         if match_once:
@@ -617,7 +643,8 @@ class FullStep:
         loss = self.wrapper(out, targets)["core_loss"]
         mark("loss")
         self.reducer.zero_grad()
-        loss.backward()
+        with self._direct(True):
+            loss.backward()
         mark("backward")
         self.reducer.finish()
         self.opt.step()
@@ -643,9 +670,31 @@ def rccl_info(world, dev):
     return info
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (one per GPU, RCCL) the way
+    the driver would -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` -- and
+    hand back its exit code.  A bare `--gpus 8` therefore can never run one rank and report `n_gpus: 1`."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch_under_torchrun(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different job size",
+              file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -838,7 +887,7 @@ def main():
             out["trunk_step_no_checkpoint"] = tr2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args.model)
+            out["cpu_baseline"] = cpu_baseline(args.model, timed_steps=args.cpu_steps)
         except Exception as e:
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         out["adapter_path"]["cpu_port"] = adapter_cpu_port(args.rank)

@@ -39,12 +39,16 @@ __device__ __forceinline__ void load16(const float* p, float (&v)[16]) {
     }
 }
 
+// max that keeps a NaN once one was seen: a diverged step must surface in the next call's scale, not be clamped to FMAX
+__device__ __forceinline__ float nanmax(float acc, float a) { return (a != a || a > acc) ? a : acc; }
+
 template <typename XT, int FMT>
 __global__ __launch_bounds__(256) void k_fp8_quantize(const XT* __restrict__ x, unsigned char* __restrict__ out,
                                                       const float* __restrict__ amax_in, float* __restrict__ amax_out,
                                                       float* __restrict__ scale_out, long long n16) {
     constexpr float FMAX = FMT == SAM3_FP8_E4M3 ? 448.f : 57344.f;
-    const float amax = fmaxf(*amax_in, 5.9604645e-8f);
+    const float ain = *amax_in;
+    const float amax = ain != ain ? ain : fmaxf(ain, 5.9604645e-8f);
     const float scale = amax / FMAX, inv = FMAX / amax;
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
     float seen = 0.f;
@@ -57,8 +61,9 @@ __global__ __launch_bounds__(256) void k_fp8_quantize(const XT* __restrict__ x, 
             float c[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                seen = fmaxf(seen, fabsf(v[4 * q + j]));
-                c[j] = fminf(fmaxf(v[4 * q + j] * inv, -FMAX), FMAX);
+                seen = nanmax(seen, fabsf(v[4 * q + j]));
+                const float sv = v[4 * q + j] * inv;
+                c[j] = sv != sv ? sv : fminf(fmaxf(sv, -FMAX), FMAX);       // a NaN stays a NaN (fminf / fmaxf would clamp it away)
             }
             int word = 0;
             if (FMT == SAM3_FP8_E4M3) {
@@ -76,11 +81,11 @@ __global__ __launch_bounds__(256) void k_fp8_quantize(const XT* __restrict__ x, 
     // wave at 8192 waves -- the kernel ran at 1.3 TB/s)
     __shared__ float wmax[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) seen = fmaxf(seen, __shfl_down(seen, o, 64));
+    for (int o = 32; o > 0; o >>= 1) seen = nanmax(seen, __shfl_down(seen, o, 64));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = seen;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        const float m = nanmax(nanmax(wmax[0], wmax[1]), nanmax(wmax[2], wmax[3]));   // NaN's bit pattern outranks every finite amax
         atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(m));
     }
 }

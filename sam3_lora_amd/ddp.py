@@ -49,6 +49,11 @@ class LoRAGradReducer:
         for p in self.params:
             offs.append(n)
             n += (p.numel() + 63) // 64 * 64
+        # one "used this step" flag per parameter rides behind the gradients (summed by the same exchange): torch DDP leaves
+        # the gradient of a GLOBALLY unused parameter None, so that the optimizer skips it (no weight decay, no moment
+        # update) -- see `finish`
+        self._flag0 = n
+        n += (len(self.params) + 63) // 64 * 64
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self._offs = offs
         for p, o in zip(self.params, offs):
@@ -58,6 +63,11 @@ class LoRAGradReducer:
         # buckets: contiguous ranges of the flat buffer, built from the END (last params finish first)
         self.buckets = []          # (start, end, first_param_idx, last_param_idx)
         per = max(1, bucket_bytes // 4)
+        self.skip_unused = True    # leave .grad = None on parameters no rank produced a gradient for (torch DDP's behaviour)
+        self.fired = set()         # indices of the parameters whose gradient arrived in the armed backward
+        self._flags_host = torch.zeros(len(self.params), dtype=torch.float32)
+        if dev.type == "cuda":
+            self._flags_host = self._flags_host.pin_memory()
         hi = len(self.params)
         while hi > 0:
             lo = hi - 1
@@ -95,13 +105,18 @@ class LoRAGradReducer:
             self.flat.zero_()
 
     # ------------------------------------------------------------------ step protocol ----
-    def zero_grad(self):
-        """Zero the flat buffer (keeps every ``param.grad`` a view of it) and arm the hooks."""
+    def zero_grad(self, arm: bool = True):
+        """Zero the flat buffer (keeps every ``param.grad`` a view of it) and arm the hooks.  ``arm=False``: the first of
+        several accumulated micro-batches -- nothing is exchanged until :meth:`arm` is called before the last backward
+        (``model.no_sync()`` of native_trainer.py:985-991)."""
         self.flat.zero_()
         for p, o in zip(self.params, self._offs):
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
                 p.grad = self.flat[o:o + p.numel()].view_as(p)
-        self.arm()
+        self.fired = set()
+        self._armed = False
+        if arm:
+            self.arm()
 
     def arm(self):
         """Call before the backward of the LAST micro-batch (no_sync semantics for earlier ones)."""
@@ -120,6 +135,7 @@ class LoRAGradReducer:
 
     def _make_hook(self, idx: int):
         def hook(param):
+            self.fired.add(idx)        # also during un-armed (accumulating) micro-batches: the parameter is in use
             if not self._armed:
                 return
             o = self._offs[idx]
@@ -152,12 +168,35 @@ class LoRAGradReducer:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
+        exchange = self.world_size > 1 or self.run_alone
+        locally_unused = [i for i in range(len(self.params)) if i not in self.fired] if self.skip_unused else []
+        flags = self.flat[self._flag0:self._flag0 + len(self.params)]
+        if exchange and self.skip_unused:
+            # the flags are only complete now, so they travel as one small trailing message
+            self._flags_host.zero_()
+            if self.fired:
+                self._flags_host[sorted(self.fired)] = 1.0
+            flags.copy_(self._flags_host, non_blocking=True)
+            if self.overlap:
+                self._side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._side):
+                    self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in self._works:
             w.wait()
         if self.overlap:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         if self.average and self.world_size > 1:
             self.flat.mul_(1.0 / self.world_size)
+        if locally_unused:
+            # a parameter unused on EVERY rank keeps .grad = None (the optimizer then skips it, as after the reference's
+            # zero_grad()); one unused only here was reduced as zeros + the other ranks' gradients.  Only a rank that has
+            # locally unused parameters needs to look (a globally unused one is locally unused everywhere).
+            globally = locally_unused if not exchange else \
+                [i for i, v in zip(locally_unused, flags[locally_unused].tolist()) if v == 0.0]
+            for i in globally:
+                self.params[i].grad = None
         self._works = []
         self._armed = False
 

@@ -24,7 +24,7 @@ import torch
 
 from . import _ffi
 
-__all__ = ["enable_fp8_frozen", "fp8_enabled", "fp8_linear", "fp8_dx", "Fp8Quantizer", "Fp8Weight", "state_for"]
+__all__ = ["enable_fp8_frozen", "fp8_enabled", "fp8_linear", "fp8_dx", "Fp8Quantizer", "Fp8Weight", "state_for", "eligible", "would_use"]
 
 _STATE = {"on": False}
 _WEIGHTS = {}          # id(weight) -> (weakref to the weight, Fp8Weight); tensors compare element-wise, so not a dict key
@@ -87,6 +87,12 @@ def eligible(x2: torch.Tensor, w: torch.Tensor) -> bool:
     return (_STATE["on"] and x2.is_cuda and x2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and not w.requires_grad
             and x2.dim() == 2 and x2.shape[0] > 0 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 and x2.is_contiguous()
             and not torch.is_autocast_enabled("cuda"))
+
+
+def would_use(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """:func:`eligible` for an input of any rank before it is flattened to rows (the flattening makes it contiguous)."""
+    return (_STATE["on"] and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and not w.requires_grad
+            and x.numel() > 0 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 and not torch.is_autocast_enabled("cuda"))
 
 
 def state_for(w: torch.Tensor) -> Fp8Weight:

@@ -24,7 +24,7 @@ from . import _ffi
 from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
 __all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE",
-           "enable_direct_grad_accumulation", "pack_operands_many", "repack_adapters"]
+           "enable_direct_grad_accumulation", "direct_grad_accumulation", "pack_operands_many", "repack_adapters"]
 
 _ws_lock = threading.Lock()
 _workspaces = {}  # (device index, stream handle) -> uint8 tensor
@@ -281,7 +281,9 @@ def frozen_linear(x: torch.Tensor, lin: torch.nn.Linear, cache: TransposedCopy) 
     frozen = x.is_cuda and not w.requires_grad and (lin.bias is None or not lin.bias.requires_grad) and x.dtype == w.dtype \
         and not torch.is_autocast_enabled("cuda")
     if frozen and x.requires_grad and torch.is_grad_enabled():
-        return _FrozenLinearFn.apply(x, w, lin.bias, None if fp8.fp8_enabled() else cache.get(w))
+        # the transposed copy serves the bf16 / fp32 TN-form backward; the fp8 route keeps its own e4m3 transpose, so skip it
+        # only for the layers that actually take that route
+        return _FrozenLinearFn.apply(x, w, lin.bias, None if fp8.would_use(x, w) else cache.get(w))
     if frozen and fp8.fp8_enabled():        # no gradient needed (first block, eval): still the fp8 GEMM
         x2 = x.reshape(-1, x.shape[-1])
         return _frozen_fwd(x2 if x2.is_contiguous() else x2.contiguous(), w, lin.bias).view(*x.shape[:-1], w.shape[0])
@@ -400,6 +402,33 @@ def enable_direct_grad_accumulation(on: bool = True) -> None:
     _DIRECT["on"] = bool(on)
 
 
+class direct_grad_accumulation:
+    """Scoped form of :func:`enable_direct_grad_accumulation`: ``with direct_grad_accumulation(): loss.backward()``.
+    The switch changes what autograd is handed for A / B (a stride-0 zero while ``param.grad`` itself is updated inside
+    the kernel), which is only right for ``backward()`` followed by an optimizer step -- so the trainer turns it on
+    around exactly that call and restores the previous state afterwards; ``torch.autograd.grad``, tensor hooks and
+    gradient-clipping hooks elsewhere in the process keep seeing real gradients.  ``touched`` collects the ids of the
+    parameters whose ``.grad`` the kernels wrote inside the scope."""
+
+    def __init__(self, on: bool = True):
+        self.on, self.touched = bool(on), set()
+
+    def __enter__(self):
+        self._prev, self._prev_touched = _DIRECT["on"], _DIRECT.get("touched")
+        _DIRECT["on"], _DIRECT["touched"] = self.on, self.touched
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT["on"], _DIRECT["touched"] = self._prev, self._prev_touched
+        return False
+
+
+def _note_direct(*params) -> None:
+    t = _DIRECT.get("touched")
+    if t is not None:
+        t.update(id(p) for p in params)
+
+
 def _zero_grad_like(p: torch.Tensor) -> torch.Tensor:
     key = (p.device, p.dtype)
     z = _ZEROS.get(key)
@@ -481,6 +510,7 @@ class _LoRALinearFn(torch.autograd.Function):
         direct = _direct_targets(A, B) if (need_w and ctx.pad is None and gy2.shape[0] > 0 and _is_master(A) and _is_master(B)
                                            and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]) else None
         if direct is not None:
+            _note_direct(A, B)
             lora_bwd_(gy2, x2, tT, Am, Bm, gx2, direct[0], direct[1], ctx.scaling, ctx.layout, accumulate=True,
                       drop_p=ctx.drop_p, seed=ctx.seed, packed=ctx.packed)
             gx = gx2.view(ctx.x_shape).to(ctx.x_dtype) if need_x else None
@@ -554,6 +584,7 @@ class _LoRAMlpFn(torch.autograd.Function):
         direct = d1 is not None and d2 is not None
         if direct:          # accumulate straight into param.grad (see enable_direct_grad_accumulation)
             (gA1, gB1), (gA2, gB2) = d1, d2
+            _note_direct(A1, B1, A2, B2)
         else:
             gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
         with torch.autocast("cuda", enabled=False):

@@ -13,7 +13,6 @@ focal=True)`` (``train_sam3_lora_native.py:743-745``).
 """
 from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Tuple
-from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch

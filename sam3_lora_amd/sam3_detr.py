@@ -207,9 +207,10 @@ def gen_sineembed_for_position(pos: torch.Tensor, num_feats: int = 256) -> torch
     half = num_feats // 2
     key = (half, str(pos.device))
     freq = _SINE_FREQ.get(key)
-    if freq is None:
-        k = torch.arange(half, dtype=torch.float32, device=pos.device)
-        freq = _SINE_FREQ[key] = 10000 ** (2 * torch.div(k, 2, rounding_mode="floor") / half)
+    if freq is None or freq.is_inference():
+        with torch.inference_mode(False):       # a table first built under inference_mode could not be saved for backward later
+            k = torch.arange(half, dtype=torch.float32, device=pos.device)
+            freq = _SINE_FREQ[key] = 10000 ** (2 * torch.div(k, 2, rounding_mode="floor") / half)
     n = pos.size(-1)
     if n == 4:
         ordered = torch.stack((pos[:, :, 1], pos[:, :, 0], pos[:, :, 2], pos[:, :, 3]), dim=2)
@@ -476,9 +477,10 @@ class TransformerDecoder(nn.Module):
 
     def _grid(self, H: int, W: int, device):
         key = (H, W, str(device))
-        if key not in self._coords:
-            self._coords[key] = (torch.arange(0, H, device=device, dtype=torch.float32) / H,
-                                 torch.arange(0, W, device=device, dtype=torch.float32) / W)
+        if key not in self._coords or self._coords[key][0].is_inference():
+            with torch.inference_mode(False):   # see gen_sineembed_for_position
+                self._coords[key] = (torch.arange(0, H, device=device, dtype=torch.float32) / H,
+                                     torch.arange(0, W, device=device, dtype=torch.float32) / W)
         return self._coords[key]
 
     def _get_rpb_matrix(self, reference_boxes: torch.Tensor, feat_size, presence_row: bool = False) -> torch.Tensor:

@@ -157,6 +157,9 @@ def match_all_steps(matcher, stage_outputs: Sequence, stage_targets: Sequence[Di
     otherwise match one by one (``Sam3LossWrapper.launch_matching``): one batched cost, one device->host copy.  A handle
     left by the model's forward (``Sam3Image.set_prefetch_matcher``) is collected instead of starting over."""
     whole = hasattr(matcher, "launch_matching")
+    # every step of every stage, whatever view the SAM3Output currently iterates in (the reference switches it to
+    # ALL_STEPS_PER_STAGE before matching, :914-918; the loss wrapper then reads every step's "indices")
+    stage_outputs = getattr(stage_outputs, "output", stage_outputs)
     for stage, targets in zip(stage_outputs, stage_targets):
         for outputs in _steps(stage):
             pending = outputs.pop("_match_handle", None) if isinstance(outputs, dict) else None
@@ -226,12 +229,21 @@ class SAM3TrainerNative:
         trainable = [p for p in self.model.parameters() if p.requires_grad]
         self.optimizer = AdamW(trainable, lr=float(self.config["training"]["learning_rate"]),
                                weight_decay=self.config["training"]["weight_decay"])
+        self.trainable = trainable
         self.reducer = LoRAGradReducer(trainable) if self.world_size > 1 else None
         # the adapters' backward adds straight into param.grad (the reducer's flat buffer under data parallelism)
-        # instead of handing fresh gradient tensors to autograd: engine.direct_grad (default on)
-        if (self.config.get("engine") or {}).get("direct_grad", True) and self.device.type == "cuda":
-            from .functional import enable_direct_grad_accumulation
-            enable_direct_grad_accumulation(True)
+        # instead of handing fresh gradient tensors to autograd: engine.direct_grad (default on).  The switch is scoped to
+        # this trainer's own loss.backward() calls (functional.direct_grad_accumulation) -- nothing else in the process
+        # sees zero placeholder gradients.
+        self.direct_grad = bool(engine.get("direct_grad", True)) and self.device.type == "cuda"
+        # engine.grad_accumulation_steps (default 1 = the reference CLI, which ignores training.gradient_accumulation_steps,
+        # SURVEY F6): micro-batches whose gradients are summed before one exchange + one optimizer step
+        # (sam3_lora/train/native_trainer.py:985-991: model.no_sync() for all but the last micro-batch)
+        self.accum_steps = max(1, int(engine.get("grad_accumulation_steps", 1)))
+        self._fired = set()
+        if self.reducer is None:        # which parameters received a gradient this step (see _drop_unused_grads)
+            self._fired_hooks = [p.register_post_accumulate_grad_hook(lambda q, i=i: self._fired.add(i))
+                                 for i, p in enumerate(trainable)]
         self.matcher, self.loss_wrapper = build_criterion("global" if self.world_size > 1 else "local")
         # engine.match_once: the loop's matching starts inside the forward, right after the decoder, and its host part
         # overlaps with the mask head's device work (Sam3Image.set_prefetch_matcher); same indices either way
@@ -252,20 +264,62 @@ class SAM3TrainerNative:
         match_all_steps(self.loss_wrapper, outputs, targets)
         return self.loss_wrapper(outputs, targets)[CORE_LOSS_KEY]
 
-    def train_step(self, batch) -> float:
-        loss = self._loss(batch)
-        if self.reducer is not None:
-            self.reducer.zero_grad()
-            loss.backward()
-            self.reducer.finish()
+    def _backward(self, loss: torch.Tensor) -> None:
+        if self.direct_grad:
+            from .functional import direct_grad_accumulation
+            with direct_grad_accumulation(True):
+                loss.backward()
         else:
-            self.optimizer.zero_grad(set_to_none=False)      # keep the .grad tensors: the kernels accumulate into them
             loss.backward()
+
+    def _zero_grad(self) -> None:
+        """``optimizer.zero_grad()`` of :937 with the tensors kept where they exist (the kernels accumulate into them); a
+        gradient that is None stays None."""
+        self._fired = set()
+        self.optimizer.zero_grad(set_to_none=False)
+        if self.direct_grad:
+            for p in self.trainable:
+                if p.grad is None:                  # first step, or dropped as unused last step
+                    p.grad = torch.zeros_like(p)
+
+    def _drop_unused_grads(self) -> None:
+        """The reference's ``zero_grad()`` sets gradients to None, so an adapter that took no part in a step (e.g. the
+        geometry encoder's when a batch has no box prompts) is skipped by AdamW -- no weight decay, no moment update.
+        Here the tensors are kept and zeroed instead; to keep the same trajectory, a parameter no gradient arrived for
+        gets ``.grad = None`` before the optimizer step."""
+        for i, p in enumerate(self.trainable):
+            if i not in self._fired:
+                p.grad = None
+
+    def train_step(self, batch) -> float:
+        """One optimizer step; ``batch`` is one batch or (``engine.grad_accumulation_steps`` > 1) a list of micro-batches."""
+        micro = list(batch) if isinstance(batch, (list, tuple)) else [batch]
+        total = 0.0
+        for k, mb in enumerate(micro):
+            last = k == len(micro) - 1
+            loss = self._loss(mb)
+            if len(micro) > 1:
+                loss = loss / len(micro)
+            if self.reducer is not None:
+                if k == 0:
+                    self.reducer.zero_grad(arm=last)
+                elif last:
+                    self.reducer.arm()              # earlier micro-batches: no exchange (no_sync)
+                self._backward(loss)
+            else:
+                if k == 0:
+                    self._zero_grad()
+                self._backward(loss)
+            total += float(loss.item())
+        if self.reducer is not None:
+            self.reducer.finish()                   # leaves .grad = None on globally unused parameters
+        else:
+            self._drop_unused_grads()
         self.optimizer.step()
         if self.device.type == "cuda":      # A / B just changed: refresh every adapter's operand images in one batch
             from .functional import repack_adapters
             repack_adapters(self.model)
-        return loss.item()
+        return total
 
     @torch.no_grad()
     def validate(self, loader: Iterable) -> float:
@@ -305,7 +359,15 @@ class SAM3TrainerNative:
         for epoch in range(epochs):
             if hasattr(train_loader, "set_epoch"):
                 train_loader.set_epoch(epoch)
-            losses = [self.train_step(b) for b in train_loader]
+            if self.accum_steps > 1:
+                it, losses = iter(train_loader), []
+                while True:
+                    group = [b for _, b in zip(range(self.accum_steps), it)]
+                    if not group:
+                        break
+                    losses.append(self.train_step(group))
+            else:
+                losses = [self.train_step(b) for b in train_loader]
             avg_train = sum(losses) / len(losses) if losses else 0.0
             record = {"epoch": epoch + 1, "train_loss": avg_train}
             self._save(out_dir / "last_lora_weights.pt")

@@ -59,3 +59,25 @@ def test_two_ranks_launched_like_the_driver_complete():
     assert r["exchange_overlap"]["world"] == 2 and r["exchange_overlap"]["step_ms_exposed"] > 0
     assert r["distributed"]["rank_device_ids"] == [0, 0] and r["distributed"]["backend"] == "gloo"
     assert sum(1 for l in p.stdout.splitlines() if l.startswith("{")) == 1      # rank 0 only
+
+
+def test_gpus_flag_disagreeing_with_world_size_is_refused():
+    """a line must never describe a different job size than the one launched."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 2 and "WORLD_SIZE=1" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bare_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher re-executes under torch.distributed.run (two ranks on the one GPU of the
+    test box over gloo) and the line says n_gpus 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "2",
+           "--batch", "1", "--kernel-iters", "2", "--model", "tiny", "--no-cpu-baseline", "--no-fp8", "--no-overlap"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    r = _last_json(p.stdout)
+    assert r["n_gpus"] == 2 and r["distributed"]["rank_device_ids"] == [0, 0] and r["config"]["global_batch"] == 2

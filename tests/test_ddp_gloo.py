@@ -38,8 +38,7 @@ def _worker(rank, world, port, q):
         for p in params:
             assert p.grad.data_ptr() >= red.flat.data_ptr()
         # two "micro-batches": only the second is armed (no_sync semantics for the first)
-        red.zero_grad()
-        red._armed = False
+        red.zero_grad(arm=False)
         x = torch.full((8, 64), float(rank + 1))
         def loss_fn():
             hcur = x @ params[0] @ params[1] @ params[2] @ params[3]
@@ -56,7 +55,18 @@ def _worker(rank, world, port, q):
         want = sum(gathered) / world
         got = torch.cat([p.grad.flatten() for p in params])
         ok = torch.allclose(got, want, rtol=1e-5, atol=1e-6)
-        ok = ok and bool((unused.grad == 0).all())           # zero-filled, reduced, not skipped
+        # a parameter NO rank produced a gradient for keeps .grad = None (torch DDP: the optimizer then skips it); its slot
+        # still travelled as zeros, and the next zero_grad() makes .grad a view of the flat buffer again
+        ok = ok and unused.grad is None
+        # a parameter used on rank 0 only is NOT dropped anywhere: zeros + rank 0's gradient, averaged
+        red.zero_grad()
+        if rank == 0:
+            (params[4].sum() * 4.0).backward()
+        red.finish()
+        ok = ok and params[4].grad is not None and bool(torch.allclose(params[4].grad, torch.full_like(params[4], 4.0 / world)))
+        ok = ok and params[0].grad is None and unused.grad is None
+        red.zero_grad()
+        ok = ok and unused.grad is not None and unused.grad.data_ptr() >= red.flat.data_ptr() and params[0].grad is not None
         # every rank holds identical reduced grads
         g_all = [torch.zeros_like(got) for _ in range(world)]
         dist.all_gather(g_all, got)

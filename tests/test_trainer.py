@@ -132,6 +132,56 @@ def test_end_to_end_with_validation(tmp_path):
 
 
 @pytest.mark.gpu
+def test_accumulated_micro_batches_equal_one_big_step_and_unused_adapters_are_skipped(tmp_path):
+    """engine.grad_accumulation_steps (native_trainer.py:985-991 no_sync semantics): two micro-batches, one optimizer step ==
+    the gradient of their mean loss.  The direct accumulation into .grad is scoped to the trainer's backward:
+    outside it torch.autograd.grad returns real gradients.  An adapter that takes no part in a step keeps .grad = None and
+    is not touched by AdamW (the reference's zero_grad() semantics)."""
+    sys.path.insert(0, HERE)
+    import toy_sam3
+    import lora_layers as L
+    from sam3_lora_amd import functional as Fn
+    path, cfg = _write(tmp_path, engine={"grad_accumulation_steps": 2})
+    torch.manual_seed(0)
+    tr = T.SAM3TrainerNative(path, model_builder=toy_sam3.model_builder, data_builder=toy_sam3.data_builder)
+    assert tr.accum_steps == 2 and tr.direct_grad and not Fn._DIRECT["on"]
+    batches = list(toy_sam3.data_builder(cfg, "train"))[:2]
+    with torch.no_grad():
+        for m in tr.model.modules():
+            if isinstance(m, L.LoRALayer):
+                m.lora_B.normal_(0, 0.05)
+    Fn.repack_adapters(tr.model)
+    params = tr.trainable
+    # reference gradient: mean of the two micro-batch losses through plain autograd (the direct path is off out here)
+    loss = (tr._loss(batches[0]) + tr._loss(batches[1])) / 2
+    want = torch.autograd.grad(loss, params, allow_unused=True)
+    assert all(g is not None and float(g.abs().max()) > 0 for g in want)
+    before = [p.detach().clone() for p in params]
+    # an adapter outside the graph: a spare LoRALinear registered with the optimizer but never called
+    spare = L.LoRALinear(torch.nn.Linear(16, 16), rank=4, alpha=8).to(tr.device)
+    extra = [spare.lora.lora_A, spare.lora.lora_B]
+    with torch.no_grad():
+        spare.lora.lora_B.fill_(0.5)
+    tr.trainable = params + extra
+    tr.optimizer.add_param_group({"params": extra})
+    tr._fired_hooks += [p.register_post_accumulate_grad_hook(lambda q, i=len(params) + k: tr._fired.add(i)) for k, p in enumerate(extra)]
+    seen = {}
+    orig_step = tr.optimizer.step
+    def spy(*a, **k):
+        seen["grads"] = [None if p.grad is None else p.grad.detach().clone() for p in tr.trainable]
+        return orig_step(*a, **k)
+    tr.optimizer.step = spy
+    tr.train_step(batches)
+    got = seen["grads"]
+    for g, w in zip(got[:len(params)], want):
+        assert g is not None and float((g - w).abs().max()) <= 2e-3 * float(w.abs().max()) + 1e-7
+    assert got[-1] is None and got[-2] is None                               # unused: skipped, not zero
+    assert torch.equal(spare.lora.lora_B.detach(), torch.full_like(spare.lora.lora_B, 0.5))   # no weight decay applied
+    assert any(not torch.equal(b, p.detach()) for b, p in zip(before, params))
+    assert not Fn._DIRECT["on"]
+
+
+@pytest.mark.gpu
 def test_no_validation_split_copies_last_to_best(tmp_path):
     sys.path.insert(0, HERE)
     import toy_sam3
