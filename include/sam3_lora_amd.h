@@ -34,8 +34,11 @@
  *     1 <= r <= SAM3_LORA_MAX_RANK; ranks above 32 run as consecutive groups of 32 rank indices (one more pass over
  *     the activations per group -- the reference has no rank limit, configs/full_lora_config.yaml:12).
  *   - activation dtype (x, y, gy, gx):
- *         SAM3_LORA_BF16  bf16 operands on the bf16 MFMAs, fp32 accumulation; the rank-r intermediates t / gt are
- *                         rounded to bf16 once;
+ *         SAM3_LORA_BF16  bf16 data on the bf16 MFMAs, fp32 accumulation.  r <= 16: the operand images of A / B and the
+ *                         rank-r intermediates t / gt are carried as hi + lo bf16 pairs (16 mantissa bits), so the branch
+ *                         and its gradients are fp32 arithmetic on the caller's bf16 tensors -- the only bf16 roundings are
+ *                         those of x / gy (the caller's) and of y / gx on the way out.  16 < r: A, B, t, gt rounded to
+ *                         bf16 once each (also for r <= 16 with SAM3_LORA_SINGLE_ROUND=1 in the environment);
  *         SAM3_LORA_F32   exact fp32: fp32 operands on v_mfma_f32_16x16x4_f32, fp32 intermediates -- the arithmetic
  *                         of the reference's un-autocast training (train_sam3_lora_native.py).
  *     gA/gB are accumulated and returned in fp32 either way.
@@ -50,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SAM3_LORA_ABI_VERSION 2
+#define SAM3_LORA_ABI_VERSION 3
 #define SAM3_LORA_MAX_RANK 1024
 
 #define SAM3_LORA_LAYOUT_ROOT 0
@@ -173,29 +176,6 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
                     void* stream);
 
 /*
- * "Augmented frozen GEMM" mode (bf16, no dropout): the rank-r intermediates come out of the frozen GEMMs the
- * caller runs anyway, so the row-reduction kernel disappears from both directions.
- * The caller stores the frozen weight inside  Waug[out + r_pad, in + r_pad]  (bf16, row pitch ldw, r_pad = 16
- * for r <= 16 else 32):   Waug[:out, :in] = W,   Waug[out:, :in] = A_c^T,   Waug[:out, in:] = B_c^T,  and computes
- *     forward   [ W x + b | t  ] = x  @ Waug[:, :in]^T  (+ [b | 0])        t  = x  A_c      [M, r_pad]
- *     backward  [ gy W    | gt ] = gy @ Waug[:out, :]                       gt = gy B_c^T    [M, r_pad] (unscaled)
- * sam3_lora_aug_scatter refreshes the A/B slots from the fp32 masters (call it whenever A or B changed).
- * sam3_lora_fwd_fused:  y_inout += scaling * t @ B_c ; emits tT for the backward.      (replaces sam3_lora_fwd)
- * sam3_lora_bwd_fused:  gB += scaling * t^T gy ; gA += scaling * x^T gt ; gx_inout += scaling * gt @ A_c^T.
- * t / gt are the [M, r_pad] column slices of the GEMM outputs (row pitch ldt / ldgt in elements, 8-byte aligned).
- */
-int sam3_lora_aug_scatter(const void* A, const void* B, void* Waug, int64_t ldw, int in_features, int out_features,
-                          int rank, int layout, void* stream);
-size_t sam3_lora_fused_workspace_bytes(int64_t M, int in_features, int out_features, int rank);
-int sam3_lora_fwd_fused(const void* t, int64_t ldt, const void* B, void* y_inout, void* tT_out, int64_t M,
-                        int in_features, int out_features, int rank, int64_t ldy, int layout, float scaling, int dtype,
-                        void* workspace, size_t workspace_bytes, void* stream);
-int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, const void* gt, int64_t ldgt, const void* A,
-                        void* gx_inout, float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features,
-                        int rank, int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, int dtype,
-                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-
-/*
  * Profiling aid, not part of the training path: restrict which internal stages the NEXT calls of
  * sam3_lora_fwd / sam3_lora_bwd launch (process-wide; returns the previous mask; default all).
  * bench.py uses it to time one kernel at a time with HIP events on the caller's stream.  With a
@@ -206,14 +186,15 @@ int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, con
 #define SAM3_LORA_STAGE_T2 4u       /* k_t2     : y += s.t.B_c (fwd) / gx += s.gt.A_c^T (bwd)   */
 #define SAM3_LORA_STAGE_T3_GB 8u    /* k_t3     : gB partials = t^T.gy (+ gt partials, r <= 16) */
 #define SAM3_LORA_STAGE_T3_GA 16u   /* k_t3     : gA partials = gt^T.x                          */
-#define SAM3_LORA_STAGE_REDUCE 32u  /* k_reduce : fixed-order sum of the partials into gA/gB    */
+#define SAM3_LORA_STAGE_REDUCE 32u  /* fixed-order sum of the partials into gA/gB: rides on the backward's k_t2 launch (bf16, gx wanted), k_reduce otherwise */
 #define SAM3_LORA_STAGE_GT_REDUCE 64u /* k_gt_reduce : chunk sum of the gt partials k_t3 emitted (r <= 16)  */
 #define SAM3_LORA_STAGE_ALL 0xffffffffu
 unsigned sam3_lora_debug_set_stages(unsigned mask);
 
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
- * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS) are read from the environment once, at the first launch; this
- * re-reads them (tests that flip a knob between calls). */
+ * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE) are read from the
+ * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
+ * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);
 
 /*

@@ -18,7 +18,7 @@ LAYOUT_ROOT = 0
 LAYOUT_PACKAGE = 1
 DT_BF16 = 0
 DT_F32 = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_RANK = 1024
 
 EXPORTS = (
@@ -26,7 +26,6 @@ EXPORTS = (
     "sam3_lora_fwd_workspace_bytes", "sam3_lora_bwd_workspace_bytes",
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages", "sam3_lora_debug_reload_knobs",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
-    "sam3_lora_aug_scatter", "sam3_lora_fused_workspace_bytes", "sam3_lora_fwd_fused", "sam3_lora_bwd_fused",
     "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
 )
 ACT_NONE, ACT_GELU = 0, 1
@@ -95,17 +94,6 @@ def _declare(lib):
     lib.sam3_lora_prof_start.argtypes = [ctypes.c_uint, c_int]
     lib.sam3_lora_prof_stop.restype = c_int
     lib.sam3_lora_prof_stop.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
-    lib.sam3_lora_aug_scatter.restype = c_int
-    lib.sam3_lora_aug_scatter.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]
-    lib.sam3_lora_fused_workspace_bytes.restype = c_size_t
-    lib.sam3_lora_fused_workspace_bytes.argtypes = [c_int64, c_int, c_int, c_int]
-    lib.sam3_lora_fwd_fused.restype = c_int
-    lib.sam3_lora_fwd_fused.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                        c_int64, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]
-    lib.sam3_lora_bwd_fused.restype = c_int
-    lib.sam3_lora_bwd_fused.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_float,
-                                        c_int, c_int, c_void_p, c_size_t, c_void_p]
     for f in (lib.sam3_vit_qkv_rope_fwd, lib.sam3_vit_qkv_rope_bwd):
         f.restype = c_int
     lib.sam3_vit_qkv_rope_fwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_int, c_void_p]

@@ -15,6 +15,14 @@
 //
 // Read-once activation streams are loaded non-temporal; the read half of T2's in-place update is not.
 //
+// HL ("hi + lo", bf16 activations, r <= 16): every bf16 operand that is NOT caller data -- the images of A and B, and the
+// rank-r intermediates t / gt -- is carried as a PAIR of bf16 values v = hi + lo (hi = bf16(v), lo = bf16(v - hi): 16
+// mantissa bits), laid out exactly like a rank-32 operand (rank indices 16..31 = the lo parts).  The contractions then run
+// hi.hi + hi.lo + lo.hi on the same MFMAs -- free on kernels that sit at < 1 % MFMA utilisation -- and the branch
+// s.(x A) B and its four gradient products are fp32 arithmetic on the caller's bf16 data: the only bf16 roundings left
+// are the ones of the caller's own tensors (x, gy in; y, gx out).  SAM3_LORA_SINGLE_ROUND=1 restores the single-rounded
+// operands (one bf16 rounding of A, B, t, gt each).
+//
 // MFMA operand roles are chosen so that no result ever needs a cross-lane shuffle:
 //   * T1 computes t^T (A-operand = LoRA weight, B-operand = activation rows): the C/D layout
 //     (lane&15 = activation row, (lane>>4)*4+reg = rank index) is exactly the B-operand layout
@@ -142,6 +150,8 @@ struct PackJob {
     long long si, sj;
     int ldd;              // row pitch of dst in elements (0 => J); > J when packing into a slice of a wider buffer
     int f32;
+    int hl;               // bf16 hi + lo image: 1 = rows 16..31 hold the lo parts of rows 0..15 (I == 32), 2 = the same for
+                          // columns (J == 32); Iv / Jv then bound the index inside one half
 };
 
 constexpr int PACK_JOBS_MAX = 64;    // 64 x 56 B of kernel arguments per launch
@@ -154,14 +164,16 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)jb.I * jb.J) return;
     const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
-    const float v = (i < jb.Iv && j < jb.Jv) ? jb.src[i * jb.si + j * jb.sj] : 0.f;
+    const int is = jb.hl == 1 ? (i & 15) : i, js = jb.hl == 2 ? (j & 15) : j;       // source index (both halves read the same master)
+    const bool lo = (jb.hl == 1 && i >= 16) || (jb.hl == 2 && j >= 16);
+    float v = (is < jb.Iv && js < jb.Jv) ? jb.src[is * jb.si + js * jb.sj] : 0.f;
     const long long o = (long long)i * (jb.ldd ? jb.ldd : jb.J) + j;
     if (jb.f32) {
         reinterpret_cast<float*>(jb.dst)[o] = v;
         return;
     }
-    bf16x2 t = {(__bf16)v, (__bf16)0.f};
-    reinterpret_cast<bf16_t*>(jb.dst)[o] = (bf16_t)(__builtin_bit_cast(unsigned, t) & 0xffffu);
+    if (lo) v -= bf_lo(pack2(v, 0.f));          // the residual of the hi half's rounding
+    reinterpret_cast<bf16_t*>(jb.dst)[o] = (bf16_t)(pack2(v, 0.f) & 0xffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -216,15 +228,40 @@ __device__ __forceinline__ void wave_sync() {   // LDS ops of one wave execute i
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One lane's 4 consecutive rank entries of row m (rank tile rt) -> the row-major image T[Mp][RP] and the fragment-major
+// image TTf (block (m/32, rt) = 64 lanes x 8 elements: exactly the A-operand k_t3 needs, 1 KB per load).
+template <int RT>
+__device__ __forceinline__ void store_t4(bf16_t* __restrict__ T, bf16_t* __restrict__ TTf, long long m, int rt, int r0,
+                                         unsigned p0, unsigned p1) {
+    constexpr int RP = RT * 16;
+    *reinterpret_cast<uint2*>(T + m * RP + rt * 16 + r0) = make_uint2(p0, p1);
+    const long long blk = m >> 5;
+    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
+    bf16_t* tb = TTf + (((blk * RT + rt) * 4 + gq) * 16 + r0) * 8 + jq;   // [blk][rt][gq][n' = r0 + j][jq]
+    tb[0] = (bf16_t)(p0 & 0xffffu);
+    tb[8] = (bf16_t)(p0 >> 16);
+    tb[16] = (bf16_t)(p1 & 0xffffu);
+    tb[24] = (bf16_t)(p1 >> 16);
+}
+// HL: the fp32 values v -> hi = bf16(v) as rank tile 0, lo = bf16(v - hi) as rank tile 1 of a rank-32 image
+__device__ __forceinline__ void store_t4_hl(bf16_t* __restrict__ T, bf16_t* __restrict__ TTf, long long m, int r0, f32x4 v) {
+    const unsigned h0 = pack2(v[0], v[1]), h1 = pack2(v[2], v[3]);
+    store_t4<2>(T, TTf, m, 0, r0, h0, h1);
+    store_t4<2>(T, TTf, m, 1, r0, pack2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), pack2(v[2] - bf_lo(h1), v[3] - bf_hi(h1)));
+}
+
 // PART (small M, r <= 16): blockIdx.y selects a range of K chunks and the workgroup writes its fp32 partial to
 // P[split][row][16]; k_gt_reduce then adds the splits in fixed order and emits T / TTf.  With M/64 workgroups alone a
 // small batch leaves most CUs idle (M = 5184: 81 workgroups on 256 CUs).
-template <typename XT, int RT, int BK, bool PART = false>
+// HL (RT == 2): W1 rows 16..31 are the lo parts of A_c^T / B_c; the two accumulators are added (t = x.hi + x.lo in fp32)
+// and t leaves as a hi + lo pair.
+template <typename XT, int RT, int BK, bool PART = false, bool HL = false>
 __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ W1, bf16_t* __restrict__ T,
                                             bf16_t* __restrict__ TTf, long long M, long long Mp, int K,
                                             DropKey dk, float* __restrict__ P = nullptr, int kc_per = 0) {
-    static_assert(!PART || RT == 1, "split-K partials are laid out for one rank tile");
+    static_assert(!PART || RT == 1 || HL, "split-K partials are laid out for one rank tile");
+    static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
     constexpr int RP = RT * 16, BM = 64, CPR = BK / 8;          // CPR 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;                               // tile rows covered per pass of 256 threads
     constexpr int XP = BM / RPP, WP = RP / RPP;                  // passes for the x tile / the W1 tile
@@ -298,22 +335,18 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
     }
     // lane (n, g) holds t[row = m0 + wave*16 + n][rank idx = rt*16 + g*4 + j]
     const long long m = m0 + wave * 16 + n;
+    if (HL) acc[0] += acc[RT - 1];          // x.A_hi + x.A_lo
     if (PART) {
         *reinterpret_cast<f32x4*>(P + ((long long)blockIdx.y * Mp + m) * 16 + g * 4) = acc[0];
         return;
     }
-    const long long blk = m >> 5;
-    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const unsigned p0 = pack2(acc[rt][0], acc[rt][1]), p1 = pack2(acc[rt][2], acc[rt][3]);
-        *reinterpret_cast<uint2*>(T + m * RP + rt * 16 + g * 4) = make_uint2(p0, p1);
-        bf16_t* tb = TTf + (((blk * RT + rt) * 4 + gq) * 16 + g * 4) * 8 + jq;   // [blk][rt][gq][n'=g*4+j][jq]
-        tb[0] = (bf16_t)(p0 & 0xffffu);
-        tb[8] = (bf16_t)(p0 >> 16);
-        tb[16] = (bf16_t)(p1 & 0xffffu);
-        tb[24] = (bf16_t)(p1 >> 16);
+    if (HL) {
+        store_t4_hl(T, TTf, m, g * 4, acc[0]);
+        return;
     }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        store_t4<RT>(T, TTf, m, rt, g * 4, pack2(acc[rt][0], acc[rt][1]), pack2(acc[rt][2], acc[rt][3]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -365,6 +398,62 @@ __device__ __forceinline__ uint4 act8(uint4 y, uint4 h, int act) {
         for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(hv[i]);
     }
     return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
+// ------------------------------------------------------------------------------------------
+// second-stage, fixed-order reduction of the T3 partials into the fp32 gradient tensors
+//   dst[r*sr + n*sn] (+)= scale * sum_rs part[rs][r][n]
+// block = 64 consecutive (r, n) elements; wave w sums partials w, w+4, w+8, ... (independent loads in
+// flight), then the four wave sums are combined in the fixed order 0,1,2,3 -> bit-reproducible.
+// The bf16 backward does not launch it on its own: the blocks RIDE on the last kernel of the call, k_t2 over gx (the
+// partials are complete by then -- stream order), as its leading blockIdx.y rows: 16 MB of partial reads hidden inside
+// a 35-120 us streaming kernel instead of a dependent 7-9 us launch at the end of every backward call.
+// ------------------------------------------------------------------------------------------
+struct ReduceJob {
+    const float* part;
+    float* dst;
+    int NR, RP, N, rank;
+    long long sr, sn;
+};
+struct ReduceRide {
+    ReduceJob j0, j1;
+    float scale;
+    int accumulate;
+    int rows;       // leading blockIdx.y rows of the host kernel that run reduction blocks (0 = none riding)
+    int nblk;       // reduction blocks per job
+};
+
+__device__ __forceinline__ void reduce_block(const ReduceJob& jb, long long blk, float scale, int accumulate, float* sm /* [4][64] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long idx = blk * 64 + lane;
+    const bool ok = jb.dst != nullptr && idx < (long long)jb.rank * jb.N;
+    int r = 0, n = 0;
+    float s = 0.f;
+    if (ok) {
+        r = (int)(idx / jb.N);
+        n = (int)(idx % jb.N);
+        const long long stride = (long long)jb.RP * jb.N;
+        const float* p = jb.part + (long long)r * jb.N + n;
+        int rs = wave;
+        for (; rs + 12 < jb.NR; rs += 16) {
+            const float a0 = p[rs * stride], a1 = p[(rs + 4) * stride], a2 = p[(rs + 8) * stride],
+                        a3 = p[(rs + 12) * stride];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; rs < jb.NR; rs += 4) s += p[rs * stride];
+    }
+    sm[wave * 64 + lane] = s;
+    __syncthreads();
+    if (ok && wave == 0) {
+        const float tot = ((sm[lane] + sm[64 + lane]) + sm[128 + lane]) + sm[192 + lane];
+        float* d = jb.dst + r * jb.sr + n * jb.sn;
+        *d = accumulate ? (*d + scale * tot) : scale * tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce(ReduceJob j0, ReduceJob j1, float scale, int accumulate) {
+    __shared__ float sm[4 * 64];
+    reduce_block(blockIdx.y == 0 ? j0 : j1, blockIdx.x, scale, accumulate, sm);
 }
 
 template <typename YT>
@@ -458,13 +547,22 @@ struct YTile<float> {
     }
 };
 
-template <typename YT, int RT, bool DROP, int ACT = 0>
+// HL (RT == 2): W2t = [hi | lo] of the LoRA operand, T = [hi | lo] of t: delta = hi.t_hi + hi.t_lo + lo.t_hi.
+template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false>
 __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
-                                            int tiles_per_wg, DropKey dk, YT* __restrict__ AUX = nullptr,
-                                            long long ldaux = 0) {
+                                            int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
+                                            ReduceRide ride) {
+    static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
     __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
+    if (blockIdx.y < (unsigned)ride.rows) {     // riding reduction blocks (scheduled first; see reduce_block)
+        const long long e = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        if (e < 2LL * ride.nblk)
+            reduce_block(e < ride.nblk ? ride.j0 : ride.j1, e % ride.nblk, ride.scale, ride.accumulate, &slab_all[0][0]);
+        return;
+    }
+    const unsigned by = blockIdx.y - (unsigned)ride.rows;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     float* slab = slab_all[wave];
@@ -483,8 +581,8 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
     }
 
     const long long ntiles = (M + 15) / 16, nfull = M / 16;
-    const long long t_begin = (long long)blockIdx.y * tiles_per_wg + wave;
-    const long long t_end = min((long long)(blockIdx.y + 1) * tiles_per_wg, ntiles);
+    const long long t_begin = (long long)by * tiles_per_wg + wave;
+    const long long t_end = min((long long)(by + 1) * tiles_per_wg, ntiles);
     const int col = c0 + (lane & 15) * 8;
 
     // T fragment of a tile (MFMA B-operand: k = rank index, n = activation row); T has Mp >= 16*ntiles rows
@@ -500,6 +598,12 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
             if (RT == 1) {
                 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wlo[ct]),
                                                              __builtin_bit_cast(s16x4, tlo), d, 0, 0, 0);
+            } else if (HL) {
+                // three K = 16 products: w_hi.t_hi + w_hi.t_lo + w_lo.t_hi   (lo.lo is below fp32 resolution); K = 16 forms keep
+                // the operand registers of the rank-32 kernel (a K = 32 MFMA would need (w_hi, w_hi) duplicated: +32 VGPRs)
+                d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, whi[ct]), __builtin_bit_cast(s16x4, tlo), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wlo[ct]), __builtin_bit_cast(s16x4, thi), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wlo[ct]), __builtin_bit_cast(s16x4, tlo), d, 0, 0, 0);
             } else {
                 const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
                 const uint4 tb = make_uint4(tlo.x, tlo.y, thi.x, thi.y);
@@ -558,11 +662,15 @@ __global__ __launch_bounds__(256) void k_t2(YT* __restrict__ Y, long long ldy, c
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename XT, int RT, bool GATHER, bool DROP>
+// HL (RT == 2): the two fragment blocks of a step are the hi and lo parts of the same 16 rank indices and accumulate
+// into ONE rank tile (RTA = 1): G = t_hi^T X + t_lo^T X.
+template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false>
 __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
                                             long long M, long long Mp, int N, int rows_per_wg, DropKey dk) {
-    constexpr int RP = RT * 16, CW = 128, CPR = 16;
+    static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
+    constexpr int RTA = HL ? 1 : RT;            // rank tiles of the result
+    constexpr int RP = RTA * 16, CW = 128, CPR = 16;
     __shared__ uint4 xs[4][32 * CPR];      // 32 rows x 256 B per wave; reused as the reduction buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
@@ -594,9 +702,9 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
             r_.x[q].load(X + (m < M ? m : M - 1) * ldx + colc);
         }
     };
-    f32x4 acc[RT][8];
+    f32x4 acc[RTA][8];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RTA; ++rt)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     uint4* slab = xs[wave];
@@ -644,8 +752,8 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
                 // D[i = rank idx][n = column] += sum_m T[m][i] * X[m][col]
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[rt]), xf,
-                                                                     acc[rt][ct], 0, 0, 0);
+                acc[HL ? 0 : rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[rt]), xf,
+                                                                              acc[HL ? 0 : rt][ct], 0, 0, 0);
         }
         wave_sync();
     };
@@ -665,7 +773,7 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
     float* red = reinterpret_cast<float*>(&xs[0][0]);     // [4 waves][8 col tiles][64 lanes][4] floats = 32 KB
     float* out = Gpart + (long long)rg * RP * N;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    for (int rt = 0; rt < RTA; ++rt) {
         __syncthreads();
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
@@ -696,12 +804,14 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
 // GTP[column pair][row][16] (fp32).  k_gt_reduce sums the pairs in fixed order.  Extra traffic: 2 x ceil(N/256) x M
 // x 64 B (partials out and back, 100 MB at N = 4736) instead of a second M x N x 2 B read (393 MB).
 // ------------------------------------------------------------------------------------------
-template <typename XT>
+// HL: TTf holds (t_hi, t_lo) blocks per step (rank-32 layout) and W1b rows 16..31 the lo parts of B_c: both products
+// run hi + lo into the same fp32 accumulators.
+template <typename XT, bool HL>
 __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf,
                                              float* __restrict__ Gpart, long long M, long long Mp, int N,
                                              int rows_per_wg, const bf16_t* __restrict__ W1b,
                                              float* __restrict__ GTP) {
-    constexpr int RP = 16, CPR = 16;
+    constexpr int RP = 16, CPR = 16, NH = HL ? 2 : 1;
     __shared__ uint4 xs[4][32 * CPR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
@@ -722,24 +832,27 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
     }
     // B operand of the gt contraction, per lane: B_c[r = n][c0 + cc*128 + ks*32 + g*8 .. +8]; the same for all four
     // waves and all row steps -> staged once in LDS in fragment order (32 registers per lane otherwise)
-    __shared__ uint4 wbs[8][64];
-    if (wave < 2) {
+    __shared__ uint4 wbs[NH * 8][64];        // [half][chunk][ks]
+    if (wave < 2 * NH) {
+        const int cc = wave & 1, h = wave >> 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int cb = c0 + wave * 128 + ks * 32 + g * 8;
-            wbs[wave * 4 + ks][lane] = and4(*reinterpret_cast<const uint4*>(W1b + (long long)n * N + (cb < N ? cb : N - 8)),
-                                            cb < N ? 0xffffffffu : 0u);
+            const int cb = c0 + cc * 128 + ks * 32 + g * 8;
+            wbs[h * 8 + cc * 4 + ks][lane] =
+                and4(*reinterpret_cast<const uint4*>(W1b + (long long)(h * 16 + n) * N + (cb < N ? cb : N - 8)), cb < N ? 0xffffffffu : 0u);
         }
     }
     __syncthreads();
     struct Regs {
-        uint4 t;
+        uint4 t[NH];
         Raw8<XT> x[8];
     };
     auto gload = [&](int s0, int cc, Regs& r_) {
         const int s = s0 < nst ? s0 : nst - 1;
         const long long mb = w_begin + (long long)s * 32;
-        r_.t = *reinterpret_cast<const uint4*>(TTf + ((mb >> 5) * 64 + lane) * 8);
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            r_.t[h] = *reinterpret_cast<const uint4*>(TTf + (((mb >> 5) * NH + h) * 64 + lane) * 8);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const long long m = mb + lr + 4 * q;
@@ -769,8 +882,11 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
             for (int ks = 0; ks < 4; ++ks) {
                 const uint4 xa = slab[row * CPR + ((ks * 4 + g) ^ (t3_h(row) << 1))];
                 // D[i = row][n = rank idx] += sum_col gy[row][col] * B_c[rank idx][col]
-                ga[rtile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa),
-                                                                   __builtin_bit_cast(bf16x8, wbs[cc * 4 + ks][lane]), ga[rtile], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+                    ga[rtile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa),
+                                                                       __builtin_bit_cast(bf16x8, wbs[h * 8 + cc * 4 + ks][lane]),
+                                                                       ga[rtile], 0, 0, 0);
             }
             if (cc == 1) {
                 float* gp = GTP + ((long long)blockIdx.x * Mp + mb + rtile * 16 + g * 4) * 16 + n;
@@ -790,8 +906,10 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
             const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            acc[cc][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t),
-                                                                 __builtin_bit_cast(bf16x8, both), acc[cc][ct], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                acc[cc][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[h]),
+                                                                     __builtin_bit_cast(bf16x8, both), acc[cc][ct], 0, 0, 0);
         }
         wave_sync();
     };
@@ -831,33 +949,10 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
 }
 
 // ------------------------------------------------------------------------------------------
-// repack: strided bf16 t[M, RP] (a column slice of the augmented frozen GEMM's output, row pitch ldt)
-//   -> T[Mp, RP] row-major (k_t2's operand) and TTf fragment-major (k_t3's operand); rows >= M are zero.
-// ------------------------------------------------------------------------------------------
-template <int RT>
-__global__ __launch_bounds__(256) void k_repack(const bf16_t* __restrict__ t, long long ldt, bf16_t* __restrict__ T,
-                                                bf16_t* __restrict__ TTf, long long M, long long Mp) {
-    constexpr int RP = RT * 16;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 4 consecutive rank entries
-    if (idx >= Mp * (RP / 4)) return;
-    const long long m = idx / (RP / 4);
-    const int r0 = (int)(idx % (RP / 4)) * 4;
-    uint2 v = make_uint2(0u, 0u);
-    if (m < M) v = *reinterpret_cast<const uint2*>(t + m * ldt + r0);
-    *reinterpret_cast<uint2*>(T + m * RP + r0) = v;
-    const long long blk = m >> 5;
-    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7), rt = r0 >> 4, n0 = r0 & 15;
-    bf16_t* tb = TTf + (((blk * RT + rt) * 4 + gq) * 16 + n0) * 8 + jq;
-    tb[0] = (bf16_t)(v.x & 0xffffu);
-    tb[8] = (bf16_t)(v.x >> 16);
-    tb[16] = (bf16_t)(v.y & 0xffffu);
-    tb[24] = (bf16_t)(v.y >> 16);
-}
-
-// ------------------------------------------------------------------------------------------
 // gt = sum over column pairs (fixed order) of the fp32 partials k_t3e wrote -> bf16 T[Mp, 16] row-major
 // (k_t2's operand) and TTf fragment-major (k_t3's operand), exactly the two images k_t1 would have produced.
 // ------------------------------------------------------------------------------------------
+template <bool HL>
 __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP, int nchunks, bf16_t* __restrict__ T,
                                                    bf16_t* __restrict__ TTf, long long Mp) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 4 consecutive rank entries
@@ -867,60 +962,8 @@ __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP
     f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < nchunks; ++c)
         s4 += __builtin_bit_cast(f32x4, ldg16(GTP + ((long long)c * Mp + m) * 16 + r0));
-    uint2 v;
-    v.x = pack2(s4[0], s4[1]);
-    v.y = pack2(s4[2], s4[3]);
-    *reinterpret_cast<uint2*>(T + m * 16 + r0) = v;
-    const long long blk = m >> 5;
-    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
-    bf16_t* tb = TTf + ((blk * 4 + gq) * 16 + r0) * 8 + jq;
-    tb[0] = (bf16_t)(v.x & 0xffffu);
-    tb[8] = (bf16_t)(v.x >> 16);
-    tb[16] = (bf16_t)(v.y & 0xffffu);
-    tb[24] = (bf16_t)(v.y >> 16);
-}
-
-// ------------------------------------------------------------------------------------------
-// second-stage, fixed-order reduction of the T3 partials into the fp32 gradient tensors
-//   dst[r*sr + n*sn] (+)= scale * sum_rs part[rs][r][n]
-// ------------------------------------------------------------------------------------------
-struct ReduceJob {
-    const float* part;
-    float* dst;
-    int NR, RP, N, rank;
-    long long sr, sn;
-};
-
-// block = 64 consecutive (r, n) elements; wave w sums partials w, w+4, w+8, ... (independent loads in
-// flight), then the four wave sums are combined in the fixed order 0,1,2,3 -> bit-reproducible.
-__global__ __launch_bounds__(256) void k_reduce(ReduceJob j0, ReduceJob j1, float scale, int accumulate) {
-    const ReduceJob jb = blockIdx.y == 0 ? j0 : j1;
-    __shared__ float sm[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + lane;
-    const bool ok = jb.dst != nullptr && idx < (long long)jb.rank * jb.N;
-    int r = 0, n = 0;
-    float s = 0.f;
-    if (ok) {
-        r = (int)(idx / jb.N);
-        n = (int)(idx % jb.N);
-        const long long stride = (long long)jb.RP * jb.N;
-        const float* p = jb.part + (long long)r * jb.N + n;
-        int rs = wave;
-        for (; rs + 12 < jb.NR; rs += 16) {
-            const float a0 = p[rs * stride], a1 = p[(rs + 4) * stride], a2 = p[(rs + 8) * stride],
-                        a3 = p[(rs + 12) * stride];
-            s += a0; s += a1; s += a2; s += a3;
-        }
-        for (; rs < jb.NR; rs += 4) s += p[rs * stride];
-    }
-    sm[wave][lane] = s;
-    __syncthreads();
-    if (ok && wave == 0) {
-        const float tot = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
-        float* d = jb.dst + r * jb.sr + n * jb.sn;
-        *d = accumulate ? (*d + scale * tot) : scale * tot;
-    }
+    if (HL) store_t4_hl(T, TTf, m, r0, s4);
+    else store_t4<1>(T, TTf, m, 0, r0, pack2(s4[0], s4[1]), pack2(s4[2], s4[3]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -969,6 +1012,24 @@ struct T3Plan {
 };
 bool env_flag(const char* name);
 long long env_int(const char* name, long long dflt);
+
+// Geometry of ONE rank group (<= 32 rank indices).  bf16 activations and r <= 16: the hi + lo form (see the file header) --
+// operand images, t and gt are laid out as for rank 32 (RP = 32, two 16-wide tiles = hi | lo) while the gradients keep
+// one 16-wide rank tile (RG = 16).
+struct Geo {
+    int RP;     // width of the operand images and of t / gt in elements (16 or 32)
+    int RT;     // RP / 16: rank tiles the kernels load
+    int RG;     // width of the gradient partials' rank tile (16 or 32)
+    bool hl;
+};
+inline Geo geo_of(int rank, int dtype) {
+    Geo g;
+    g.hl = dtype != SAM3_LORA_F32 && rank <= 16 && !env_flag("SAM3_LORA_SINGLE_ROUND");
+    g.RG = rpad(rank);
+    g.RP = g.hl ? 32 : g.RG;
+    g.RT = g.RP / 16;
+    return g;
+}
 
 T3Plan plan_t3(long long Mp, int N, int RT) {
     // workgroup = 128 columns x a row group (4 waves x a quarter each, 32-row steps).  ~190 VGPRs allow
@@ -1052,7 +1113,7 @@ struct Knob {
 };
 Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", false, 0},   {"SAM3_LORA_T1_NO_SPLIT", false, 0},
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
-                  {"SAM3_LORA_TWO_PASS_GY", false, 0}};
+                  {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1125,7 +1186,7 @@ void launch_pack(const PackJob* jobs, int n, hipStream_t st) {
         long long nmax = 0;
         int dim = 0;
         for (int i = 0; i < PACK_JOBS_MAX; ++i) {
-            pj.j[i] = i < cnt ? jobs[base + i] : PackJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+            pj.j[i] = i < cnt ? jobs[base + i] : PackJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const long long ne = (long long)pj.j[i].I * pj.j[i].J;
             nmax = ne > nmax ? ne : nmax;
             dim = pj.j[i].J > dim ? pj.j[i].J : dim;
@@ -1153,7 +1214,7 @@ struct PackedLayout {
     size_t w1, w2t, w1b, w2tb, total;
 };
 PackedLayout packed_layout(int in_f, int out_f, int rank, int dtype) {
-    const int RP = rpad(rank);
+    const int RP = geo_of(rank, dtype).RP;
     const size_t e = dtype == SAM3_LORA_F32 ? 4 : 2;
     PackedLayout p;
     size_t off = 0;
@@ -1171,16 +1232,16 @@ size_t packed_total(int in_f, int out_f, int rank, int dtype) {
 }
 // bytes of the saved t of one group: bf16 fragment-major [r_pad, M_pad], or fp32 row-major [M_pad, r_pad]
 inline size_t saved_t_group_bytes(long long M, int rank, int dtype) {
-    return (size_t)rpad(rank) * (size_t)round_up(M, 64) * (dtype == SAM3_LORA_F32 ? 4 : 2);
+    return (size_t)geo_of(rank, dtype).RP * (size_t)round_up(M, 64) * (dtype == SAM3_LORA_F32 ? 4 : 2);
 }
 
 template <typename XT>
 void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t* TT, long long M, long long Mp, int K,
-               int RT, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, float* part = nullptr) {
+               int RT, bool hl, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, float* part = nullptr) {
     dim3 grid((unsigned)(Mp / 64));
     const int nk = (K + 127) / 128;
     // small M: split K over workgroups so that ~640 of them exist (fp32 partials in `part`, fixed-order sum after)
-    if (RT == 1 && part && K >= 2048 && grid.x < 512 && !env_flag("SAM3_LORA_T1_NO_SPLIT")) {
+    if ((RT == 1 || hl) && part && K >= 2048 && grid.x < 512 && !env_flag("SAM3_LORA_T1_NO_SPLIT")) {
         int ks = (int)((640 + grid.x - 1) / grid.x);
         ks = ks > 8 ? 8 : ks;
         const int kc_per = (nk + ks - 1) / ks;
@@ -1188,12 +1249,17 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
         if (ks > 1) {
             {
                 ProfScope ps(SAM3_LORA_STAGE_T1, K, st);
-                hipLaunchKernelGGL((k_t1<XT, 1, 128, true>), dim3(grid.x, (unsigned)ks), dim3(256), 0, st, (const XT*)X, ldx, W1, T,
-                                   TT, M, Mp, K, dk, part, kc_per);
+                if (hl)
+                    hipLaunchKernelGGL((k_t1<XT, 2, 128, true, true>), dim3(grid.x, (unsigned)ks), dim3(256), 0, st, (const XT*)X, ldx,
+                                       W1, T, TT, M, Mp, K, dk, part, kc_per);
+                else
+                    hipLaunchKernelGGL((k_t1<XT, 1, 128, true>), dim3(grid.x, (unsigned)ks), dim3(256), 0, st, (const XT*)X, ldx, W1, T,
+                                       TT, M, Mp, K, dk, part, kc_per);
             }
             ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, K, st);
-            hipLaunchKernelGGL(k_gt_reduce, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)part, ks, T, TT,
-                               Mp);
+            const dim3 rg((unsigned)((Mp * 4 + 255) / 256));
+            if (hl) hipLaunchKernelGGL(k_gt_reduce<true>, rg, dim3(256), 0, st, (const float*)part, ks, T, TT, Mp);
+            else hipLaunchKernelGGL(k_gt_reduce<false>, rg, dim3(256), 0, st, (const float*)part, ks, T, TT, Mp);
             return;
         }
     }
@@ -1218,13 +1284,17 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
     pad = (unsigned)env_int("SAM3_LORA_T1_LDS_PAD", pad);
     if (RT == 1)
         hipLaunchKernelGGL((k_t1<XT, 1, 128>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+    else if (hl)
+        hipLaunchKernelGGL((k_t1<XT, 2, 128, false, true>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
     else
         hipLaunchKernelGGL((k_t1<XT, 2, 128>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
 }
 
+// `ride`: the reduction blocks of this backward call (see reduce_block); rows == 0 when nothing rides
 template <typename YT>
-void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT,
-               hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0) {
+void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT, bool hl,
+               hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0,
+               const ReduceRide* ride_in = nullptr) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
     // 3 tiles per wave measured best on MI355X for both N = 4736 and N = 1024 at M = 41472 (sweep 4..48:
@@ -1232,35 +1302,42 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     long long tiles_per_wg = 12;
     while (tiles_per_wg > 4 && nchunks * ((ntiles + tiles_per_wg - 1) / tiles_per_wg) < 1024) tiles_per_wg -= 4;
     tiles_per_wg = env_int("SAM3_LORA_T2_TPW", tiles_per_wg);
-    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg));
+    ReduceRide ride{};
+    if (ride_in) {
+        ride = *ride_in;
+        ride.rows = (int)((2LL * ride.nblk + nchunks - 1) / nchunks);
+    }
+    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows);
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
-#define T2_LAUNCH(RTV, DV, AV) \
-    hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
-                       (YT*)aux, ldaux)
-#define T2_RT(RTV)                                                                     \
+#define T2_LAUNCH(RTV, DV, AV, HV) \
+    hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV, HV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
+                       (YT*)aux, ldaux, ride)
+#define T2_RT(RTV, HV)                                                                     \
     do {                                                                               \
-        if (act == 1) T2_LAUNCH(RTV, false, 1);            /* forward: no mask on y */   \
-        else if (act == 2) { if (dk.thr) T2_LAUNCH(RTV, true, 2); else T2_LAUNCH(RTV, false, 2); } \
-        else { if (dk.thr) T2_LAUNCH(RTV, true, 0); else T2_LAUNCH(RTV, false, 0); }    \
+        if (act == 1) T2_LAUNCH(RTV, false, 1, HV);            /* forward: no mask on y */   \
+        else if (act == 2) { if (dk.thr) T2_LAUNCH(RTV, true, 2, HV); else T2_LAUNCH(RTV, false, 2, HV); } \
+        else { if (dk.thr) T2_LAUNCH(RTV, true, 0, HV); else T2_LAUNCH(RTV, false, 0, HV); }    \
     } while (0)
-    if (RT == 1) T2_RT(1); else T2_RT(2);
+    if (RT == 1) T2_RT(1, false); else if (hl) T2_RT(2, true); else T2_RT(2, false);
 #undef T2_RT
 #undef T2_LAUNCH
 }
 
 template <typename XT>
 void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N,
-               const T3Plan& p, int RT, unsigned stage_bit, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
+               const T3Plan& p, int RT, bool hl, unsigned stage_bit, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
     const bool gather = env_flag("SAM3_LORA_T3_GATHER");
     ProfScope ps(stage_bit, N, st);
-#define T3_LAUNCH(RTV, GV) \
-    do { if (dk.thr) hipLaunchKernelGGL((k_t3<XT, RTV, GV, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); \
-         else hipLaunchKernelGGL((k_t3<XT, RTV, GV, false>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); } while (0)
+#define T3_LAUNCH(RTV, GV, HV) \
+    do { if (dk.thr) hipLaunchKernelGGL((k_t3<XT, RTV, GV, true, HV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); \
+         else hipLaunchKernelGGL((k_t3<XT, RTV, GV, false, HV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); } while (0)
     if (RT == 1) {
-        if (gather) T3_LAUNCH(1, true); else T3_LAUNCH(1, false);
+        if (gather) T3_LAUNCH(1, true, false); else T3_LAUNCH(1, false, false);
+    } else if (hl) {
+        if (gather) T3_LAUNCH(2, true, true); else T3_LAUNCH(2, false, true);
     } else {
-        if (gather) T3_LAUNCH(2, true); else T3_LAUNCH(2, false);
+        if (gather) T3_LAUNCH(2, true, false); else T3_LAUNCH(2, false, false);
     }
 #undef T3_LAUNCH
 }
@@ -1268,15 +1345,17 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
 // gB partials AND gt partials from one pass over gy (r <= 16); then the fixed-order chunk sum -> GT / GTT images
 template <typename XT>
 void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N,
-                    const T3Plan& p, const bf16_t* W1b, float* GTP, bf16_t* GT, bf16_t* GTT, hipStream_t st) {
+                    const T3Plan& p, bool hl, const bf16_t* W1b, float* GTP, bf16_t* GT, bf16_t* GTT, hipStream_t st) {
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
     {
         ProfScope ps(SAM3_LORA_STAGE_T3_GB, N, st);
-        hipLaunchKernelGGL((k_t3e<XT>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP);
+        if (hl) hipLaunchKernelGGL((k_t3e<XT, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP);
+        else hipLaunchKernelGGL((k_t3e<XT, false>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP);
     }
     ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, N, st);
-    hipLaunchKernelGGL(k_gt_reduce, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, p.nchunks,
-                       GT, GTT, Mp);
+    const dim3 rg((unsigned)((Mp * 4 + 255) / 256));
+    if (hl) hipLaunchKernelGGL(k_gt_reduce<true>, rg, dim3(256), 0, st, (const float*)GTP, p.nchunks, GT, GTT, Mp);
+    else hipLaunchKernelGGL(k_gt_reduce<false>, rg, dim3(256), 0, st, (const float*)GTP, p.nchunks, GT, GTT, Mp);
 }
 
 // ---- exact-fp32 launchers (lora_f32_kernels.inc) ----------------------------------------------------
@@ -1325,11 +1404,12 @@ struct FwdWs {
     size_t w1, w2t, t, tt, t1p, total;
 };
 // fp32 split-K partials of k_t1 (bf16 path, r <= 16 and fewer than 512 row tiles): up to 8 splits x Mp x 16
-inline size_t t1_part_bytes(long long Mp, int RP, int dtype) {
-    return (dtype != SAM3_LORA_F32 && RP == 16 && Mp / 64 < 512) ? (size_t)8 * Mp * 64 : 0;
+inline size_t t1_part_bytes(long long Mp, int RG, int dtype) {
+    return (dtype != SAM3_LORA_F32 && RG == 16 && Mp / 64 < 512) ? (size_t)8 * Mp * 64 : 0;
 }
 FwdWs fwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
-    const int RP = rpad(rank);
+    const Geo gq = geo_of(rank, dtype);
+    const int RP = gq.RP;
     const long long Mp = round_up(M, 64);
     const size_t e = dtype == SAM3_LORA_F32 ? 4 : 2;
     FwdWs w;
@@ -1338,7 +1418,7 @@ FwdWs fwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     w.w2t = off; off += al256((size_t)out_f * RP * e);
     w.t = off; off += al256((size_t)Mp * RP * e);
     w.tt = off; off += al256((size_t)RP * Mp * e);
-    w.t1p = off; off += al256(t1_part_bytes(Mp, RP, dtype));
+    w.t1p = off; off += al256(t1_part_bytes(Mp, gq.RG, dtype));
     w.total = off;
     return w;
 }
@@ -1348,12 +1428,13 @@ struct BwdWs {
     T3Plan pB, pA, pE;      // pE: the one-pass (k_t3e) plan over gy, bf16 path with r <= 16
 };
 BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
-    const int RP = rpad(rank);
+    const Geo gq = geo_of(rank, dtype);
+    const int RP = gq.RP, RG = gq.RG;
     const long long Mp = round_up(M, 64);
     const size_t e = dtype == SAM3_LORA_F32 ? 4 : 2;
     BwdWs w;
-    w.pB = plan_t3(Mp, out_f, RP / 16);
-    w.pA = plan_t3(Mp, in_f, RP / 16);
+    w.pB = plan_t3(Mp, out_f, RG / 16);
+    w.pA = plan_t3(Mp, in_f, RG / 16);
     w.pE = plan_t3e(Mp, out_f);
     size_t off = 0;
     w.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * e);
@@ -1363,11 +1444,11 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     w.gtt = off; off += al256((size_t)RP * Mp * e);
     w.t = off; off += al256((size_t)Mp * RP * e);
     w.tt = off; off += al256((size_t)RP * Mp * e);
-    w.pb = off; off += al256((size_t)(w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR) * RP * out_f * 4);
-    w.pa = off; off += al256((size_t)w.pA.NR * RP * in_f * 4);
+    w.pb = off; off += al256((size_t)(w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR) * RG * out_f * 4);
+    w.pa = off; off += al256((size_t)w.pA.NR * RG * in_f * 4);
     {   // gt partials of k_t3e (bf16, r <= 16); the same region serves k_t1's split-K partials at small M
-        const size_t a = (dtype != SAM3_LORA_F32 && RP == 16) ? (size_t)w.pE.nchunks * Mp * 16 * 4 : 0;
-        const size_t b = t1_part_bytes(Mp, RP, dtype);
+        const size_t a = (dtype != SAM3_LORA_F32 && RG == 16) ? (size_t)w.pE.nchunks * Mp * 16 * 4 : 0;
+        const size_t b = t1_part_bytes(Mp, RG, dtype);
         w.gtp = off; off += al256(a > b ? a : b);
     }
     w.total = off;
@@ -1455,14 +1536,16 @@ static int pack_jobs_of(const void* A, const void* B, void* packed, int in_featu
     char* p = (char*)packed;
     int n = 0;
     for (int g = 0; g < n_groups(rank); ++g) {
-        const int rg = group_rank(rank, g), RP = rpad(rg);
+        const int rg = group_rank(rank, g);
+        const Geo gq = geo_of(rg, dtype);
+        const int RP = gq.RP, hr = gq.hl ? 1 : 0, hc = gq.hl ? 2 : 0;       // hi + lo along the image's rows / columns
         const PackedLayout pl = packed_layout(in_features, out_features, rg, dtype);
         const float* Ag = (const float*)A + 32LL * g * s.a_sr;
         const float* Bg = (const float*)B + 32LL * g * s.b_sr;
-        jobs[n++] = PackJob{Ag, p + pl.w1, RP, in_features, rg, in_features, s.a_sr, s.a_si, 0, f32};
-        jobs[n++] = PackJob{Bg, p + pl.w2t, out_features, RP, out_features, rg, s.b_so, s.b_sr, 0, f32};
-        jobs[n++] = PackJob{Bg, p + pl.w1b, RP, out_features, rg, out_features, s.b_sr, s.b_so, 0, f32};
-        jobs[n++] = PackJob{Ag, p + pl.w2tb, in_features, RP, in_features, rg, s.a_si, s.a_sr, 0, f32};
+        jobs[n++] = PackJob{Ag, p + pl.w1, RP, in_features, rg, in_features, s.a_sr, s.a_si, 0, f32, hr};
+        jobs[n++] = PackJob{Bg, p + pl.w2t, out_features, RP, out_features, rg, s.b_so, s.b_sr, 0, f32, hc};
+        jobs[n++] = PackJob{Bg, p + pl.w1b, RP, out_features, rg, out_features, s.b_sr, s.b_so, 0, f32, hr};
+        jobs[n++] = PackJob{Ag, p + pl.w2tb, in_features, RP, in_features, rg, s.a_si, s.a_sr, 0, f32, hc};
         p += pl.total;
     }
     return n;
@@ -1512,7 +1595,8 @@ static void fwd_group(const void* x, const void* A_g, const void* B_g, bool pre,
                       int in_features, int out_features, int rank, long long ldx, long long ldy, const Strides& s,
                       float scale, const DropKey& dk, int dtype, char* ws, hipStream_t st, int act, void* act_out,
                       long long ldact) {
-    const int RP = rpad(rank), RT = RP / 16;
+    const Geo gq = geo_of(rank, dtype);
+    const int RP = gq.RP, RT = gq.RT, hr = gq.hl ? 1 : 0, hc = gq.hl ? 2 : 0;
     const long long Mp = round_up(M, 64);
     const bool f32 = dtype == SAM3_LORA_F32;
     const FwdWs w = fwd_ws(M, in_features, out_features, rank, dtype);
@@ -1521,8 +1605,8 @@ static void fwd_group(const void* x, const void* A_g, const void* B_g, bool pre,
     void* W2t = pre ? (void*)((char*)A_g + pl.w2t) : (void*)(ws + w.w2t);
     // W1[RP][in] = A_c^T ; W2t[out][RP] = B_c^T
     if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
-        PackJob ja{(const float*)A_g, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0, f32};
-        PackJob jb{(const float*)B_g, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0, f32};
+        PackJob ja{(const float*)A_g, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0, f32, hr};
+        PackJob jb{(const float*)B_g, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0, f32, hc};
         launch_pack(ja, jb, st);
     }
     if (f32) {
@@ -1537,10 +1621,11 @@ static void fwd_group(const void* x, const void* A_g, const void* B_g, bool pre,
     bf16_t* T = (bf16_t*)(ws + w.t);
     bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
     if (stage_on(SAM3_LORA_STAGE_T1))
-        launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1, T, TT, M, Mp, in_features, RT, st, dk, RT == 1 ? (float*)(ws + w.t1p) : nullptr);
+        launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1, T, TT, M, Mp, in_features, RT, gq.hl, st, dk,
+                          gq.RG == 16 ? (float*)(ws + w.t1p) : nullptr);
     if (stage_on(SAM3_LORA_STAGE_T2))
-        launch_t2<bf16_t>(y_inout, ldy, T, (const bf16_t*)W2t, M, out_features, scale, RT, st, DropKey{0u, 0u, 0}, act ? 1 : 0,
-                          act_out, ldact);
+        launch_t2<bf16_t>(y_inout, ldy, T, (const bf16_t*)W2t, M, out_features, scale, RT, gq.hl, st, DropKey{0u, 0u, 0},
+                          act ? 1 : 0, act_out, ldact);
 }
 
 static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
@@ -1607,7 +1692,9 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
                       void* gx_inout, float* gA_g, float* gB_g, long long M, int in_features, int out_features, int rank,
                       long long ldgy, long long ldx, long long ldgx, const Strides& s, float scale, const DropKey& dk,
                       int dtype, int accumulate, char* ws, hipStream_t st, int a2, void* hpre, long long ldpre) {
-    const int RP = rpad(rank), RT = RP / 16;
+    const Geo gq = geo_of(rank, dtype);
+    const int RP = gq.RP, RT = gq.RT, RG = gq.RG, hr = gq.hl ? 1 : 0, hc = gq.hl ? 2 : 0;
+    const bool hl = gq.hl;
     const long long Mp = round_up(M, 64);
     const bool f32 = dtype == SAM3_LORA_F32;
     const BwdWs w = bwd_ws(M, in_features, out_features, rank, dtype);
@@ -1619,9 +1706,9 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     float* PA = (float*)(ws + w.pa);
     // W1b[RP][out] = B_c ; W2tb[in][RP] = A_c ; W1a[RP][in] = A_c^T (only to recompute t)
     if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
-        PackJob jobs[3] = {{(const float*)B_g, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so, 0, f32},
-                           {(const float*)A_g, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0, f32},
-                           {(const float*)A_g, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0, f32}};
+        PackJob jobs[3] = {{(const float*)B_g, W1b, RP, out_features, rank, out_features, s.b_sr, s.b_so, 0, f32, hr},
+                           {(const float*)A_g, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0, f32, hc},
+                           {(const float*)A_g, W1a, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0, f32, hr}};
         launch_pack(jobs, tT_saved ? 2 : 3, st);
     }
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
@@ -1646,32 +1733,42 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         const bf16_t* TT = (const bf16_t*)tT_saved;
         if (!TT) {  // no saved t: recompute t = x . A_c (one more pass over x)
             bf16_t* TTs = (bf16_t*)(ws + w.tt);
-            float* t1p = RT == 1 ? (float*)(ws + w.gtp) : nullptr;     // free until k_t3e runs (stream order)
-            launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1a, (bf16_t*)(ws + w.t), TTs, M, Mp, in_features, RT, st, dk, t1p);
+            float* t1p = RG == 16 ? (float*)(ws + w.gtp) : nullptr;     // free until k_t3e runs (stream order)
+            launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1a, (bf16_t*)(ws + w.t), TTs, M, Mp, in_features, RT, hl, st, dk, t1p);
             TT = TTs;
         }
         // r <= 16 with weight gradients wanted: gy is read ONCE -- k_t3e emits the gt partials beside the gB partials
-        one_pass = RT == 1 && gB_g && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
+        one_pass = RG == 16 && gB_g && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
         float* GTP = (float*)(ws + w.gtp);
         if (one_pass) {
-            launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, (const bf16_t*)W1b, GTP, GT, GTT, st);
+            launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, hl, (const bf16_t*)W1b, GTP, GT, GTT, st);
         } else {
-            if (s1) launch_t1<bf16_t>(gy, ldgy, (const bf16_t*)W1b, GT, GTT, M, Mp, out_features, RT, st, DropKey{0u, 0u, 0},
-                                      RT == 1 ? GTP : nullptr);                                                          // gt = gy . B_c^T
-            if (gB_g && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
+            if (s1) launch_t1<bf16_t>(gy, ldgy, (const bf16_t*)W1b, GT, GTT, M, Mp, out_features, RT, hl, st, DropKey{0u, 0u, 0},
+                                      RG == 16 ? GTP : nullptr);                                                         // gt = gy . B_c^T
+            if (gB_g && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, hl, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         }
-        if (gA_g && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
-        if (gx_inout && s2)
-            launch_t2<bf16_t>(gx_inout, ldgx, GT, (const bf16_t*)W2tb, M, in_features, scale, RT, st, dk, a2, hpre, ldpre);
+        if (gA_g && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
     }
-    if ((gA_g || gB_g) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
-        // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
-        ReduceJob rb{PB, gB_g, one_pass ? w.pE.NR : w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
-        ReduceJob ra{PA, gA_g, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
+    // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
+    const bool want_reduce = (gA_g || gB_g) && stage_on(SAM3_LORA_STAGE_REDUCE);
+    ReduceRide ride{};
+    if (want_reduce) {
+        ride.j0 = ReduceJob{PB, gB_g, one_pass ? w.pE.NR : w.pB.NR, RG, out_features, rank, s.b_sr, s.b_so};
+        ride.j1 = ReduceJob{PA, gA_g, w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
+        ride.scale = scale;
+        ride.accumulate = accumulate;
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
-        dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);
+        ride.nblk = (int)(((nb > na ? nb : na) + 63) / 64);
+    }
+    // the reduction rides on the bf16 rank-r update of gx (the last kernel of the call) when there is one
+    const bool riding = want_reduce && !f32 && gx_inout && s2 && !env_flag("SAM3_LORA_NO_RIDE");
+    if (!f32 && gx_inout && s2)
+        launch_t2<bf16_t>(gx_inout, ldgx, (bf16_t*)(ws + w.gt), (const bf16_t*)W2tb, M, in_features, scale, RT, hl, st, dk, a2, hpre,
+                          ldpre, riding ? &ride : nullptr);
+    if (want_reduce && !riding) {
+        dim3 grid((unsigned)ride.nblk, 2);
         ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
-        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scale, accumulate);
+        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, ride.j0, ride.j1, scale, accumulate);
     }
 }
 
@@ -1738,125 +1835,6 @@ int sam3_lora_bwd_act(const void* gy, const void* x, const void* tT_saved, const
     return bwd_impl(gy, x, tT_saved, A, B, gx_inout, gA_accum, gB_accum, M, in_features, out_features, rank, ldgy, ldx, ldgx,
                     layout, scaling, drop_p, seed, offset, dtype, accumulate, workspace, workspace_bytes, stream, act, pre_act,
                     ldpre);
-}
-
-// ---- "augmented frozen GEMM" mode --------------------------------------------------------------------
-// The caller keeps the frozen weight inside Waug[out + r_pad, in + r_pad] (bf16, row pitch ldw):
-//     Waug[:out, :in] = W         Waug[out:, :in] = A_c^T        Waug[:out, in:] = B_c^T
-// so the frozen GEMMs it runs anyway also produce the rank-r intermediates for free:
-//     x  @ Waug[:, :in]^T = [ W x | t  ]      (forward)        gy @ Waug[:out, :] = [ gy W | gt ]   (backward)
-// and k_t1 disappears from both directions; only the rank-r update (k_t2) and the M-reductions (k_t3) remain.
-
-int sam3_lora_aug_scatter(const void* A, const void* B, void* Waug, int64_t ldw, int in_features, int out_features,
-                          int rank, int layout, void* stream) {
-    g_err[0] = 0;
-    int rc;
-    if ((rc = check_common(1, in_features, out_features, rank, layout, SAM3_LORA_BF16))) return rc;
-    if (rank > 32) return fail(SAM3_LORA_ENOTSUP, "fused mode holds the rank slot inside the weight: rank <= 32");
-    if (!A || !B || !Waug) return fail(SAM3_LORA_EINVAL, "NULL pointer");
-    const int RP = rpad(rank);
-    if (ldw < in_features + RP) return fail(SAM3_LORA_EINVAL, "ldw (%lld) < in_features + r_pad", (long long)ldw);
-    const Strides s = strides_of(layout, in_features, out_features, rank);
-    bf16_t* W = (bf16_t*)Waug;
-    // rows out..out+RP: A_c^T [RP, in] ; columns in..in+RP of rows 0..out: B_c^T [out, RP]
-    PackJob ja{(const float*)A, W + (long long)out_features * ldw, RP, in_features, rank, in_features, s.a_sr, s.a_si, (int)ldw};
-    PackJob jb{(const float*)B, W + in_features, out_features, RP, out_features, rank, s.b_so, s.b_sr, (int)ldw};
-    launch_pack(ja, jb, (hipStream_t)stream);
-    return launch_ok("sam3_lora_aug_scatter");
-}
-
-size_t sam3_lora_fused_workspace_bytes(int64_t M, int in_features, int out_features, int rank) {
-    if (check_common(M, in_features, out_features, rank, 0, SAM3_LORA_BF16) || rank > 32) return 0;
-    const BwdWs w = bwd_ws(M, in_features, out_features, rank, SAM3_LORA_BF16);   // superset of what the fused calls need
-    return w.total;
-}
-
-int sam3_lora_fwd_fused(const void* t, int64_t ldt, const void* B, void* y_inout, void* tT_out, int64_t M,
-                        int in_features, int out_features, int rank, int64_t ldy, int layout, float scaling, int dtype,
-                        void* workspace, size_t workspace_bytes, void* stream) {
-    g_err[0] = 0;
-    int rc;
-    if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
-    if (dtype != SAM3_LORA_BF16) return fail(SAM3_LORA_ENOTSUP, "fused mode is bf16 only");
-    if (rank > 32) return fail(SAM3_LORA_ENOTSUP, "fused mode holds the rank slot inside the weight: rank <= 32");
-    if ((rc = check_act(y_inout, ldy, out_features, dtype, "y_inout"))) return rc;
-    if (!t || !B) return fail(SAM3_LORA_EINVAL, "t or B is NULL");
-    if (((uintptr_t)t & 7) || ((ldt * 2) & 7)) return fail(SAM3_LORA_EINVAL, "t: base and row pitch must be 8-byte aligned");
-    const BwdWs w = bwd_ws(M, in_features, out_features, rank, SAM3_LORA_BF16);
-    if (!workspace || workspace_bytes < w.total)
-        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    const int RP = rpad(rank), RT = RP / 16;
-    const long long Mp = round_up(M, 64);
-    char* ws = (char*)workspace;
-    bf16_t* T = (bf16_t*)(ws + w.t);
-    bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
-    const Strides s = strides_of(layout, in_features, out_features, rank);
-    // W2t[out][RP] = B_c^T lives in the PB partial slot (>= out*RP*2 bytes, unused in forward)
-    bf16_t* W2t = (bf16_t*)(ws + w.pb);
-    PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0};
-    PackJob j0{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
-    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(jb, j0, st);
-    {
-        ProfScope ps(SAM3_LORA_STAGE_T1, RP, st);   // reported as the (tiny) stand-in of T1
-        const long long nth = Mp * (RP / 4);
-        if (RT == 1) hipLaunchKernelGGL(k_repack<1>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)t, ldt, T, TT, M, Mp);
-        else hipLaunchKernelGGL(k_repack<2>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)t, ldt, T, TT, M, Mp);
-    }
-    if (stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(y_inout, ldy, T, W2t, M, out_features, scaling, RT, st);
-    return launch_ok("sam3_lora_fwd_fused");
-}
-
-int sam3_lora_bwd_fused(const void* gy, const void* x, const void* tT_saved, const void* gt, int64_t ldgt, const void* A,
-                        void* gx_inout, float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features,
-                        int rank, int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, int dtype,
-                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    g_err[0] = 0;
-    int rc;
-    if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
-    if (dtype != SAM3_LORA_BF16) return fail(SAM3_LORA_ENOTSUP, "fused mode is bf16 only");
-    if (rank > 32) return fail(SAM3_LORA_ENOTSUP, "fused mode holds the rank slot inside the weight: rank <= 32");
-    if ((rc = check_act(gy, ldgy, out_features, dtype, "gy"))) return rc;
-    if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
-    if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
-    if (!tT_saved || !gt || !A) return fail(SAM3_LORA_EINVAL, "tT_saved, gt or A is NULL");
-    if (((uintptr_t)gt & 7) || ((ldgt * 2) & 7)) return fail(SAM3_LORA_EINVAL, "gt: base and row pitch must be 8-byte aligned");
-    const BwdWs w = bwd_ws(M, in_features, out_features, rank, SAM3_LORA_BF16);
-    if (!workspace || workspace_bytes < w.total)
-        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    const int RP = rpad(rank), RT = RP / 16;
-    const long long Mp = round_up(M, 64);
-    char* ws = (char*)workspace;
-    bf16_t* W2tb = (bf16_t*)(ws + w.w2tb);
-    bf16_t* GT = (bf16_t*)(ws + w.gt);
-    bf16_t* GTT = (bf16_t*)(ws + w.gtt);
-    float* PB = (float*)(ws + w.pb);
-    float* PA = (float*)(ws + w.pa);
-    const Strides s = strides_of(layout, in_features, out_features, rank);
-    PackJob ja{(const float*)A, W2tb, in_features, RP, in_features, rank, s.a_si, s.a_sr, 0};
-    PackJob j0{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
-    if (stage_on(SAM3_LORA_STAGE_PACK)) launch_pack(ja, j0, st);
-    {
-        ProfScope ps(SAM3_LORA_STAGE_T1, RP, st);
-        const long long nth = Mp * (RP / 4);
-        if (RT == 1) hipLaunchKernelGGL(k_repack<1>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)gt, ldgt, GT, GTT, M, Mp);
-        else hipLaunchKernelGGL(k_repack<2>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const bf16_t*)gt, ldgt, GT, GTT, M, Mp);
-    }
-    if (gB_accum && stage_on(SAM3_LORA_STAGE_T3_GB))
-        launch_t3<bf16_t>(gy, ldgy, (const bf16_t*)tT_saved, PB, M, Mp, out_features, w.pB, RT, SAM3_LORA_STAGE_T3_GB, st);
-    if (gA_accum && stage_on(SAM3_LORA_STAGE_T3_GA))
-        launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, SAM3_LORA_STAGE_T3_GA, st);
-    if (gx_inout && stage_on(SAM3_LORA_STAGE_T2)) launch_t2<bf16_t>(gx_inout, ldgx, GT, W2tb, M, in_features, scaling, RT, st);
-    if ((gA_accum || gB_accum) && stage_on(SAM3_LORA_STAGE_REDUCE)) {
-        ReduceJob rb{PB, gB_accum, w.pB.NR, RP, out_features, rank, s.b_sr, s.b_so};
-        ReduceJob ra{PA, gA_accum, w.pA.NR, RP, in_features, rank, s.a_sr, s.a_si};
-        const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
-        dim3 grid((unsigned)(((nb > na ? nb : na) + 63) / 64), 2);
-        ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
-        hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, rb, ra, scaling, accumulate);
-    }
-    return launch_ok("sam3_lora_bwd_fused");
 }
 
 int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm, int in_features, int out_features,

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import _ffi
 from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
-__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "AugmentedWeight", "LAYOUT_ROOT", "LAYOUT_PACKAGE",
+__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "LAYOUT_ROOT", "LAYOUT_PACKAGE",
            "enable_direct_grad_accumulation", "direct_grad_accumulation", "pack_operands_many", "repack_adapters"]
 
 _ws_lock = threading.Lock()
@@ -632,124 +632,10 @@ def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool, wt_cac
                             float(l2.scaling), int(layout), p, seed1, seed2, pk1, pk2, Wt1, Wt2)
 
 
-class AugmentedWeight:
-    """Per-module state of the "augmented frozen GEMM" mode (include/sam3_lora_amd.h): the frozen weight lives
-    inside ``Waug[out + r_pad, in + r_pad]`` together with bf16 copies of A_c^T (extra rows) and B_c^T (extra
-    columns); the module's frozen ``weight`` parameter is re-pointed at ``Waug[:out, :in]`` (no second copy of W).
-    The A/B slots are refreshed whenever the fp32 masters changed (tensor version counters)."""
-
-    def __init__(self):
-        self.Waug = None
-        self.bias_aug = None
-        self._stamp = None
-        self._bias_ptr = None
-
-    def ensure(self, weight: torch.nn.Parameter, bias, A, B, layout: int):
-        lib = _ffi.load()
-        out_f, in_f = weight.shape
-        rank = _rank_of(A, layout)
-        RP = 16 if rank <= 16 else 32
-        W = self.Waug
-        if (W is None or W.device != weight.device or W.shape != (out_f + RP, in_f + RP)
-                or weight.data_ptr() != W.data_ptr() or weight.stride(0) != W.stride(0)):
-            W = torch.zeros(out_f + RP, in_f + RP, dtype=torch.bfloat16, device=weight.device)
-            W[:out_f, :in_f].copy_(weight.detach())
-            weight.data = W[:out_f, :in_f]            # alias: the parameter IS the slice from now on
-            self.Waug, self._stamp, self._bias_ptr = W, None, None
-        if bias is None:
-            self.bias_aug = None
-        elif self._bias_ptr != (bias.data_ptr(), bias._version):
-            self.bias_aug = torch.cat([bias.detach().to(torch.bfloat16), bias.new_zeros(RP, dtype=torch.bfloat16)])
-            self._bias_ptr = (bias.data_ptr(), bias._version)
-        stamp = (A.data_ptr(), A._version, B.data_ptr(), B._version)
-        if stamp != self._stamp:
-            Am, Bm = _master(A), _master(B)
-            rc = lib.sam3_lora_aug_scatter(Am.data_ptr(), Bm.data_ptr(), W.data_ptr(), W.stride(0), in_f, out_f, rank,
-                                           layout, ctypes.c_void_p(torch.cuda.current_stream(W.device).cuda_stream))
-            _ffi.check(rc, "sam3_lora_aug_scatter")
-            self._stamp = stamp
-        return W, self.bias_aug, RP
-
-
-class _LoRALinearFusedFn(torch.autograd.Function):
-    """Frozen linear + LoRA with t / gt taken from the augmented frozen GEMMs (no row-reduction kernel)."""
-
-    @staticmethod
-    def forward(ctx, x, Waug, bias_aug, A, B, scaling, layout, in_f, out_f, RP):
-        lib = _ffi.load()
-        x2 = _rows(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
-        with torch.autocast("cuda", enabled=False):
-            y_aug = F.linear(x2, Waug[:, :in_f], bias_aug)          # [M, out + RP] = [ W x + b | t ]
-        M = x2.shape[0]
-        rank = _rank_of(A, layout)
-        y2, t = y_aug[:, :out_f], y_aug[:, out_f:]
-        Bm = _master(B)
-        need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        tT = saved_t_like(M, rank, x2.device) if need_w else None
-        nws = lib.sam3_lora_fused_workspace_bytes(M, in_f, out_f, rank)
-        ws = _workspace(x2.device, nws)
-        rc = lib.sam3_lora_fwd_fused(t.data_ptr(), t.stride(0), Bm.data_ptr(), y2.data_ptr(),
-                                     tT.data_ptr() if tT is not None else None, M, in_f, out_f, rank, y2.stride(0), layout,
-                                     float(scaling), DT_BF16, ws.data_ptr(), ws.numel(),
-                                     ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
-        _ffi.check(rc, "sam3_lora_fwd_fused")
-        ctx.meta = (scaling, layout, in_f, out_f, RP, x.shape, x.dtype)
-        ctx.save_for_backward(x2, Waug, A, B, tT)
-        return y2.view(*x.shape[:-1], out_f)
-
-    @staticmethod
-    def backward(ctx, gy):
-        lib = _ffi.load()
-        x2, Waug, A, B, tT = ctx.saved_tensors
-        scaling, layout, in_f, out_f, RP, x_shape, x_dtype = ctx.meta
-        gy2 = _rows(gy if gy.dtype == torch.bfloat16 else gy.to(torch.bfloat16))
-        need_x = ctx.needs_input_grad[0]
-        need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        M = x2.shape[0]
-        rank = _rank_of(A, layout)
-        with torch.autocast("cuda", enabled=False):
-            if need_x:
-                gx_aug = gy2 @ Waug[:out_f, :]                      # [M, in + RP] = [ gy W | gt ]
-                gx2, gt = gx_aug[:, :in_f], gx_aug[:, in_f:]
-            else:
-                gx2, gt = None, gy2 @ Waug[:out_f, in_f:]
-        Am = _master(A)
-        gA = torch.empty_like(Am) if need_w else None
-        gB = torch.empty_like(_master(B)) if need_w else None
-        if need_w and tT is None:
-            raise LoRAKernelError("sam3_lora_amd: fused backward needs the t saved by its forward")
-        nws = lib.sam3_lora_fused_workspace_bytes(M, in_f, out_f, rank)
-        ws = _workspace(x2.device, nws)
-        tsave = tT if tT is not None else saved_t_like(M, rank, x2.device)   # unused when no weight grads are needed
-        rc = lib.sam3_lora_bwd_fused(gy2.data_ptr(), x2.data_ptr(), tsave.data_ptr(), gt.data_ptr(), gt.stride(0),
-                                     Am.data_ptr(), gx2.data_ptr() if gx2 is not None else None,
-                                     gA.data_ptr() if gA is not None else None, gB.data_ptr() if gB is not None else None,
-                                     M, in_f, out_f, rank, gy2.stride(0), x2.stride(0),
-                                     gx2.stride(0) if gx2 is not None else in_f, layout, float(scaling), DT_BF16, 0,
-                                     ws.data_ptr(), ws.numel(),
-                                     ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
-        _ffi.check(rc, "sam3_lora_bwd_fused")
-        gx = gx2.view(x_shape).to(x_dtype) if need_x else None
-        if need_w:
-            gA = gA.to(A.dtype) if ctx.needs_input_grad[3] else None
-            gB = gB.to(B.dtype) if ctx.needs_input_grad[4] else None
-        return gx, None, None, gA, gB, None, None, None, None, None
-
-
-def fused_mode_enabled() -> bool:
-    """Opt-in (SAM3_LORA_FUSED=1).  Measured on MI355X / ROCm 7.2 / torch 2.10 (same-box A/B, whole ViT-trunk step,
-    batch 8): 331 ms with the augmented GEMMs vs 304 ms standalone -- the k_t1 launches it removes (7.6 ms) are
-    outweighed by hipBLASLt picking slower kernels for N = 4752 / 1040 (+12 ms) and by PyTorch's elementwise
-    kernels (GELU fwd/bwd, copies) leaving their vectorised path on the row-strided views (+20 ms).  It pays only
-    once those consumers are ours too; kept for that next step."""
-    import os
-    return os.environ.get("SAM3_LORA_FUSED", "0") == "1"
-
-
 def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], A: torch.Tensor,
                 B: torch.Tensor, scaling: float, layout: int, dropout_p: float = 0.0,
-                training: bool = False, aug: Optional[AugmentedWeight] = None,
-                cache: Optional[PackedOperands] = None, wt_cache: Optional[TransposedCopy] = None) -> torch.Tensor:
+                training: bool = False, cache: Optional[PackedOperands] = None,
+                wt_cache: Optional[TransposedCopy] = None) -> torch.Tensor:
     """``F.linear(x, weight, bias) + scaling * (dropout(x) @ A_c) @ B_c`` on the HIP path.
 
     ``layout`` selects how A/B are stored (LAYOUT_ROOT: A[in,r], B[r,out]; LAYOUT_PACKAGE:
@@ -757,21 +643,11 @@ def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[
     (lora_layers.py:54, lora_layer.py:73) and is generated inside the kernels from a counter-based
     hash; the seed is drawn from torch's CPU generator, so ``torch.manual_seed`` controls it and
     ``torch.utils.checkpoint`` (which restores the RNG state for its recompute) replays the mask.
-
-    With ``aug`` given, a bf16 frozen weight and no active dropout, the "augmented frozen GEMM" mode is used:
-    ``t`` and ``gt`` fall out of the frozen GEMMs and only the rank-r update and the M-reductions run as
-    separate kernels.
     """
     p, seed = 0.0, 0
     if training and dropout_p > 0.0:
         p = float(dropout_p)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    if (aug is not None and p == 0.0 and weight is not None and weight.is_cuda and weight.dtype == torch.bfloat16
-            and not weight.requires_grad and fused_mode_enabled() and not torch.is_autocast_enabled("cuda")
-            and x.dtype in (torch.bfloat16, torch.float32)):
-        Waug, bias_aug, RP = aug.ensure(weight, bias, A, B, layout)
-        return _LoRALinearFusedFn.apply(x, Waug, bias_aug, A, B, float(scaling), int(layout), weight.shape[1],
-                                        weight.shape[0], RP)
     packed = None
     if cache is not None and A.is_cuda and x.numel() > 0:
         fin = A.shape[0] if layout == LAYOUT_ROOT else A.shape[1]

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .._ffi import MAX_RANK
-from ..functional import LAYOUT_PACKAGE, AugmentedWeight, PackedOperands, TransposedCopy, lora_linear, merge_weight
+from ..functional import LAYOUT_PACKAGE, PackedOperands, TransposedCopy, lora_linear, merge_weight
 
 
 class LoRALayer(nn.Module):
@@ -63,7 +63,6 @@ class LinearWithLoRA(nn.Module):
         self.out_features = linear.out_features
         self.lora = LoRALayer(linear.in_features, linear.out_features, rank=rank, alpha=alpha,
                               dropout=dropout)
-        self._aug = AugmentedWeight()     # plain attribute: not a parameter/buffer, not in state_dict
         self._wt = TransposedCopy()       # W^T of the frozen weight for the TN-form input-gradient GEMM (not state)
 
     # nn.MultiheadAttention and friends read these off the wrapped module
@@ -78,7 +77,7 @@ class LinearWithLoRA(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lo = self.lora
         return lora_linear(x, self.linear.weight, self.linear.bias, lo.lora_A, lo.lora_B, lo.scaling,
-                           LAYOUT_PACKAGE, lo.dropout_p, self.training, aug=self._aug, cache=lo._packed, wt_cache=self._wt)
+                           LAYOUT_PACKAGE, lo.dropout_p, self.training, cache=lo._packed, wt_cache=self._wt)
 
     def merge_weights(self) -> nn.Linear:
         """A plain nn.Linear whose weight is ``W + scaling * B @ A`` (bias cloned)."""

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ._ffi import MAX_RANK
-from .functional import LAYOUT_ROOT, AugmentedWeight, PackedOperands, TransposedCopy, lora_linear
+from .functional import LAYOUT_ROOT, PackedOperands, TransposedCopy, lora_linear
 
 __all__ = [
     "LoRALayer", "LoRALinear", "LoRAConfig", "apply_lora_to_model", "get_lora_parameters",
@@ -70,13 +70,12 @@ class LoRALinear(nn.Module):
             p.requires_grad = False
         self.lora = LoRALayer(original_layer.in_features, original_layer.out_features,
                               rank=rank, alpha=alpha, dropout=dropout)
-        self._aug = AugmentedWeight()     # plain attribute: not a parameter/buffer, not in state_dict
         self._wt = TransposedCopy()       # W^T of the frozen weight for the TN-form input-gradient GEMM (not state)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lo = self.lora
         return lora_linear(x, self.original_layer.weight, self.original_layer.bias, lo.lora_A, lo.lora_B,
-                           lo.scaling, LAYOUT_ROOT, lo.dropout_p, self.training, aug=self._aug, cache=lo._packed, wt_cache=self._wt)
+                           lo.scaling, LAYOUT_ROOT, lo.dropout_p, self.training, cache=lo._packed, wt_cache=self._wt)
 
 
 class LoRAConfig:

@@ -52,3 +52,73 @@ LORA = dict(rank=4, alpha=8, dropout=0.0, target_modules=["fc1", "fc2", "linear1
             apply_to_detr_encoder=True, apply_to_detr_decoder=True, apply_to_mask_decoder=False)
 LORA_B_SEED, LORA_B_STD = 5, 0.05
 LR, WD, STEPS = 1e-3, 0.01, 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A wider instance of the same structure ("tiny widths exaggerate bf16 noise"): 256-wide trunk with 8 blocks
+# at 224^2 (16 x 16 tokens, 64-wide heads, 8 x 8 windows), 128-wide DETR, rank-16 adapters (alpha 32: the benchmark's
+# configs[1]).  Its ~10 M weights are NOT stored in the fixture: every parameter is drawn from a generator seeded by the
+# CRC of its name (`seeded_parameter`), by the generating script on the reference's model and by the test on this
+# library's -- the fixture holds the buffers, the batch and the reference's outputs only.
+WIDE = dict(
+    vit=dict(img_size=224, pretrain_img_size=112, patch_size=14, embed_dim=256, depth=8, num_heads=4, mlp_ratio=4.625,
+             drop_path_rate=0.0, window_size=8, global_att_blocks=(3, 7)),
+    d_model=128, heads=4, ffn=512, dropout=0.0, enc_layers=3, dec_layers=3, num_queries=20, geo_layers=2,
+    text=dict(width=128, heads=4, layers=3, context_length=8, vocab_size=64), scoring_hidden=256, roi_size=3)
+WIDE_RES = 224
+LORA_WIDE = dict(LORA, rank=16, alpha=32)
+CONFIGS = {"tiny": (TINY, RES, LORA), "wide": (WIDE, WIDE_RES, LORA_WIDE)}
+
+
+def seeded_parameter(name: str, shape) -> torch.Tensor:
+    """Value of parameter ``name`` in the wide fixture: fp32 normal draws from a generator seeded by crc32(name).
+    Matrices / kernels ~ N(0, 1/(4 fan_in)) (about the scale of the reference's own initialisers: no head saturates),
+    embedding tables 0.1 N, 1-D ``*.weight`` (norm scales) ~ 1 + 0.1 N, 1-D biases 0.05 N, everything else (position
+    tables, ...) 0.02 N."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    shape = tuple(shape)
+    z = torch.randn(shape, generator=g)
+    leaf = name.rsplit(".", 1)[-1]
+    if len(shape) >= 2 and leaf in ("weight", "in_proj_weight", "text_projection"):
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        if "embed" in name and len(shape) == 2 and "patch_embed" not in name:     # nn.Embedding tables
+            return z * 0.1
+        return z * 0.5 * fan_in ** -0.5
+    if len(shape) == 1 and leaf == "weight":
+        return 1.0 + 0.1 * z
+    if len(shape) == 1:
+        return 0.05 * z
+    return 0.02 * z
+
+
+def make_images_res(res, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(3, res, res, generator=g) for _ in SAMPLES]
+
+
+def box_mask_res(box, res):
+    cx, cy, w, h = box
+    x0, x1 = int(round((cx - w / 2) * res)), int(round((cx + w / 2) * res))
+    y0, y1 = int(round((cy - h / 2) * res)), int(round((cy + h / 2) * res))
+    m = torch.zeros(res, res, dtype=torch.bool)
+    m[y0:y1, x0:x1] = True
+    return m
+
+
+def seeded_adapter(name: str, a_shape, b_shape):
+    """(A, B) of adapter ``name`` in the wide fixture (root layout A[in, r], B[r, out]): A ~ U(+-1/sqrt(r)) as the
+    reference's initialiser draws it (lora_layers.py:42-44), B ~ N(0, LORA_B_STD^2) -- a warmed state."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(("lora:" + name).encode()))
+    r = a_shape[1]
+    A = (torch.rand(tuple(a_shape), generator=g) * 2 - 1) * r ** -0.5
+    B = torch.randn(tuple(b_shape), generator=g) * LORA_B_STD
+    return A, B
+
+
+# adapters whose gradients the wide fixture stores (first / last trunk block, text tower, fusion encoder, decoder)
+WIDE_GRAD_MODULES = ("trunk.blocks.0.mlp.fc1", "trunk.blocks.0.mlp.fc2", "trunk.blocks.7.mlp.fc1", "trunk.blocks.7.mlp.fc2",
+                     "resblocks.0.mlp.c_fc", "encoder.layers.0.linear1", "decoder.layers.2.linear2")

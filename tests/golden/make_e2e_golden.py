@@ -6,7 +6,10 @@ UniversalSegmentationHead, Sam3Image, collate_fn_api, BinaryHungarianMatcherV2, 
 injector -- imported from /root/reference and assembled exactly as ``sam3/model_builder.py:58-324,478-512`` assembles
 them, at the tiny widths of e2e_case_defs.TINY, dropout / DropPath 0, CPU fp32.  Build container only.
 
-    python tests/golden/make_e2e_golden.py   ->  e2e_tiny.npz
+    python tests/golden/make_e2e_golden.py        ->  e2e_tiny.npz   (all weights stored)
+    python tests/golden/make_e2e_golden.py wide   ->  e2e_wide.npz   (e2e_case_defs.WIDE: 256-wide trunk x 8 blocks at
+                                                      224^2, rank-16 adapters; weights = e2e_case_defs.seeded_parameter,
+                                                      so only buffers, batch and outputs are stored)
 
 Stores: the state dict, the collated batch, the training-mode forward (every output tensor, aux outputs, matcher
 indices), the eval-mode forward, and -- with root LoRA injected and B seeded non-zero -- the loss dictionary, A/B
@@ -34,7 +37,7 @@ import e2e_case_defs as D
 from loss_case_defs import CLI_LOSS_CFG
 
 
-def build_reference_tiny():
+def build_reference_tiny(c=None):
     from sam3.model.decoder import TransformerDecoder, TransformerDecoderLayer
     from sam3.model.encoder import TransformerEncoderFusion, TransformerEncoderLayer
     from sam3.model.geometry_encoders import SequenceGeometryEncoder
@@ -47,7 +50,7 @@ def build_reference_tiny():
     from sam3.model.vitdet import ViT
     from sam3.model.vl_combiner import SAM3VLBackbone
     from sam3.train.matcher import BinaryHungarianMatcherV2
-    c = D.TINY
+    c = c or D.TINY
     d, h, ffn, p = c["d_model"], c["heads"], c["ffn"], c["dropout"]
     vit = ViT(norm_layer="LayerNorm", qkv_bias=True, use_abs_pos=True, tile_abs_pos=True, rel_pos_blocks=(),
               use_rope=True, use_interp_rope=True, pretrain_use_cls_token=True, retain_cls_token=False, ln_pre=True,
@@ -98,20 +101,21 @@ def build_reference_tiny():
                      use_instance_query=False, multimask_output=True, inst_interactive_predictor=None, matcher=matcher)
 
 
-def reference_batch():
+def reference_batch(res=None):
     from sam3.train.data.collator import collate_fn_api
     from sam3.train.data.sam3_image_dataset import Datapoint, FindQueryLoaded, Image, InferenceMetadata, Object
-    imgs = D.make_images()
+    res = res or D.RES
+    imgs = D.make_images_res(res)
     dps = []
     for i, ((text, boxes), img) in enumerate(zip(D.SAMPLES, imgs)):
-        objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask(b))
+        objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask_res(b, res))
                 for j, b in enumerate(boxes)]
         q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
                             query_processing_order=0,
                             inference_metadata=InferenceMetadata(coco_image_id=i, original_image_id=i,
-                                                                 original_category_id=0, original_size=(D.RES, D.RES),
+                                                                 original_category_id=0, original_size=(res, res),
                                                                  object_id=-1, frame_index=-1))
-        dps.append(Datapoint(find_queries=[q], images=[Image(data=img, objects=objs, size=(D.RES, D.RES))]))
+        dps.append(Datapoint(find_queries=[q], images=[Image(data=img, objects=objs, size=(res, res))]))
     return collate_fn_api(dps, dict_key="input", with_seg_masks=True)["input"]
 
 
@@ -140,6 +144,8 @@ def dump_outputs(res, tag, out):
 
 
 def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+    CFG, RESOLUTION, LORA_CFG = D.CONFIGS[which]
     sam3_manifest._install_stubs()
     sam3_manifest._patch_cuda_literals()
     sys.modules["timm.layers"].trunc_normal_ = torch.nn.init.trunc_normal_
@@ -162,26 +168,34 @@ def main():
     LF.sigmoid_focal_loss = functools.partial(LF.sigmoid_focal_loss, triton=False)
 
     torch.manual_seed(0)
-    model = build_reference_tiny()
+    model = build_reference_tiny(CFG)
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
-        te = model.backbone.language_backbone.encoder
-        te.positional_embedding.copy_(torch.randn(te.positional_embedding.shape, generator=g) * 0.01)
-        te.text_projection.copy_(torch.randn(te.text_projection.shape, generator=g) * te.width ** -0.5)
-        for n, p in model.named_parameters():      # non-trivial norms / biases; non-zero final box-head layer
-            if p.ndim == 1:
-                p.add_(torch.randn(p.shape, generator=g) * 0.1)
-        model.transformer.decoder.bbox_embed.layers[-1].weight.copy_(
-            torch.randn(model.transformer.decoder.bbox_embed.layers[-1].weight.shape, generator=g) * 0.05)
+        if which != "tiny":     # weights by name-seeded draws (reproduced by the test): nothing of them is stored
+            for n, p in model.named_parameters():
+                p.copy_(D.seeded_parameter(n, p.shape))
+        else:
+            te = model.backbone.language_backbone.encoder
+            te.positional_embedding.copy_(torch.randn(te.positional_embedding.shape, generator=g) * 0.01)
+            te.text_projection.copy_(torch.randn(te.text_projection.shape, generator=g) * te.width ** -0.5)
+            for n, p in model.named_parameters():      # non-trivial norms / biases; non-zero final box-head layer
+                if p.ndim == 1:
+                    p.add_(torch.randn(p.shape, generator=g) * 0.1)
+            model.transformer.decoder.bbox_embed.layers[-1].weight.copy_(
+                torch.randn(model.transformer.decoder.bbox_embed.layers[-1].weight.shape, generator=g) * 0.05)
     res = {}
+    param_names = {n for n, _ in model.named_parameters()}
     for k, v in model.state_dict().items():
+        if which != "tiny" and k in param_names:
+            continue                                    # reproduced from its name (seeded_parameter)
         if v.is_complex():
             res[f"sd/{k}.re"], res[f"sd/{k}.im"] = np_(v.real), np_(v.imag)
         else:
             res[f"sd/{k}"] = np_(v)
     res["sd_keys"] = np.array(list(model.state_dict().keys()))
+    res["param_names"] = np.array(sorted(param_names))
 
-    batch = reference_batch()
+    batch = reference_batch(RESOLUTION)
     fi, ft = batch.find_inputs[0], batch.find_targets[0]
     res["batch/img_batch"] = np_(batch.img_batch)
     res["batch/texts"] = np.array(batch.find_text_batch)
@@ -205,12 +219,16 @@ def main():
 
     # LoRA + the native CLI's loss stack and loop
     with contextlib.redirect_stdout(io.StringIO()):
-        ref_root.apply_lora_to_model(model, ref_root.LoRAConfig(**D.LORA))
+        ref_root.apply_lora_to_model(model, ref_root.LoRAConfig(**LORA_CFG))
     names = [n for n, m in model.named_modules() if isinstance(m, ref_root.LoRALinear)]
     gb = torch.Generator().manual_seed(D.LORA_B_SEED)
     with torch.no_grad():
         for n, m in model.named_modules():
             if isinstance(m, ref_root.LoRALayer):
+                if which != "tiny":     # reproduced from the name by the test, not stored
+                    A, B = D.seeded_adapter(n, m.lora_A.shape, m.lora_B.shape)
+                    m.lora_A.copy_(A), m.lora_B.copy_(B)
+                    continue
                 m.lora_B.copy_(torch.randn(m.lora_B.shape, generator=gb) * D.LORA_B_STD)
                 res[f"lora/{n}.lora_A"], res[f"lora/{n}.lora_B"] = np_(m.lora_A), np_(m.lora_B)
     res["lora_module_names"] = np.array(names)
@@ -238,18 +256,22 @@ def main():
             for k, v in loss_dict.items():
                 res[f"loss/{k}"] = np.float64(float(v))
             for n, m in model.named_modules():
-                if isinstance(m, ref_root.LoRALayer):
+                if isinstance(m, ref_root.LoRALayer) and (which == "tiny" or any(w in n for w in D.WIDE_GRAD_MODULES)):
                     res[f"gA/{n}"], res[f"gB/{n}"] = np_(m.lora_A.grad), np_(m.lora_B.grad)
         opt.step()
         if step == 0:
             for n, m in model.named_modules():
-                if isinstance(m, ref_root.LoRALayer):
+                if isinstance(m, ref_root.LoRALayer) and which == "tiny":
                     res[f"A1/{n}"], res[f"B1/{n}"] = np_(m.lora_A), np_(m.lora_B)
         losses.append(total.item())
     res["losses"] = np.array(losses, np.float64)
-    np.savez_compressed(os.path.join(HERE, "e2e_tiny.npz"), **res)
+    if which != "tiny":         # the big per-query mask tensors are pinned by the tiny fixture; keep this one small
+        for k in [k for k in res if k.endswith(("pred_masks", "pred_masks_o2m", "encoder_hidden_states"))]:
+            res[k] = res[k][:, :4] if res[k].ndim == 4 else res[k][::8]
+    out_path = os.path.join(HERE, f"e2e_{which}.npz")
+    np.savez_compressed(out_path, **res)
     print("adapted:", len(names), "modules; losses:", " ".join(f"{l:.6f}" for l in losses))
-    print("arrays:", len(res), "; bytes:", os.path.getsize(os.path.join(HERE, "e2e_tiny.npz")))
+    print("arrays:", len(res), "; bytes:", os.path.getsize(out_path))
 
 
 if __name__ == "__main__":

@@ -6,10 +6,13 @@ GPU parity (run with ``-m gpu`` on an MI355X): the HIP path, called through the 
     GPU plus size-independent properties (linearity, bitwise run-to-run determinism).
 
 Tolerances (floating point; stated per check):
-  bf16 activations: the kernels contract bf16 operands with fp32 accumulation and round the rank-r intermediate
-  (t, gt) to bf16 once.  Against a model of exactly those roundings (``adapter_delta_bf16_model``) outputs agree to
-  6e-3 of the tensor's max magnitude; against the fp32 reference to 1e-2 of it (bf16 has 8 mantissa bits: 2^-9 = 2e-3
-  relative per rounding).
+  bf16 activations, r <= 16 (the benchmark's layout): A, B and the rank-r intermediates t / gt travel as hi + lo bf16 pairs,
+  so the branch is fp32 arithmetic on the caller's bf16 data.  Against the fp64 oracle ON THE SAME bf16 INPUTS the fp32
+  weight gradients agree to 3e-5 of max |.| and every bf16 output element to ONE rounding of the output (2^-8 relative,
+  ``_one_rounding``) -- tests ``test_hi_lo_*``; the older, looser checks below (1e-2 against the reference's fp32 outputs
+  from fp32 inputs, 6e-3 against the single-rounding model) bound the effect of rounding x / gy themselves.
+  bf16 activations, 16 < r <= 32 per group: A, B, t, gt rounded to bf16 once each: 6e-3 of max |.| against a model of exactly
+  those roundings (``adapter_delta_bf16_model``), 1e-2 against the fp32 reference.
   fp32 activations: exact fp32 products and accumulation (v_mfma_f32_16x16x4_f32), fp32 intermediates: 1e-5 of the
   tensor's max magnitude against the reference's own fp32 outputs and against the fp64 oracle.
 """
@@ -53,9 +56,18 @@ def _knobs_back_to_environment():
     yield
     if torch.cuda.is_available():
         import os
-        for k in ("SAM3_LORA_T3_GATHER", "SAM3_LORA_TWO_PASS_GY", "SAM3_LORA_T1_NO_SPLIT"):
+        for k in ("SAM3_LORA_T3_GATHER", "SAM3_LORA_TWO_PASS_GY", "SAM3_LORA_T1_NO_SPLIT", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE"):
             os.environ.pop(k, None)
         _reload_knobs()
+
+
+def _one_rounding(got, ref, slack=3e-5):
+    """Every element of the bf16 tensor ``got`` is the fp64 reference up to ONE rounding to bf16 (half an ulp = 2^-8 relative
+    at most) plus the fp32 accumulation error of the kernels (``slack`` of the tensor's max magnitude)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    bound = 2.0 ** -8 * np.abs(ref) + slack * np.abs(ref).max()
+    bad = np.abs(got - ref) > bound
+    assert not bad.any(), (int(bad.sum()), float((np.abs(got - ref) / (np.abs(ref).max() + 1e-30)).max()))
 
 
 def _golden(golden_dir, name):
@@ -65,7 +77,7 @@ def _golden(golden_dir, name):
 def test_library_is_the_hip_one():
     from sam3_lora_amd import _ffi
     lib = _ffi.load()
-    assert lib.sam3_lora_abi_version() == 2
+    assert lib.sam3_lora_abi_version() == 3
     assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
 
 
@@ -343,42 +355,6 @@ def test_errors_are_loud():
         root_api.LoRALinear(torch.nn.Linear(16, 16))(torch.zeros(2, 16))  # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize("api", ["root", "package"])
-def test_augmented_gemm_mode_matches_standalone(api, monkeypatch):
-    """t / gt taken from the augmented frozen GEMMs == the standalone kernels (same roundings: bf16 t, gt)."""
-    torch.manual_seed(3)
-    fin, fout, r = 256, 384, 16
-    outs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("SAM3_LORA_FUSED", fused)
-        torch.manual_seed(3)
-        lin = torch.nn.Linear(fin, fout)
-        mod = (root_api.LoRALinear(lin, rank=r, alpha=32) if api == "root" else pkg_api.LinearWithLoRA(lin, rank=r, alpha=32.0))
-        with torch.no_grad():
-            mod.lora.lora_B.normal_(0, 0.05)
-        mod.to(DEV)
-        base = mod.original_layer if api == "root" else mod.linear
-        base.to(torch.bfloat16)
-        x = torch.randn(3, 50, fin, device=DEV).bfloat16().requires_grad_(True)
-        y = mod(x)
-        y.float().square().sum().backward()
-        outs[fused] = (y.detach().float(), x.grad.float(), mod.lora.lora_A.grad.clone(), mod.lora.lora_B.grad.clone())
-        if fused == "1":
-            assert mod._aug.Waug is not None and base.weight.data_ptr() == mod._aug.Waug.data_ptr()   # aliased, no copy
-            # masters change -> slots refresh on the next call
-            with torch.no_grad():
-                mod.lora.lora_A.mul_(2.0)
-            y2 = mod(x.detach())
-            want = torch.nn.functional.linear(x.detach(), base.weight, base.bias).float() + 2.0 * (
-                (x.detach().float() @ (mod.lora.lora_A if api == "root" else mod.lora.lora_A.t()).float())
-                @ (mod.lora.lora_B if api == "root" else mod.lora.lora_B.t()).float())
-            assert ((y2.float() - want).abs().max() / want.abs().max()).item() < 2e-2
-        else:
-            assert mod._aug.Waug is None            # standalone mode (the default) never builds the augmented buffer
-    for a, b in zip(outs["1"], outs["0"]):
-        assert ((a - b).abs().max() / b.abs().max()).item() < 1.5e-2
-
-
 # SAM3 Linears the package API's substring targets reach that are not multiples of 8 wide
 # (tests/golden/sam3_linears.json: geometry_encoder.points_direct_project 2->256, boxes_direct_project 4->256,
 #  boxes_pos_enc_project 258->256; heads 256->4 and 256->1 for completeness)
@@ -653,3 +629,98 @@ def test_small_m_split_k_row_reduction(M, K, drop, dtype, monkeypatch):
         ref = O.adapter_delta(x.float().cpu().numpy(), A.cpu().numpy(), B.cpu().numpy(), 2.0, cases.LAYOUT_ROOT,
                               acc_dtype=np.float64).reshape(M, -1)
         assert _relmax(outs["split"][0], ref) < 1e-2
+
+
+HL_SHAPES = [(300, 256, 384, 16, 0), (1000, 1024, 520, 8, 1), (77, 64, 128, 3, 0), (5184, 4736, 1024, 16, 0), (4097, 1024, 4736, 4, 1)]
+
+
+@pytest.mark.parametrize("M,fin,fout,rank,layout", HL_SHAPES)
+@pytest.mark.parametrize("saved,packed", [(True, False), (False, True)])
+def test_hi_lo_operands_make_the_bf16_path_fp32_exact(M, fin, fout, rank, layout, saved, packed, monkeypatch):
+    """r <= 16, bf16 activations, fp32 masters that are NOT bf16-representable: outputs are the fp64 oracle (on the same bf16
+    x / gy / base) up to one rounding of the bf16 output; gA / gB (fp32) to 3e-5 -- north_star's "1e-3 on bf16" with two
+    orders of magnitude to spare.  The single-rounded operands (SAM3_LORA_SINGLE_ROUND=1, the previous behaviour) miss the
+    fp32 bound by more than 10x on the same inputs, which is what the hi + lo form is for."""
+    rng = np.random.default_rng(M + rank)
+    x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    gy = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    base = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    gxb = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    A = (rng.uniform(-1, 1, (fin, rank) if layout == 0 else (rank, fin)) / np.sqrt(rank)).astype(np.float32)
+    B = (rng.standard_normal((rank, fout) if layout == 0 else (fout, rank)) * 0.05).astype(np.float32)
+    s = 2.0
+    want_y = base + O.adapter_delta(x, A, B, s, layout, acc_dtype=np.float64)
+    gx_l, gA_w, gB_w = O.adapter_backward(gy, x, A, B, s, layout, acc_dtype=np.float64)
+
+    def run():
+        dA, dB = _t(A), _t(B)
+        blob = Fn.pack_operands(dA, dB, layout) if packed else None
+        y = _t(base, torch.bfloat16)
+        tT = Fn.lora_fwd_(_t(x, torch.bfloat16), dA, dB, y, s, layout, save_t=saved, packed=blob)
+        gx = _t(gxb, torch.bfloat16)
+        gA, gB = torch.zeros_like(dA), torch.zeros_like(dB)
+        Fn.lora_bwd_(_t(gy, torch.bfloat16), _t(x, torch.bfloat16), tT, dA, dB, gx, gA, gB, s, layout, packed=blob)
+        return y.float().cpu().numpy(), gx.float().cpu().numpy(), gA.cpu().numpy(), gB.cpu().numpy()
+
+    y, gx, gA, gB = run()
+    _one_rounding(y, want_y)
+    _one_rounding(gx, gxb + gx_l)
+    assert _relmax(gA, gA_w) < 3e-5 and _relmax(gB, gB_w) < 3e-5, (_relmax(gA, gA_w), _relmax(gB, gB_w))
+    monkeypatch.setenv("SAM3_LORA_SINGLE_ROUND", "1")
+    _reload_knobs()
+    y1, gx1, gA1, gB1 = run()
+    assert 10 * _relmax(gA, gA_w) < _relmax(gA1, gA_w) < 1e-2 and 10 * _relmax(gB, gB_w) < _relmax(gB1, gB_w) < 1e-2
+    assert _relmax(y1, want_y) < 1e-2 and _relmax(gx1, gxb + gx_l) < 1e-2
+
+
+def test_hi_lo_with_dropout_and_fused_gelu():
+    """The same bound through the dropout mask (oracle's specification of the stream) and the activation-fused entry points:
+    a = GELU(bf16(h)) to one rounding, gh = gx * GELU'(h) to one rounding of the product."""
+    rng = np.random.default_rng(3)
+    M, fin, fout, rank, s, p, seed = 777, 264, 520, 16, 2.0, 0.2, 99
+    x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    gy = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    base = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    A = (rng.uniform(-1, 1, (fin, rank)) / 4).astype(np.float32)
+    B = (rng.standard_normal((rank, fout)) * 0.05).astype(np.float32)
+    mask = O.dropout_scale_mask(M, fin, p, seed)
+    want_y = base + O.adapter_delta(x, A, B, s, 0, drop_scale_mask=mask, acc_dtype=np.float64)
+    gx_l, gA_w, gB_w = O.adapter_backward(gy, x, A, B, s, 0, drop_scale_mask=mask, acc_dtype=np.float64)
+    dA, dB = _t(A), _t(B)
+    y = _t(base, torch.bfloat16)
+    act = torch.empty_like(y)
+    tT = Fn.lora_fwd_(_t(x, torch.bfloat16), dA, dB, y, s, 0, save_t=True, drop_p=p, seed=seed, gelu_out=act)
+    _one_rounding(y.float().cpu().numpy(), want_y)
+    yb = y.float()
+    _one_rounding(act.float().cpu().numpy(), torch.nn.functional.gelu(yb.double()).cpu().numpy(), slack=1e-6)
+    gx = torch.zeros(M, fin, device=DEV, dtype=torch.bfloat16)
+    gA, gB = torch.zeros_like(dA), torch.zeros_like(dB)
+    Fn.lora_bwd_(_t(gy, torch.bfloat16), _t(x, torch.bfloat16), tT, dA, dB, gx, gA, gB, s, 0, drop_p=p, seed=seed)
+    _one_rounding(gx.float().cpu().numpy(), gx_l)
+    assert _relmax(gA.cpu().numpy(), gA_w) < 3e-5 and _relmax(gB.cpu().numpy(), gB_w) < 3e-5
+
+
+def test_riding_reduction_is_bit_identical_to_the_separate_launch(monkeypatch):
+    """The fixed-order sum of the gA / gB partials rides on the backward's k_t2 launch; SAM3_LORA_NO_RIDE=1 runs it as its
+    own kernel: same blocks, same order -> the same bits, overwrite and accumulate mode, with and without gx."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M, fin, fout, rank = 2000, 264, 520, 16
+    x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    A = torch.randn(fin, rank, device=DEV, generator=g) / 16
+    B = torch.randn(rank, fout, device=DEV, generator=g) / 16
+    outs = {}
+    for ride in ("1", "0"):
+        if ride == "0":
+            monkeypatch.setenv("SAM3_LORA_NO_RIDE", "1")
+            _reload_knobs()
+        res = []
+        for accumulate in (False, True):
+            gx = torch.ones(M, fin, device=DEV, dtype=torch.bfloat16)
+            gA, gB = torch.full_like(A, 0.5), torch.full_like(B, 0.25)
+            Fn.lora_bwd_(gy, x, None, A, B, gx, gA, gB, 2.0, 0, accumulate=accumulate)
+            res += [gx, gA, gB]
+        outs[ride] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs["1"][1], outs["1"][4])          # accumulate mode really added onto the 0.5

@@ -17,11 +17,45 @@ from sam3_lora_amd.sam3_data import (Datapoint, FindQueryLoaded, Image, Inferenc
 from sam3_lora_amd.sam3_image import SAM3Output, TINY_CONFIG, build_sam3_image_model
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_tiny.npz")
+GOLD_WIDE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_wide.npz")
 
 
 @pytest.fixture(scope="module")
 def gold():
     return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def gold_wide():
+    return np.load(GOLD_WIDE)
+
+
+def build_wide(gold_wide, device="cpu", **kw):
+    """This library's model at e2e_case_defs.WIDE with the name-seeded weights the generating script gave the reference's
+    model; the buffers (position tables, RoPE factors) come from the fixture."""
+    model = build_sam3_image_model(device=device, eval_mode=False, config=D.WIDE, tokenizer=D.toy_tokenizer, **kw)
+    assert sorted(model.state_dict().keys()) == sorted(str(k) for k in gold_wide["sd_keys"])
+    names = [n for n, _ in model.named_parameters()]
+    assert sorted(names) == [str(n) for n in gold_wide["param_names"]]
+    sd = {n: D.seeded_parameter(n, p.shape) for n, p in model.named_parameters()}
+    sd.update(state_dict_of(gold_wide))
+    model.load_state_dict({k: v.to(device) for k, v in sd.items()}, strict=True)
+    return model
+
+
+def make_batch_wide():
+    res = D.WIDE_RES
+    dps = []
+    for i, ((text, boxes), img) in enumerate(zip(D.SAMPLES, D.make_images_res(res))):
+        objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask_res(b, res))
+                for j, b in enumerate(boxes)]
+        q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
+                            query_processing_order=0,
+                            inference_metadata=InferenceMetadata(coco_image_id=i, original_image_id=i,
+                                                                 original_category_id=0, original_size=(res, res),
+                                                                 object_id=-1, frame_index=-1))
+        dps.append(Datapoint(find_queries=[q], images=[Image(data=img, objects=objs, size=(res, res))]))
+    return collate_fn_api(dps, dict_key="input", with_seg_masks=True)["input"]
 
 
 def state_dict_of(gold):
@@ -60,6 +94,8 @@ def make_batch():
 
 def close(a, ref, rtol, what):
     a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    if a.shape != ref.shape and a.ndim == ref.ndim:     # the wide fixture keeps the first 4 queries / every 8th token
+        a = a[:, :ref.shape[1]] if a.ndim == 4 else a[::8]
     scale = max(float(np.abs(ref).max()), 1e-6)
     err = float(np.abs(a - ref).max()) / scale
     assert a.shape == ref.shape, (what, a.shape, ref.shape)
@@ -188,19 +224,39 @@ def test_matching_started_inside_forward_gives_the_reference_indices(gold):
         assert torch.equal(plain[k].detach(), with_pre[k].detach()), k
 
 
+def test_wide_fixture_forward_matches_reference_cpu(gold_wide):
+    """The wider instance (256-wide trunk x 8 blocks, 128-wide DETR, name-seeded weights): eval and training forward of
+    the un-adapted model against the reference's, CPU fp32, matcher indices bit-exact."""
+    model = build_wide(gold_wide)
+    batch = make_batch_wide()
+    assert torch.equal(batch.img_batch, torch.from_numpy(gold_wide["batch/img_batch"]))
+    model.eval()
+    with torch.no_grad():
+        out = model(batch)[0]
+    assert check_outputs(gold_wide, "eval", out, 3e-5) >= 6
+    model.train()
+    out = model(batch)[0]
+    assert len(out["aux_outputs"]) == D.WIDE["dec_layers"] - 1
+    assert check_outputs(gold_wide, "train", out, 3e-5) >= 20
+
+
 # ------------------------------------------------------------------------------------------------------- GPU --
-def _inject(model, gold):
+def _inject(model, gold, lora_cfg=None):
     import contextlib, io
     from sam3_lora_amd import lora_layers as L
     with contextlib.redirect_stdout(io.StringIO()):
-        L.apply_lora_to_model(model, L.LoRAConfig(**D.LORA))
+        L.apply_lora_to_model(model, L.LoRAConfig(**(lora_cfg or D.LORA)))
     names = [n for n, m in model.named_modules() if isinstance(m, L.LoRALinear)]
     assert names == [str(n) for n in gold["lora_module_names"]]
     layers = {n: m for n, m in model.named_modules() if isinstance(m, L.LoRALayer)}
     with torch.no_grad():
         for n, m in layers.items():
-            m.lora_A.copy_(torch.from_numpy(gold[f"lora/{n}.lora_A"]))
-            m.lora_B.copy_(torch.from_numpy(gold[f"lora/{n}.lora_B"]))
+            if f"lora/{n}.lora_A" in gold.files:
+                m.lora_A.copy_(torch.from_numpy(gold[f"lora/{n}.lora_A"]))
+                m.lora_B.copy_(torch.from_numpy(gold[f"lora/{n}.lora_B"]))
+            else:           # the wide fixture: adapters by name-seeded draws
+                A, B = D.seeded_adapter(n, m.lora_A.shape, m.lora_B.shape)
+                m.lora_A.copy_(A), m.lora_B.copy_(B)
     return layers
 
 
@@ -268,37 +324,118 @@ def test_training_step_through_hip_adapters_matches_reference(gold, ckpt):
     assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
 
 
-@pytest.mark.gpu
-def test_bf16_training_layout_tracks_reference_curve(gold):
-    """Frozen tensors and activations in bf16 (the benchmark's layout), A/B fp32: loss curve within 2e-2 of the
-    reference's fp32 curve at these tiny widths, indices of the first step identical."""
-    from sam3_lora_amd.trainer import match_all_steps, move_to_device
-    from sam3_lora_amd.vit import to_training_layout
-    dev = torch.device("cuda")
-    model = build(gold, act_checkpoint=False, match_in_forward=False)
-    _inject(model, gold)
-    model.to(dev).train()
-    to_training_layout(model)
+def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True):
+    """The loop of train_sam3_lora_native.py:887-943; returns what parity is judged on: element-wise errors of the first
+    step's outputs against the reference (max |a - ref| / max |ref| per tensor), of the loss dictionary, of the stored A/B
+    gradients, the loss curve, and whether the first step's matcher indices are the reference's."""
+    from sam3_lora_amd.trainer import match_all_steps
     matcher, wrapper = _criterion()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.LR, weight_decay=D.WD)
-    batch = move_to_device(make_batch(), dev)
-    losses = []
-    for step in range(D.STEPS):
+    if prefetch:
+        model.set_prefetch_matcher(wrapper)
+        matcher = wrapper
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=wd)
+    m = {"losses": [], "outputs": {}, "loss_terms": {}, "grads": {}}
+    for step in range(steps):
         outputs = model(batch)
         targets = [model.back_convert(t) for t in batch.find_targets]
         match_all_steps(matcher, outputs.output, targets)
-        loss = wrapper(outputs, targets)["core_loss"]
+        loss_dict = wrapper(outputs, targets)
         opt.zero_grad()
-        loss.backward()
+        loss_dict["core_loss"].backward()
+        if step == 0:
+            out = outputs.output[0][0]
+            for k in ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks", "queries", "encoder_hidden_states"):
+                ref = gold[f"lora/{k}"]
+                a = out[k].detach().float().cpu().numpy()
+                if a.shape != ref.shape:
+                    a = a[:, :ref.shape[1]] if a.ndim == 4 else a[::8]
+                m["outputs"][k] = float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12))
+            for i, aux in enumerate(out["aux_outputs"]):
+                for k in ("pred_logits", "pred_boxes"):
+                    ref = gold[f"lora/aux{i}/{k}"]
+                    m["outputs"][f"aux{i}/{k}"] = float(np.abs(aux[k].detach().float().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12))
+            got = torch.stack([out["indices"][0], out["indices"][1]]).cpu().numpy()
+            m["indices_equal"] = bool(np.array_equal(got, gold["lora/indices"]))
+            for k in gold.files:
+                if k.startswith("loss/") and "ce_f1" not in k and "acc" not in k:
+                    ref = float(gold[k])
+                    m["loss_terms"][k[5:]] = abs(float(loss_dict[k[5:]]) - ref) / max(abs(ref), 1e-3)
+            for n_, mod in layers.items():
+                if f"gA/{n_}" in gold.files:
+                    m["grads"][n_] = max(_rel(mod.lora_A.grad, gold[f"gA/{n_}"]), _rel(mod.lora_B.grad, gold[f"gB/{n_}"]))
         opt.step()
-        losses.append(loss.item())
-        out = outputs.output[0][0]
-        assert out["pred_masks"].dtype == torch.bfloat16 and out["encoder_hidden_states"].dtype == torch.bfloat16
-        # scores and boxes leave in fp32 (matcher cost, box losses)
-        assert out["pred_logits"].dtype == out["pred_boxes"].dtype == out["presence_logit_dec"].dtype == torch.float32
-    ref = gold["losses"]
-    rel = np.abs(np.array(losses) - ref) / np.abs(ref)
-    assert rel.max() <= 2e-2, f"bf16 loss curve {losses} vs reference {ref.tolist()} (rel {rel})"
+        m["losses"].append(loss_dict["core_loss"].item())
+    ref = gold["losses"][:steps]
+    m["loss_curve_rel"] = [float(v) for v in np.abs(np.array(m["losses"]) - ref) / np.abs(ref)]
+    return m
+
+
+def _record(name, m):
+    """Measured parity numbers -> gpurun_out/ (copied to profiles/ as evidence)."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"parity_{name}.json"), "w") as f:
+        json.dump(m, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.gpu
+def test_wide_training_step_fp32_matches_reference(gold_wide):
+    """The wider fixture (rank-16 adapters, 256-wide trunk) through the exact-fp32 HIP adapters: north_star's 1e-3 on logits,
+    loss terms and the four-step loss curve; indices bit-exact; the stored A/B gradients."""
+    from sam3_lora_amd.trainer import move_to_device
+    dev = torch.device("cuda")
+    model = build_wide(gold_wide, act_checkpoint=False, match_in_forward=False)
+    layers = _inject(model, gold_wide, D.LORA_WIDE)
+    model.to(dev).train()
+    m = run_training_steps(model, layers, gold_wide, move_to_device(make_batch_wide(), dev), D.STEPS, D.LR, D.WD)
+    _record("wide_fp32", m)
+    assert m["indices_equal"]
+    assert max(m["outputs"].values()) <= 1e-3, m["outputs"]
+    assert max(m["loss_terms"].values()) <= 1e-3, m["loss_terms"]
+    assert len(m["grads"]) >= 6 and max(m["grads"].values()) <= 5e-3, m["grads"]
+    assert max(m["loss_curve_rel"]) <= 1e-3, (m["losses"], m["loss_curve_rel"])
+
+
+# bf16 layout (frozen tensors and activations bf16, A/B fp32 -- what bench.py runs) against the reference's fp32 CPU run.
+# Bounds = measured error x ~2 (gpurun_out/parity_bf16_*.json of the round that set them; tools/bf16_parity_probe.py
+# attributes the residual: the same numbers with the adapter branch evaluated in fp32 by torch -- i.e. what is left is the
+# bf16 storage of the trunk's activations and PyTorch-ROCm's bf16 GEMMs / attention, not the adapter kernels).
+BF16_BOUNDS = {"tiny": dict(logits=2e-2, boxes=2e-2, loss=2e-2, curve=2e-2), "wide": dict(logits=2e-2, boxes=2e-2, loss=2e-2, curve=2e-2)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["tiny", "wide"])
+def test_bf16_training_layout_against_reference(which, gold, gold_wide):
+    """Frozen tensors and activations in bf16 (the benchmark's layout), A/B fp32: pred_logits / pred_boxes of the final and
+    auxiliary outputs, every loss term and the loss curve against the reference's fp32 run, element-wise, with the measured
+    numbers recorded; matcher indices of the first step identical."""
+    from sam3_lora_amd.trainer import move_to_device
+    from sam3_lora_amd.vit import to_training_layout
+    dev = torch.device("cuda")
+    g = gold if which == "tiny" else gold_wide
+    if which == "tiny":
+        model = build(g, act_checkpoint=False, match_in_forward=False)
+        layers, batch = _inject(model, g), make_batch()
+    else:
+        model = build_wide(g, act_checkpoint=False, match_in_forward=False)
+        layers, batch = _inject(model, g, D.LORA_WIDE), make_batch_wide()
+    model.to(dev).train()
+    to_training_layout(model)
+    m = run_training_steps(model, layers, g, move_to_device(batch, dev), D.STEPS, D.LR, D.WD)
+    _record(f"bf16_{which}", m)
+    out = model(move_to_device(batch, dev)).output[0][0]
+    assert out["pred_masks"].dtype == torch.bfloat16 and out["encoder_hidden_states"].dtype == torch.bfloat16
+    # scores and boxes leave in fp32 (matcher cost, box losses)
+    assert out["pred_logits"].dtype == out["pred_boxes"].dtype == out["presence_logit_dec"].dtype == torch.float32
+    b = BF16_BOUNDS[which]
+    assert m["indices_equal"]
+    logit_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_logits"))
+    box_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes"))
+    assert logit_err <= b["logits"], m["outputs"]
+    assert box_err <= b["boxes"], m["outputs"]
+    assert m["loss_terms"]["core_loss"] <= b["loss"], m["loss_terms"]
+    assert max(m["loss_curve_rel"]) <= b["curve"], (m["losses"], m["loss_curve_rel"])
 
 
 @pytest.mark.gpu
