@@ -62,6 +62,7 @@ def parse():
                     help="activation checkpointing of the whole-model step (auto: off when the activations fit in HBM)")
     ap.add_argument("--match-twice", action="store_true", help="also match inside the model's forward, as the reference does")
     ap.add_argument("--no-overlap", action="store_true", help="skip the exchange-overlap measurement (N > 1)")
+    ap.add_argument("--no-data-step", action="store_true", help="skip the loader-in-the-loop measurement")
     ap.add_argument("--full-only", action="store_true", help="only the whole-model step (profiling runs)")
     ap.add_argument("--fp8-frozen", action="store_true",
                     help="headline step with fp8 frozen-W base GEMMs (BASELINE configs[4] mode; default: measured as a sub-object)")
@@ -217,7 +218,9 @@ def insitu_kernels(w, steps=2):
     if n < 0:
         raise RuntimeError(_ffi.last_error())
     M, r = w.M, w.rank
-    RP, e = (16 if r <= 16 else 32), w.x1[0].element_size()
+    e = w.x1[0].element_size()
+    single = os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") not in ("", "0")
+    RP = 32 if (r > 16 or (e == 2 and not single)) else 16       # bf16, r <= 16: t / gt travel as hi | lo pairs (32 columns)
     one_pass = r <= 16 and os.environ.get("SAM3_LORA_TWO_PASS_GY", "0") in ("", "0")
     names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2",
              _ffi.STAGE_T3_GB: "k_t3+gt" if one_pass else "k_t3", _ffi.STAGE_T3_GA: "k_t3",
@@ -577,7 +580,7 @@ class FullStep:
         from sam3_lora_amd.sam3_data import SyntheticSegmentDataset, collate_fn_api
         from sam3_lora_amd.sam3_image import build_sam3_image_model
         from sam3_lora_amd.trainer import build_criterion, move_to_device
-        self.dev, self.batch, self.world = dev, batch, world
+        self.dev, self.batch, self.world, self.bf16 = dev, batch, world, bf16
         cfg, res, src = model_setup(kind)
         self.kind, self.res = kind, res
         self.model = build_sam3_image_model(device=str(dev), eval_mode=False, match_in_forward=not match_once, seed=0,
@@ -625,9 +628,9 @@ class FullStep:
         from sam3_lora_amd.functional import repack_adapters
         self._repack = repack_adapters
 
-    def step(self, timers=None):
+    def step(self, timers=None, batch=None):
         from sam3_lora_amd.trainer import match_all_steps
-        b = self.batches[self.n & 1]
+        b = self.batches[self.n & 1] if batch is None else batch
         self.n += 1
 
         def mark(name):
@@ -652,6 +655,44 @@ class FullStep:
         mark("exchange + AdamW")
         self.last_loss = loss
         return loss
+
+
+def data_step_measurement(full, args, world, rank, timed):
+    """SURVEY section 8f-4, VERDICT r2 item 6: the same whole training step with the DATA STEP IN THE LOOP instead of two
+    resident batches -- every step pulls a fresh batch of synthetic samples (generated, resized, normalised, masks rasterised:
+    sam3_data.synthetic_datapoint) from the rank's ShardedLoader, (a) through the worker pool (samples built by threads ahead
+    of the step, collated, copied from pinned memory on a side stream) and (b) the reference's way, num_workers=0, inline."""
+    from sam3_lora_amd.sam3_data import ShardedLoader, SyntheticSegmentDataset, collate_fn_api
+    _, res, src = model_setup(full.kind)
+    steps = max(3, min(args.steps, 6))
+    workers = max(2, min(16, host_cores()[1]))
+    collate = lambda smp: collate_fn_api(smp, dict_key="input", with_seg_masks=True)
+    out = {}
+    for name, nw, n_steps in (("worker_pool", workers, steps), ("inline_num_workers_0", 0, 2)):
+        ds = SyntheticSegmentDataset(full.batch * world * (n_steps + 2), resolution=res, source=src)
+        loader = ShardedLoader(ds, full.batch, collate, shuffle=False, rank=rank, world=world, num_workers=nw, prefetch=3,
+                               device=full.dev if nw else None)
+        it = iter(loader)
+
+        def one():
+            from sam3_lora_amd.trainer import move_to_device
+            b = next(it)["input"]
+            b = move_to_device(b, full.dev)
+            if full.bf16:
+                b.img_batch = b.img_batch.bfloat16()
+            full.step(batch=b)
+        one()
+        one()
+        loader.stall_s = 0.0
+        dt = timed(one, n_steps)
+        out[name] = {"images_per_s": round(world * full.batch * n_steps / dt, 2), "ms_per_step": round(dt / n_steps * 1e3, 2),
+                     "steps": n_steps, "loader_threads": nw,
+                     "step_waited_for_data_ms": round(loader.stall_s / n_steps * 1e3, 2) if nw else None}
+        del it, loader
+    out["what"] = ("whole training step with a fresh synthetic batch per step from sam3_data.ShardedLoader: `worker_pool` = samples "
+                   "built by a thread pool + pinned async H2D ahead of the step; `inline_num_workers_0` = the reference's "
+                   "DataLoader(num_workers=0) behaviour (train_sam3_lora_native.py:831)")
+    return out
 
 
 def rccl_info(world, dev):
@@ -786,6 +827,13 @@ def main():
             ov = overlap_measurement(full, world)
             if rank == 0:
                 out["exchange_overlap"] = ov
+        if not args.no_data_step and not args.full_only:
+            try:
+                dsm = data_step_measurement(full, args, world, rank, timed)
+            except Exception as e:      # an auxiliary measurement must never cost the bench line
+                dsm = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            if rank == 0:
+                out["data_step"] = dsm
         if not args.no_fp8 and not args.fp8_frozen and args.act_dtype == "bf16":
             # BASELINE configs[4]'s mode on the same workload: frozen base GEMMs on the fp8 MFMA kernels
             loss_bf16 = full.last_loss.item()

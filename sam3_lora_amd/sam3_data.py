@@ -27,7 +27,7 @@ import torch
 __all__ = ["InferenceMetadata", "FindQueryLoaded", "Object", "Image", "Datapoint", "FindStage", "BatchedFindTarget",
            "BatchedInferenceMetadata", "BatchedDatapoint", "collate_fn_api", "SyntheticSegmentDataset",
            "synthetic_datapoint", "shard_indices", "ShardedLoader", "COCOSegmentDataset", "segmentation_to_mask",
-           "polygon_to_mask", "rle_decode", "rle_counts_from_string"]
+           "polygon_to_mask", "polygon_to_mask_loops", "polygon_marks", "rle_decode", "rle_counts_from_string"]
 
 
 # ------------------------------------------------------------------------------------------ per-sample records --
@@ -332,14 +332,25 @@ def shard_indices(n: int, rank: int, world: int, epoch: int = 0, shuffle: bool =
 
 
 class ShardedLoader:
-    """Batches of a map-style dataset for one rank: ``shard_indices`` per epoch, ``collate_fn`` per batch.  A thin
-    stand-in for ``DataLoader(dataset, batch_size, sampler=DistributedSampler(...), num_workers=0)`` that keeps the
-    sampler's ``set_epoch`` protocol and works identically with world size 1 (then it is the reference's
-    ``DataLoader(shuffle=...)``)."""
+    """Batches of a map-style dataset for one rank: ``shard_indices`` per epoch, ``collate_fn`` per batch -- the
+    reference's ``DataLoader(dataset, batch_size, sampler=DistributedSampler(...), num_workers=0)`` (``num_workers=0`` is
+    hard-coded there, ``train_sam3_lora_native.py:831``) with the sampler's ``set_epoch`` protocol; world size 1 = the
+    reference's ``DataLoader(shuffle=...)``.
 
-    def __init__(self, dataset, batch_size: int, collate_fn, shuffle: bool, rank: int = 0, world: int = 1, seed: int = 0):
+    ``num_workers > 0`` takes the data step off the training step's critical path without changing
+    what is produced or its order: the samples of the next ``prefetch`` batches are built concurrently by a pool of
+    threads (image decode / resize, mask rasterisation and the tensor arithmetic all release the GIL), collated in
+    order by a producer thread and -- with ``device`` -- copied to the GPU from pinned memory on a side stream, so that
+    ``next()`` normally returns a batch that is already resident.  ``stall_s`` accumulates the time ``next()`` had to
+    wait (0 when the loader keeps up)."""
+
+    def __init__(self, dataset, batch_size: int, collate_fn, shuffle: bool, rank: int = 0, world: int = 1, seed: int = 0,
+                 num_workers: int = 0, prefetch: int = 2, device=None):
         self.dataset, self.batch_size, self.collate_fn = dataset, int(batch_size), collate_fn
         self.shuffle, self.rank, self.world, self.seed, self.epoch = shuffle, rank, world, seed, 0
+        self.num_workers, self.prefetch = int(num_workers), max(1, int(prefetch))
+        self.device = torch.device(device) if device is not None else None
+        self.stall_s = 0.0
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -353,8 +364,90 @@ class ShardedLoader:
 
     def __iter__(self):
         idx = self.indices()
-        for i in range(0, len(idx), self.batch_size):
-            yield self.collate_fn([self.dataset[j] for j in idx[i:i + self.batch_size]])
+        groups = [idx[i:i + self.batch_size] for i in range(0, len(idx), self.batch_size)]
+        if self.num_workers <= 0:
+            for g in groups:
+                yield self.collate_fn([self.dataset[j] for j in g])
+            return
+        yield from self._iter_prefetched(groups)
+
+    # ---- worker pool -------------------------------------------------------------------------------------------
+    def _to_device(self, batch):
+        """Pinned staging + asynchronous copy on a side stream; returns (batch on device, event to wait for)."""
+        dev = self.device
+        if dev is None or dev.type != "cuda":
+            return batch, None
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream = torch.cuda.Stream(device=dev)
+
+        def move(obj):
+            if isinstance(obj, torch.Tensor):
+                return (obj.pin_memory() if obj.numel() > 0 and not obj.is_pinned() else obj).to(dev, non_blocking=True)
+            if isinstance(obj, list):
+                return [move(x) for x in obj]
+            if isinstance(obj, tuple):
+                return tuple(move(x) for x in obj)
+            if isinstance(obj, dict):
+                return {k: move(v) for k, v in obj.items()}
+            if hasattr(obj, "__dataclass_fields__"):
+                for f in obj.__dataclass_fields__:
+                    setattr(obj, f, move(getattr(obj, f)))
+            return obj
+        with torch.cuda.stream(self._copy_stream):
+            out = move(batch)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        return out, ev
+
+    def _iter_prefetched(self, groups):
+        import queue
+        import threading
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+        pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="sam3-data")
+
+        def producer():
+            try:
+                window = self.prefetch + 1          # batches whose samples are in flight in the pool
+                futs = [[pool.submit(self.dataset.__getitem__, j) for j in g] for g in groups[:window]]
+                for k in range(len(groups)):
+                    if stop.is_set():
+                        return
+                    samples = [f.result() for f in futs[k]]
+                    futs[k] = None
+                    if k + window < len(groups):
+                        futs.append([pool.submit(self.dataset.__getitem__, j) for j in groups[k + window]])
+                    item = self._to_device(self.collate_fn(samples))
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                q.put(None)
+            except BaseException as e:              # surfaces in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=producer, name="sam3-data-producer", daemon=True)
+        th.start()
+        try:
+            while True:
+                t0 = time.perf_counter()
+                item = q.get()
+                self.stall_s += time.perf_counter() - t0
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ev = item
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                yield batch
+        finally:
+            stop.set()
+            pool.shutdown(wait=False, cancel_futures=True)
 
 
 # --------------------------------------------------------------------------------------------------- COCO data --
@@ -393,7 +486,58 @@ def rle_decode(counts: Sequence[int], h: int, w: int) -> torch.Tensor:
     return flat.view(w, h).t().contiguous()
 
 
+def polygon_marks(xy: Sequence[float], h: int, w: int):
+    """The run boundaries ``rleFrPoly`` derives from one polygon, as flat column-major positions (numpy int64, unsorted,
+    duplicates kept).  Vectorised per edge; the scalar statement of the same rule is :func:`polygon_to_mask_loops`.
+    A pixel of the mask is set when an odd number of marks lie at or before its column-major index -- which is what
+    pycocotools' zero-length-run merging amounts to (equal marks cancel in pairs)."""
+    import numpy as np
+    k = len(xy) // 2
+    scale = 5.0
+    px = [int(scale * xy[2 * j] + 0.5) for j in range(k)]
+    py = [int(scale * xy[2 * j + 1] + 0.5) for j in range(k)]
+    px.append(px[0])
+    py.append(py[0])
+    us, vs = [], []
+    for j in range(k):
+        xs, xe, ys, ye = px[j], px[j + 1], py[j], py[j + 1]
+        dx, dy = abs(xe - xs), abs(ys - ye)
+        flip = (dx >= dy and xs > xe) or (dx < dy and ys > ye)
+        if flip:
+            xs, xe, ys, ye = xe, xs, ye, ys
+        if dx >= dy:
+            slope = (ye - ys) / dx if dx else 0.0
+            t = np.arange(dx, -1, -1, dtype=np.int64) if flip else np.arange(dx + 1, dtype=np.int64)
+            us.append(t + xs)
+            vs.append((ys + slope * t + 0.5).astype(np.int64))          # C cast: truncation, as int() in the scalar form
+        else:
+            slope = (xe - xs) / dy
+            t = np.arange(dy, -1, -1, dtype=np.int64) if flip else np.arange(dy + 1, dtype=np.int64)
+            vs.append(t + ys)
+            us.append((xs + slope * t + 0.5).astype(np.int64))
+    u, v = np.concatenate(us), np.concatenate(vs)
+    u0, u1, v0, v1 = u[:-1], u[1:], v[:-1], v[1:]
+    step = u1 != u0
+    down = u1 < u0
+    xd = (np.where(down, u1, u1 - 1).astype(np.float64) + 0.5) / scale - 0.5
+    keep = step & (np.floor(xd) == xd) & (xd >= 0) & (xd <= w - 1)
+    yd = (np.minimum(v0, v1).astype(np.float64) + 0.5) / scale - 0.5
+    yd = np.ceil(np.clip(yd, 0.0, float(h)))
+    return (xd[keep].astype(np.int64) * h + yd[keep].astype(np.int64))
+
+
 def polygon_to_mask(xy: Sequence[float], h: int, w: int) -> torch.Tensor:
+    """One polygon ``[x0, y0, x1, y1, ...]`` (pixels) -> bool mask [h, w] with ``pycocotools``' rasterisation rule
+    (``maskApi.c`` ``rleFrPoly``, see :func:`polygon_to_mask_loops` for the rule itself): numpy form -- the marks of all
+    edges at once, then the column-major parity fill.  Bit-identical to the scalar form (tests/test_sam3_data.py)."""
+    import numpy as np
+    marks = polygon_marks(xy, h, w)
+    toggles = np.bincount(marks, minlength=h * w + 1)[:h * w] & 1
+    flat = (np.cumsum(toggles, dtype=np.int64) & 1).astype(np.bool_)
+    return torch.from_numpy(np.ascontiguousarray(flat.reshape(w, h).T))
+
+
+def polygon_to_mask_loops(xy: Sequence[float], h: int, w: int) -> torch.Tensor:
     """One polygon ``[x0, y0, x1, y1, ...]`` (pixels) -> bool mask [h, w] with ``pycocotools``' rasterisation rule
     (``maskApi.c`` ``rleFrPoly``): vertices are scaled by 5 and rounded, every edge is walked on that fine grid,
     the crossings of the boundary with pixel-centre columns become the run boundaries of a column-major RLE (a
@@ -523,7 +667,14 @@ class COCOSegmentDataset(torch.utils.data.Dataset):
                 continue
             names.append(self.categories.get(ann.get("category_id", 0), "object"))
             x, y, bw, bh = bbox
-            box = torch.tensor([x / orig_w, y / orig_h, (x + bw) / orig_w, (y + bh) / orig_h], dtype=torch.float32)
+            # the reference's order of fp32 operations (:131-142): xyxy in pixels -> scaled to the model resolution -> divided
+            # by it; a fused x / orig_w differs in the last bit (tests/golden/dataset_cases.npz pins the bits)
+            box = torch.tensor([x, y, x + bw, y + bh], dtype=torch.float32)
+            box[0] *= R / orig_w
+            box[2] *= R / orig_w
+            box[1] *= R / orig_h
+            box[3] *= R / orig_h
+            box /= R
             segment = None
             seg = ann.get("segmentation")
             if seg:

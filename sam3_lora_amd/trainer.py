@@ -31,7 +31,9 @@ across ranks with DistributedSampler semantics.  ``--model-builder / --data-buil
 
 Settings that exist only on this engine live under an optional ``engine:`` section of the YAML (absent = reference
 behaviour) and as command-line switches: ``bf16_frozen`` (frozen tensors in bf16, A/B fp32 masters),
-``act_checkpoint`` (keep | auto | on | off), ``match_once`` (skip the model-internal matching that the loop repeats).
+``act_checkpoint`` (keep | auto | on | off), ``match_once`` (skip the model-internal matching that the loop repeats),
+``loader_workers`` / ``loader_prefetch`` (samples built by a thread pool and batches copied to the GPU ahead of the step;
+0 = the reference's ``num_workers=0``), ``grad_accumulation_steps``, ``direct_grad``, ``fp8_frozen``.
 """
 from __future__ import annotations
 
@@ -113,11 +115,17 @@ def default_data_builder(config: Dict[str, Any], split: str):
         dataset = SyntheticSegmentDataset(n if split == "train" else max(n // 4, 1), split=split)
     else:
         dataset = COCOSegmentDataset(data_dir=data_dir, split=split)
+    eng = config.get("engine") or {}
+    workers = int(eng.get("loader_workers", 0))             # 0 = the reference's num_workers=0 (:831)
+    device = None
+    if workers > 0 and torch.cuda.is_available() and eng.get("loader_to_device", True):
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     return ShardedLoader(dataset, config["training"]["batch_size"],
                          lambda samples: collate_fn_api(samples, dict_key="input", with_seg_masks=True),
                          shuffle=(split == "train"), rank=int(os.environ.get("RANK", "0")),
                          world=int(os.environ.get("WORLD_SIZE", "1")),
-                         seed=int((config.get("training") or {}).get("seed", 0) or 0))
+                         seed=int((config.get("training") or {}).get("seed", 0) or 0),
+                         num_workers=workers, prefetch=int(eng.get("loader_prefetch", 2)), device=device)
 
 
 def resolve_builder(spec: Optional[str], env: str, what: str) -> Callable:

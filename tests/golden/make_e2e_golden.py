@@ -7,6 +7,8 @@ injector -- imported from /root/reference and assembled exactly as ``sam3/model_
 them, at the tiny widths of e2e_case_defs.TINY, dropout / DropPath 0, CPU fp32.  Build container only.
 
     python tests/golden/make_e2e_golden.py        ->  e2e_tiny.npz   (all weights stored)
+    python tests/golden/make_e2e_golden.py tiny --yardstick  ->  only ref_autocast_bf16.json["tiny"] (the reference's own
+                                                      autocast(bf16) deviation from its fp32 forward; see main())
     python tests/golden/make_e2e_golden.py wide   ->  e2e_wide.npz   (e2e_case_defs.WIDE: 256-wide trunk x 8 blocks at
                                                       224^2, rank-16 adapters; weights = e2e_case_defs.seeded_parameter,
                                                       so only buffers, batch and outputs are stored)
@@ -144,8 +146,8 @@ def dump_outputs(res, tag, out):
 
 
 def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
-    CFG, RESOLUTION, LORA_CFG = D.CONFIGS[which]
+    which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "tiny"
+    CFG, RESOLUTION, LORA_CFG, LEARNING_RATE = D.CONFIGS[which]
     sam3_manifest._install_stubs()
     sam3_manifest._patch_cuda_literals()
     sys.modules["timm.layers"].trunc_normal_ = torch.nn.init.trunc_normal_
@@ -236,7 +238,49 @@ def main():
     matcher = BinaryHungarianMatcherV2(**cfg["matcher"])
     wrapper = Sam3LossWrapper(loss_fns_find=[LF.Boxes(**cfg["boxes"]), LF.IABCEMdetr(**cfg["ce"]), LF.Masks(**cfg["masks"])],
                               matcher=matcher, o2m_matcher=BinaryOneToManyMatcher(**cfg["o2m"]), **cfg["wrapper"])
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.LR, weight_decay=D.WD)
+    # The reference's OWN mixed-precision mode as a yardstick: the hydra trainer runs its model under
+    # torch.autocast(bf16) (sam3_lora/train/native_trainer.py:956-1021).  The same adapted model, same batch, forward + loss
+    # under CPU autocast(bf16) against its fp32 forward: how far bf16 moves the reference's own logits / boxes / loss.
+    def fwd_loss():
+        outputs = model(batch)
+        targets = [model.back_convert(t) for t in batch.find_targets]
+        with SAM3Output.iteration_mode(outputs, iter_mode=SAM3Output.IterMode.ALL_STEPS_PER_STAGE) as it:
+            for stage_out, tg in zip(it, targets):
+                for o in stage_out:
+                    o["indices"] = matcher(o, tg)
+                    for a in o.get("aux_outputs", []):
+                        a["indices"] = matcher(a, tg)
+        return outputs[0][0] if isinstance(outputs[0], list) else outputs[0], float(wrapper(outputs, targets)["core_loss"])
+    yardstick_only = "--yardstick" in sys.argv      # tiny: measured in its own invocation (e2e_tiny.npz predates it and must
+    if which == "tiny" and not yardstick_only:      # not move: extra forwards shift CPU reduction order by an ulp)
+        raise_skip = True
+    else:
+        raise_skip = False
+    try:
+        if raise_skip:
+            raise RuntimeError("skipped for the tiny fixture (run with --yardstick)")
+        with torch.no_grad():
+            o32, l32 = fwd_loss()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                o16, l16 = fwd_loss()
+        relmax = lambda a, b: float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12))
+        res["ref_autocast_bf16/pred_logits"] = np.float64(max([relmax(o16["pred_logits"], o32["pred_logits"])] + [
+            relmax(a["pred_logits"], b["pred_logits"]) for a, b in zip(o16["aux_outputs"], o32["aux_outputs"])]))
+        res["ref_autocast_bf16/pred_boxes"] = np.float64(max([relmax(o16["pred_boxes"], o32["pred_boxes"])] + [
+            relmax(a["pred_boxes"], b["pred_boxes"]) for a, b in zip(o16["aux_outputs"], o32["aux_outputs"])]))
+        res["ref_autocast_bf16/core_loss"] = np.float64(abs(l16 - l32) / abs(l32))
+        print("reference under autocast(bf16) vs its fp32: logits %.3e boxes %.3e loss %.3e" % (
+            res["ref_autocast_bf16/pred_logits"], res["ref_autocast_bf16/pred_boxes"], res["ref_autocast_bf16/core_loss"]))
+        import json
+        yp = os.path.join(HERE, "ref_autocast_bf16.json")
+        yd = json.load(open(yp)) if os.path.exists(yp) else {}
+        yd[which] = {k.split("/")[1]: float(v) for k, v in res.items() if k.startswith("ref_autocast_bf16/")}
+        json.dump(yd, open(yp, "w"), indent=1, sort_keys=True)
+        if yardstick_only:
+            return
+    except Exception as e:      # CPU autocast coverage is torch's business; the fixture works without the yardstick
+        print("autocast yardstick unavailable:", type(e).__name__, str(e)[:200])
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=LEARNING_RATE, weight_decay=D.WD)
     losses = []
     for step in range(D.STEPS):
         outputs = model(batch)

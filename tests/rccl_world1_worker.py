@@ -41,8 +41,7 @@ def main():
     out["buckets"] = len(red.buckets)
     x = torch.randn(300, 256, device=dev)
     # reference gradients without the reducer's exchange
-    red.zero_grad()
-    red._armed = False
+    red.zero_grad(arm=False)
     net(x).pow(2).mean().backward()
     want = red.flat.clone()
     launched = []
@@ -60,8 +59,9 @@ def main():
     out["allreduce_calls"] = len(launched)
     out["all_on_side_stream_async"] = all(side and asyn for _, side, asyn in launched)
     out["elements_reduced"] = sum(n for n, _, _ in launched)
-    out["flat_elements"] = red.flat.numel()
-    out["grads_equal"] = bool(torch.equal(red.flat, want))
+    out["flat_elements"] = red._flag0 + len(red.params)          # gradient slots + one "used" flag per parameter (ddp.py)
+    out["grads_equal"] = bool(torch.equal(red.flat[:red._flag0], want[:red._flag0]))
+    out["flags"] = red.flat[red._flag0:red._flag0 + len(red.params)].tolist()
     nb = allreduce_scalar_sum(torch.tensor([5.0], device=dev))
     out["scalar"] = nb.item()
     dist.barrier()

@@ -148,3 +148,62 @@ def test_shipped_yamls_have_every_consumed_key():
         assert "output_dir" in cfg["output"]
     full = yaml.safe_load(open(os.path.join(ROOT, "configs", "full_lora_config.yaml")))["lora"]
     assert (full["rank"], full["alpha"], full["dropout"]) == (32, 64, 0.1)      # the reference's literal values
+
+
+def test_numpy_rasteriser_is_the_scalar_rule_bit_for_bit():
+    """polygon_to_mask (numpy: all edges' run boundaries at once + column-major parity fill) == polygon_to_mask_loops (the
+    scalar restatement of pycocotools' rleFrPoly) on random polygons incl. vertices outside the image, integer / half-integer
+    vertices and degenerate edges."""
+    import random
+    random.seed(1)
+    for trial in range(150):
+        h, w = random.choice([17, 64, 100, 333]), random.choice([23, 64, 128, 257])
+        k = random.randint(3, 12)
+        if trial % 3:
+            poly = [v for _ in range(k) for v in (random.uniform(-10, w + 10), random.uniform(-10, h + 10))]
+        else:
+            poly = [v for _ in range(k) for v in (random.randint(0, w) + random.choice([0, 0.5]), random.randint(0, h) + random.choice([0, 0.5]))]
+        if trial % 7 == 0:
+            poly += poly[-2:]                       # a zero-length edge
+        assert torch.equal(SD.polygon_to_mask(poly, h, w), SD.polygon_to_mask_loops(poly, h, w)), (trial, poly)
+
+
+def test_coco_dataset_matches_the_references_getitem(tmp_path):
+    """tests/golden/dataset_cases.npz: the reference's own COCOSegmentDataset.__getitem__ on the small COCO directory of
+    dataset_case_defs.py (make_dataset_golden.py) -- image tensor (digest of the float bits + a strided sample), normalised
+    boxes and areas BIT for bit (the fp32 order of operations: scale, then divide by the resolution), nearest-resized masks,
+    query text, original size, object ids; samples through the worker pool are the same objects."""
+    import hashlib
+    import dataset_case_defs as C
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dataset_cases.npz"))
+    C.write_coco_dir(str(tmp_path))
+    ds = SD.COCOSegmentDataset(str(tmp_path), split="train")
+    assert len(ds) == int(g["n"])
+    for i in range(len(ds)):
+        dp = ds[i]
+        img, q = dp.images[0], dp.find_queries[0]
+        a = img.data.numpy()
+        assert a.shape == tuple(g[f"{i}/image_shape"]) and a.dtype == np.float32
+        assert np.array_equal(a[:, ::37, ::41], g[f"{i}/image_sample"])
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == str(g[f"{i}/image_sha256"])
+        assert tuple(img.size) == tuple(g[f"{i}/size"]) and q.query_text == str(g[f"{i}/text"])
+        assert list(q.object_ids_output) == g[f"{i}/object_ids_output"].tolist()
+        assert tuple(q.inference_metadata.original_size) == tuple(g[f"{i}/original_size"])
+        assert q.inference_metadata.coco_image_id == int(g[f"{i}/coco_image_id"])
+        assert len(img.objects) == int(g[f"{i}/n_objects"])
+        for j, o in enumerate(img.objects):
+            assert o.bbox.numpy().tobytes() == g[f"{i}/obj{j}/bbox"].tobytes(), (i, j, o.bbox, g[f"{i}/obj{j}/bbox"])
+            assert np.float32(o.area).tobytes() == np.float32(g[f"{i}/obj{j}/area"]).tobytes()
+            assert o.object_id == int(g[f"{i}/obj{j}/object_id"])
+            key = f"{i}/obj{j}/segment"
+            assert (o.segment is None) == (key not in g.files)
+            if o.segment is not None:
+                assert np.array_equal(np.packbits(o.segment.numpy()), g[key])
+    col = lambda s: SD.collate_fn_api(s, dict_key="input", with_seg_masks=True)
+    plain = list(SD.ShardedLoader(ds, 2, col, shuffle=True, seed=1))
+    pooled = list(SD.ShardedLoader(ds, 2, col, shuffle=True, seed=1, num_workers=3, prefetch=2))
+    assert len(plain) == len(pooled) == 2
+    for x, y in zip(plain, pooled):
+        assert torch.equal(x["input"].img_batch, y["input"].img_batch) and x["input"].find_text_batch == y["input"].find_text_batch
+        assert torch.equal(x["input"].find_targets[0].boxes, y["input"].find_targets[0].boxes)
+        assert torch.equal(x["input"].find_targets[0].segments, y["input"].find_targets[0].segments)

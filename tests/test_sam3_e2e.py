@@ -388,7 +388,7 @@ def test_wide_training_step_fp32_matches_reference(gold_wide):
     model = build_wide(gold_wide, act_checkpoint=False, match_in_forward=False)
     layers = _inject(model, gold_wide, D.LORA_WIDE)
     model.to(dev).train()
-    m = run_training_steps(model, layers, gold_wide, move_to_device(make_batch_wide(), dev), D.STEPS, D.LR, D.WD)
+    m = run_training_steps(model, layers, gold_wide, move_to_device(make_batch_wide(), dev), D.STEPS, D.LR_WIDE, D.WD)
     _record("wide_fp32", m)
     assert m["indices_equal"]
     assert max(m["outputs"].values()) <= 1e-3, m["outputs"]
@@ -398,10 +398,17 @@ def test_wide_training_step_fp32_matches_reference(gold_wide):
 
 
 # bf16 layout (frozen tensors and activations bf16, A/B fp32 -- what bench.py runs) against the reference's fp32 CPU run.
-# Bounds = measured error x ~2 (gpurun_out/parity_bf16_*.json of the round that set them; tools/bf16_parity_probe.py
-# attributes the residual: the same numbers with the adapter branch evaluated in fp32 by torch -- i.e. what is left is the
-# bf16 storage of the trunk's activations and PyTorch-ROCm's bf16 GEMMs / attention, not the adapter kernels).
-BF16_BOUNDS = {"tiny": dict(logits=2e-2, boxes=2e-2, loss=2e-2, curve=2e-2), "wide": dict(logits=2e-2, boxes=2e-2, loss=2e-2, curve=2e-2)}
+# Measured on MI355X (profiles/r03_parity_bf16_*.json): pred_logits 1.6e-2 / 1.5e-2 (tiny / wide), pred_boxes 1.1e-3 / 1.2e-2,
+# core_loss 1.0e-3 / 7e-3.  tools/bf16_parity_probe.py attributes it (profiles/r03_bf16_parity_probe.json): the SAME numbers come
+# out with the adapter branch evaluated by torch in fp32 on the same bf16 activations (1.5e-2 / 1.6e-2 on the logits) and with
+# round 2's single-rounded kernels -- the residual is the bf16 storage of the trunk's activations and PyTorch-ROCm's bf16 GEMMs /
+# attention, not the adapter path (whose own error is bounded at the kernel level: one rounding of the bf16 output,
+# test_gpu_parity.py::test_hi_lo_*).  Yardstick: the reference's own mixed-precision mode -- its model under
+# torch.autocast(bf16) against its fp32 forward (tests/golden/ref_autocast_bf16.json, written by make_e2e_golden.py) -- moves its
+# own logits by 8.8e-3 / 1.8e-2, boxes by 8e-4 / 8e-3, loss by 1.4e-4 / 4.4e-2.  north_star's 1e-3 on the logits is met by the
+# fp32 layout (measured 8e-7, test_wide_training_step_fp32_matches_reference); in a bf16-activation layout no adapter
+# implementation can meet it.  Bounds below = measured x 2.
+BF16_BOUNDS = {"tiny": dict(logits=3e-2, boxes=3e-3, loss=3e-3, curve=3e-3), "wide": dict(logits=3e-2, boxes=2.5e-2, loss=1.5e-2, curve=1.5e-2)}
 
 
 @pytest.mark.gpu
@@ -422,7 +429,10 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
         layers, batch = _inject(model, g, D.LORA_WIDE), make_batch_wide()
     model.to(dev).train()
     to_training_layout(model)
-    m = run_training_steps(model, layers, g, move_to_device(batch, dev), D.STEPS, D.LR, D.WD)
+    m = run_training_steps(model, layers, g, move_to_device(batch, dev), D.STEPS, D.CONFIGS[which][3], D.WD)
+    import json
+    yard = json.load(open(os.path.join(os.path.dirname(GOLD), "ref_autocast_bf16.json")))[which]
+    m["reference_autocast_bf16_vs_its_fp32"] = yard
     _record(f"bf16_{which}", m)
     out = model(move_to_device(batch, dev)).output[0][0]
     assert out["pred_masks"].dtype == torch.bfloat16 and out["encoder_hidden_states"].dtype == torch.bfloat16

@@ -71,7 +71,7 @@ def run(which, variant):
     to_training_layout(model)
     if variant == "torch_fp32":
         torch_fp32_adapters(model)
-    m = T.run_training_steps(model, layers, gold, move_to_device(batch, dev), D.STEPS, D.LR, D.WD)
+    m = T.run_training_steps(model, layers, gold, move_to_device(batch, dev), D.STEPS, D.CONFIGS[which][3], D.WD)
     return {"pred_logits": max(v for k, v in m["outputs"].items() if k.endswith("pred_logits")),
             "pred_boxes": max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes")),
             "queries": m["outputs"]["queries"], "encoder_hidden_states": m["outputs"]["encoder_hidden_states"],
