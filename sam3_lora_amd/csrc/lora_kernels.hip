@@ -549,7 +549,7 @@ struct YTile<float> {
 
 // HL (RT == 2): W2t = [hi | lo] of the LoRA operand, T = [hi | lo] of t: delta = hi.t_hi + hi.t_lo + lo.t_hi.
 template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false>
-__global__ __launch_bounds__(256, (HL && ACT != 2 && !DROP) ? 4 : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
+__global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
                                             ReduceRide ride) {
@@ -599,13 +599,15 @@ __global__ __launch_bounds__(256, (HL && ACT != 2 && !DROP) ? 4 : 1) void k_t2(Y
                 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wlo[ct]),
                                                              __builtin_bit_cast(s16x4, tlo), d, 0, 0, 0);
             } else if (HL) {
-                // K = 32: (w_hi, w_lo) . (t_hi, t_hi), then K = 16: w_hi . t_lo   (lo.lo is below fp32 resolution).  The K = 32
-                // A-operand is the rank-32 kernel's register quad and w_hi its first half: no extra operand registers, and
-                // two MFMAs per column tile instead of three (each costs its 8 passes whatever K is; the wave sits on them)
+                // (w_hi, w_lo) . (t_hi, t_hi)  +  (w_hi, w_lo) . (t_lo, 0)  =  w_hi t_hi + w_lo t_hi + w_hi t_lo   (lo.lo is below
+                // fp32 resolution).  Both are the K = 32 form on the SAME A-operand quad (the rank-32 kernel's registers: no extra
+                // operand registers).  A K = 16 MFMA for the third product measured WRONG results on MI355X when it followed
+                // the K = 32 one on the same accumulator (hipcc 7.2 emits the pair back to back: profiles/r03b notes) -- one opcode only.
                 const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
                 const uint4 tb = make_uint4(tlo.x, tlo.y, tlo.x, tlo.y);
+                const uint4 tc = make_uint4(thi.x, thi.y, 0u, 0u);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, tb), d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wlo[ct]), __builtin_bit_cast(s16x4, thi), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, tc), d, 0, 0, 0);
             } else {
                 const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
                 const uint4 tb = make_uint4(tlo.x, tlo.y, thi.x, thi.y);
