@@ -38,7 +38,6 @@ LOSS_EXPORTS = ("sam3_loss_last_error", "sam3_mask_loss_workspace_bytes", "sam3_
 FP8_EXPORTS = ("sam3_fp8_last_error", "sam3_fp8_quantize")                 # include/sam3_fp8_amd.h
 SEG_EXPORTS = ("sam3_seg_last_error", "sam3_gn_nhwc_supported", "sam3_gn_nhwc_workspace_bytes", "sam3_gn_nhwc_fwd",
                "sam3_gn_nhwc_bwd", "sam3_rpb_bias_fwd")                                             # include/sam3_seg_amd.h
-ATTN_EXPORTS = ("sam3_attn_fwd",)                                        # include/sam3_attn_amd.h
 FP8_E4M3, FP8_E5M2 = 0, 1
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
@@ -144,9 +143,6 @@ def _declare(lib):
                                      c_void_p]
     lib.sam3_rpb_bias_fwd.restype = c_int
     lib.sam3_rpb_bias_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]
-    lib.sam3_attn_fwd.restype = c_int
-    lib.sam3_attn_fwd.argtypes = [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, c_int,
-                                  c_void_p]
     lib.sam3_lora_merge.restype = c_int
     lib.sam3_lora_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p]
@@ -180,7 +176,7 @@ def load(path: str | None = None):
             lib = ctypes.CDLL(p)
         except OSError as e:  # missing libamdhip64 etc.
             raise LoRAKernelError(f"sam3_lora_amd: cannot load {p}: {e}") from e
-        missing = [s for s in EXPORTS + VIT_EXPORTS + LOSS_EXPORTS + FP8_EXPORTS + SEG_EXPORTS + ATTN_EXPORTS if not hasattr(lib, s)]
+        missing = [s for s in EXPORTS + VIT_EXPORTS + LOSS_EXPORTS + FP8_EXPORTS + SEG_EXPORTS if not hasattr(lib, s)]
         if missing:
             raise LoRAKernelError(f"sam3_lora_amd: {p} lacks symbols {missing}")
         _declare(lib)

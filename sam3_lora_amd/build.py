@@ -9,8 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 SRC = os.path.join(PKG_DIR, "csrc", "lora_kernels.hip")
 SRCS = [SRC, os.path.join(PKG_DIR, "csrc", "vit_kernels.hip"), os.path.join(PKG_DIR, "csrc", "loss_kernels.hip"),
-        os.path.join(PKG_DIR, "csrc", "fp8_kernels.hip"), os.path.join(PKG_DIR, "csrc", "seg_kernels.hip"),
-        os.path.join(PKG_DIR, "csrc", "attn_kernels.hip")]
+        os.path.join(PKG_DIR, "csrc", "fp8_kernels.hip"), os.path.join(PKG_DIR, "csrc", "seg_kernels.hip")]
 INCLUDE = os.path.join(REPO_DIR, "include")
 LIB_NAME = "libsam3_lora_amd.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
@@ -29,7 +28,6 @@ def needs_build() -> bool:
     t = os.path.getmtime(LIB_PATH)
     deps = SRCS + [os.path.join(INCLUDE, "sam3_lora_amd.h"), os.path.join(INCLUDE, "sam3_vit_amd.h"),
                    os.path.join(INCLUDE, "sam3_loss_amd.h"), os.path.join(INCLUDE, "sam3_fp8_amd.h"), os.path.join(INCLUDE, "sam3_seg_amd.h"),
-                   os.path.join(INCLUDE, "sam3_attn_amd.h"),
                    os.path.join(PKG_DIR, "csrc", "lora_f32_kernels.inc")]
     return any(os.path.getmtime(d) > t for d in deps)
 

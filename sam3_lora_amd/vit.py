@@ -156,8 +156,8 @@ class Attention(nn.Module):
         cos, sin = self._cos_sin(qkv.device)
         q, k, v = _QKVRope.apply(qkv.reshape(B * H * W, 3 * C), cos, sin, B * nW, L, self.num_heads, self.head_dim,
                                  (ws, H, W))
-        o = _attention(q, k, v)
-        return self._lin(self.proj, o.reshape(B * nW, ws, ws, C), self._wt_proj)
+        o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+        return self._lin(self.proj, o.transpose(1, 2).reshape(B * nW, ws, ws, C), self._wt_proj)
 
     @staticmethod
     def _lin(mod: nn.Module, x: torch.Tensor, cache) -> torch.Tensor:
@@ -176,7 +176,8 @@ class Attention(nn.Module):
             # transposed VIEWS (no permute copies) and its output reshapes to [B, H, W, C] for free
             cos, sin = self._cos_sin(qkv.device)
             q, k, v = _QKVRope.apply(qkv.reshape(B * L, 3 * C), cos, sin, B, L, self.num_heads, self.head_dim)
-            o = _attention(q, k, v).reshape(B, H, W, C)
+            o = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+            o = o.transpose(1, 2).reshape(B, H, W, C)
         else:   # plain PyTorch formulation (CPU / other dtypes); same mathematics
             qkv = qkv.reshape(B, L, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
             q, k, v = qkv.unbind(0)
@@ -201,96 +202,6 @@ def _sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         _SDPA_ORDER = [SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH]
     with sdpa_kernel(_SDPA_ORDER, set_priority=True):
         return F.scaled_dot_product_attention(q, k, v)
-
-
-def _attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """softmax(q k^T / sqrt(d)) v for token-major q, k, v [B, L, heads, d] -> [B, L, heads, d].  bf16 with d = 64 on the
-    GPU (the trunk's shapes): this library's forward kernel (csrc/attn_kernels.hip) + PyTorch-ROCm's attention backward on
-    its output and log-sum-exp; everything else: PyTorch-ROCm's scaled_dot_product_attention on transposed views."""
-    if _HipAttention.usable(q, k, v):
-        return _HipAttention.apply(q, k, v)
-    return _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
-
-
-class _HipAttention(torch.autograd.Function):
-    """Forward: C-ABI ``sam3_attn_fwd`` (flash-style single pass, o and log-sum-exp).  Backward: PyTorch-ROCm's
-    memory-efficient attention backward (``aten::_scaled_dot_product_efficient_attention_backward``, the kernel the trunk's
-    backward already ran: aiter fmha_bwd) fed with this forward's o / lse -- the two agree on the convention, which
-    ``_calibrate`` verifies once per process on a small problem against PyTorch's own forward (a mismatch disables the
-    kernel with a warning rather than training on wrong gradients).  SAM3_HIP_ATTENTION=0 keeps PyTorch's forward."""
-    _state = {}         # device index -> None (not usable) | dict(seed=..., offset=...)
-
-    @staticmethod
-    def usable(q, k, v) -> bool:
-        import os
-        if not (q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 4 and q.shape[-1] == 64 and q.shape == k.shape == v.shape
-                and q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and q.shape[1] % 32 == 0
-                and not torch.is_autocast_enabled("cuda")) or os.environ.get("SAM3_HIP_ATTENTION", "1") == "0":
-            return False
-        st = _HipAttention._state.get(q.device.index, "new")
-        if st == "new":
-            st = _HipAttention._calibrate(q.device)
-        return st is not None
-
-    @staticmethod
-    def _launch(q, k, v):
-        import ctypes
-        from . import _ffi
-        lib = _ffi.load()
-        B, L, H, D = q.shape
-        o = torch.empty_like(q)
-        lse = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
-        rc = lib.sam3_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, L, H, D,
-                               q.stride(0), q.stride(1), q.stride(2), float(D) ** -0.5, 0,
-                               ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"sam3_attn_fwd failed ({rc})")
-        return o, lse
-
-    @staticmethod
-    def _calibrate(device):
-        """One small problem through PyTorch's efficient-attention forward and through this kernel: outputs and log-sum-exp
-        must agree (bf16 rounding of o; 1e-3 on lse), and the philox placeholders of the backward are taken from it."""
-        import warnings
-        st = None
-        try:
-            g = torch.Generator(device=device).manual_seed(0)
-            q, k, v = (torch.randn(2, 96, 2, 64, device=device, generator=g).bfloat16() for _ in range(3))
-            ref_o, ref_lse, seed, offset = torch.ops.aten._scaled_dot_product_efficient_attention(
-                q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), None, True, 0.0, False)
-            o, lse = _HipAttention._launch(q, k, v)
-            ok = (ref_lse.dtype == torch.float32 and ref_lse.shape[:2] == lse.shape[:2] and ref_lse.shape[2] >= 96
-                  and torch.allclose(ref_lse[:, :, :96], lse, rtol=0, atol=2e-3)
-                  and torch.allclose(ref_o.transpose(1, 2).float(), o.float(), rtol=0, atol=2e-2))
-            if ok:
-                st = {"seed": seed, "offset": offset, "lse_pad": ref_lse.shape[2] != 96}
-            else:
-                warnings.warn("sam3_lora_amd: the HIP attention forward disagrees with PyTorch's efficient-attention forward "
-                              f"(lse shape {tuple(ref_lse.shape)} vs {tuple(lse.shape)}); keeping PyTorch's kernel")
-        except Exception as e:          # an aten signature this torch does not have: keep PyTorch's path
-            warnings.warn(f"sam3_lora_amd: HIP attention forward disabled ({type(e).__name__}: {str(e)[:200]})")
-        _HipAttention._state[device.index] = st
-        return st
-
-    @staticmethod
-    def forward(ctx, q, k, v):
-        o, lse = _HipAttention._launch(q, k, v)
-        ctx.save_for_backward(q, k, v, o, lse)
-        return o
-
-    @staticmethod
-    def backward(ctx, go):
-        q, k, v, o, lse = ctx.saved_tensors
-        st = _HipAttention._state[q.device.index]
-        if st["lse_pad"]:               # PyTorch's kernel keeps the log-sum-exp padded to a multiple of 32 rows
-            L = lse.shape[2]
-            lse = torch.nn.functional.pad(lse, (0, (L + 31) // 32 * 32 - L))
-        t = lambda x: x.transpose(1, 2)
-        gq, gk, gv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
-            t(go), t(q), t(k), t(v), None, t(o), lse, st["seed"], st["offset"], 0.0,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], False], False)
-        return (gq.transpose(1, 2) if gq is not None else None, gk.transpose(1, 2) if gk is not None else None,
-                gv.transpose(1, 2) if gv is not None else None)
 
 
 class _QKVRope(torch.autograd.Function):
