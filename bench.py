@@ -923,6 +923,31 @@ def main():
                                                   "torch.autograd, same activation dtype, same GPU"}
         except Exception as e:      # an auxiliary comparison must never cost the bench line
             out["torch_unfused_block"] = {"error": str(e)[:200]}
+        out["roofline"]["operands"] = ("hi + lo bf16 pairs for A, B, t, gt (fp32 arithmetic on the bf16 activations; "
+                                       "include/sam3_lora_amd.h)" if w.rank <= 16 and e_ == 2 else "single-rounded bf16 / fp32")
+    # the same kernels with single-rounded operands (round 2's arithmetic: SAM3_LORA_SINGLE_ROUND=1) -- what the hi + lo form costs
+    if not args.no_roofline and args.rank <= 16 and act_dtype == torch.bfloat16 and os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") in ("", "0"):
+        from sam3_lora_amd import _ffi
+        os.environ["SAM3_LORA_SINGLE_ROUND"] = "1"
+        _ffi.load().sam3_lora_debug_reload_knobs()
+        try:
+            w.P1, w.P2 = [None] * w.blocks, [None] * w.blocks          # blobs of the other layout must not be reused
+            for _ in range(2):
+                w.step(recompute=False)
+            tsr = timed(lambda: w.step(recompute=False), 3)
+            rows_sr = insitu_kernels(w, steps=1)
+            if rank == 0:
+                k = next((r_ for r_ in rows_sr if r_["kernel"] == "k_t2" and r_["dim"] == D_HID), rows_sr[0])
+                out["roofline"]["single_rounded_operands"] = {
+                    "kernel": f"{k['kernel']} [M={w.M},N={k['dim']}]", "avg_us": k["avg_us"], "achieved": k["GBps"],
+                    "frac": round(k["GBps"] / HBM_PEAK_GBPS, 4),
+                    "adapter_path_no_recompute_ms": round(tsr / 3 * 1e3, 3),
+                    "what": "SAM3_LORA_SINGLE_ROUND=1: A, B, t, gt rounded to bf16 once each (round 2's arithmetic) -- the price of "
+                            "the hi + lo operands is the difference to the line above"}
+        finally:
+            os.environ.pop("SAM3_LORA_SINGLE_ROUND", None)
+            _ffi.load().sam3_lora_debug_reload_knobs()
+            w.P1, w.P2 = [None] * w.blocks, [None] * w.blocks
     if world > 1:
         dist.barrier()
     del w

@@ -21,14 +21,23 @@ extern "C" {
 
 #define SAM3_FP8_E4M3 0   /* OCP e4m3fn, max 448   (activations, weights)   */
 #define SAM3_FP8_E5M2 1   /* OCP e5m2,   max 57344 (gradients)              */
+/* amax state of one tensor role: an array of this many floats; a writer updates ONE slot (one atomic per workgroup / wave,
+ * spread over the slots), a reader takes the maximum of all of them */
+#define SAM3_FP8_AMAX_SLOTS 64
 
 const char* sam3_fp8_last_error(void);
 
 /*
- *   scale      = max(*amax_in, 2^-24) / fmt_max                      (written to *scale_out: the dequantisation factor)
- *   out[i]     = fp8( clamp(x[i] / scale, -fmt_max, fmt_max) )       round-to-nearest-even, saturating
- *   *amax_out  = max(*amax_out, max_i |x[i]|)                        (caller zeroes it beforehand)
- * x: n elements, bf16 (src_dtype 0) or fp32 (1), 16-byte aligned, n % 16 == 0.  out: n bytes, 16-byte aligned.
+ *   scale      = max(max_s amax_in[s], 2^-24) / fmt_max              (written to *scale_out: the dequantisation factor)
+ *   out[i]     = fp8( clamp(x[i] / scale, -fmt_max, fmt_max) )       round-to-nearest-even, saturating; NaN stays NaN
+ *   amax_out[s] = max(amax_out[s], max_i |x[i]| over the elements slot s's workgroups saw)      (caller zeroes it beforehand)
+ * amax_in / amax_out: SAM3_FP8_AMAX_SLOTS floats each.  x: n elements, bf16 (src_dtype 0) or fp32 (1), 16-byte aligned,
+ * n % 16 == 0.  out: n bytes, 16-byte aligned.
+ *
+ * The same protocol is carried by the PRODUCING kernels of this library, which then write the fp8 image beside their bf16
+ * output and this pass disappears: sam3_lora_fwd_act_q8 / sam3_lora_bwd_act_q8 (sam3_lora_amd.h: GELU(h) for fc2's GEMM,
+ * the pre-activation gradient for fc1's input-gradient GEMM) and sam3_vit_layernorm_fwd_q8 (sam3_vit_amd.h: the inputs of
+ * the qkv and fc1 GEMMs).
  */
 int sam3_fp8_quantize(const void* x, void* out, const float* amax_in, float* amax_out, float* scale_out, int64_t n,
                       int src_dtype, int fmt, void* stream);

@@ -168,6 +168,31 @@ int sam3_lora_bwd_act(const void* gy, const void* x, const void* tT_saved, const
                       int act, const void* pre_act, int64_t ldpre);
 
 /*
+ * fp8 frozen-W mode (include/sam3_fp8_amd.h): the same two calls, and the tensor the NEXT frozen GEMM consumes -- act_out
+ * (forward: fc2's input) resp. gx_inout after the activation derivative (backward: the input of fc1's input-gradient GEMM) --
+ * also leaves as an fp8 image q8_out[M, width] (row pitch ldq bytes), quantised from the bf16-ROUNDED values with the delayed
+ * scale of sam3_fp8_quantize's protocol (amax_in / amax_out: SAM3_FP8_AMAX_SLOTS floats each; scale_out: 1 float; fmt:
+ * SAM3_FP8_E4M3 / SAM3_FP8_E5M2): bit-identical to running sam3_fp8_quantize over that tensor afterwards, without the extra
+ * read + write pass.  bf16 activations, rank <= 16, act == SAM3_LORA_ACT_GELU, and (backward) drop_p == 0; SAM3_LORA_ENOTSUP
+ * otherwise -- the caller then quantises separately.
+ */
+int sam3_lora_fwd_act_q8(const void* x, const void* A, const void* B, void* y_inout, void* tT_out,
+                         int64_t M, int in_features, int out_features, int rank,
+                         int64_t ldx, int64_t ldy, int layout, float scaling,
+                         float drop_p, uint64_t seed, uint64_t offset, int dtype,
+                         void* workspace, size_t workspace_bytes, void* stream,
+                         int act, void* act_out, int64_t ldact,
+                         void* q8_out, int64_t ldq, int fmt, const float* amax_in, float* amax_out, float* scale_out);
+int sam3_lora_bwd_act_q8(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B,
+                         void* gx_inout, float* gA_accum, float* gB_accum,
+                         int64_t M, int in_features, int out_features, int rank,
+                         int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling,
+                         float drop_p, uint64_t seed, uint64_t offset, int dtype, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream,
+                         int act, const void* pre_act, int64_t ldpre,
+                         void* q8_out, int64_t ldq, int fmt, const float* amax_in, float* amax_out, float* scale_out);
+
+/*
  * Merge for adapter-free inference: Wm[out, in] = W[out, in] + scaling * (A_c @ B_c)^T, fp32.
  * Replaces sam3_lora/lora/lora_layer.py:81-88 (merge_weights) and :160-178.
  */

@@ -27,18 +27,20 @@ EXPORTS = (
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages", "sam3_lora_debug_reload_knobs",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
+    "sam3_lora_fwd_act_q8", "sam3_lora_bwd_act_q8",
 )
 ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
 VIT_EXPORTS = ("sam3_vit_qkv_rope_fwd", "sam3_vit_qkv_rope_bwd", "sam3_vit_qkv_rope_win_fwd",
                "sam3_vit_qkv_rope_win_bwd", "sam3_vit_win_residual", "sam3_vit_layernorm_fwd",
-               "sam3_vit_layernorm_bwd", "sam3_vit_layernorm_bwd_add")      # include/sam3_vit_amd.h
+               "sam3_vit_layernorm_bwd", "sam3_vit_layernorm_bwd_add", "sam3_vit_layernorm_fwd_q8")      # include/sam3_vit_amd.h
 LOSS_EXPORTS = ("sam3_loss_last_error", "sam3_mask_loss_workspace_bytes", "sam3_mask_loss_fwd",
                 "sam3_mask_loss_bwd", "sam3_box_pair_fwd", "sam3_box_pair_bwd")                                          # include/sam3_loss_amd.h
 FP8_EXPORTS = ("sam3_fp8_last_error", "sam3_fp8_quantize")                 # include/sam3_fp8_amd.h
 SEG_EXPORTS = ("sam3_seg_last_error", "sam3_gn_nhwc_supported", "sam3_gn_nhwc_workspace_bytes", "sam3_gn_nhwc_fwd",
                "sam3_gn_nhwc_bwd", "sam3_rpb_bias_fwd")                                             # include/sam3_seg_amd.h
 FP8_E4M3, FP8_E5M2 = 0, 1
+FP8_AMAX_SLOTS = 64            # SAM3_FP8_AMAX_SLOTS
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
 _lib = None
@@ -86,6 +88,11 @@ def _declare(lib):
     lib.sam3_lora_fwd_act.argtypes = list(lib.sam3_lora_fwd.argtypes) + [c_int, c_void_p, c_int64]
     lib.sam3_lora_bwd_act.restype = c_int
     lib.sam3_lora_bwd_act.argtypes = list(lib.sam3_lora_bwd.argtypes) + [c_int, c_void_p, c_int64]
+    q8_tail = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]     # q8_out, ldq, fmt, amax_in, amax_out, scale_out
+    lib.sam3_lora_fwd_act_q8.restype = c_int
+    lib.sam3_lora_fwd_act_q8.argtypes = list(lib.sam3_lora_fwd_act.argtypes) + q8_tail
+    lib.sam3_lora_bwd_act_q8.restype = c_int
+    lib.sam3_lora_bwd_act_q8.argtypes = list(lib.sam3_lora_bwd_act.argtypes) + q8_tail
     lib.sam3_lora_debug_reload_knobs.restype = None
     lib.sam3_lora_debug_reload_knobs.argtypes = []
     lib.sam3_lora_debug_set_stages.restype = ctypes.c_uint
@@ -107,6 +114,9 @@ def _declare(lib):
     lib.sam3_vit_win_residual.argtypes = [c_void_p] * 4 + [c_int64] + [c_int] * 6 + [c_void_p]
     lib.sam3_vit_layernorm_fwd.restype = c_int
     lib.sam3_vit_layernorm_fwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_float, c_int, c_void_p]
+    lib.sam3_vit_layernorm_fwd_q8.restype = c_int
+    lib.sam3_vit_layernorm_fwd_q8.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_float, c_int, c_void_p, c_int64, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]
     lib.sam3_vit_layernorm_bwd.restype = c_int
     lib.sam3_vit_layernorm_bwd.argtypes = [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]
     lib.sam3_vit_layernorm_bwd_add.restype = c_int

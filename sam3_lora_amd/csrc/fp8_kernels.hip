@@ -8,6 +8,7 @@
 #include <cstdio>
 
 #include "sam3_fp8_amd.h"
+#include "fp8_common.inc"
 
 typedef unsigned short bf16_t;
 
@@ -39,54 +40,30 @@ __device__ __forceinline__ void load16(const float* p, float (&v)[16]) {
     }
 }
 
-// max that keeps a NaN once one was seen: a diverged step must surface in the next call's scale, not be clamped to FMAX
-__device__ __forceinline__ float nanmax(float acc, float a) { return (a != a || a > acc) ? a : acc; }
-
 template <typename XT, int FMT>
 __global__ __launch_bounds__(256) void k_fp8_quantize(const XT* __restrict__ x, unsigned char* __restrict__ out,
                                                       const float* __restrict__ amax_in, float* __restrict__ amax_out,
                                                       float* __restrict__ scale_out, long long n16) {
-    constexpr float FMAX = FMT == SAM3_FP8_E4M3 ? 448.f : 57344.f;
-    const float ain = *amax_in;
-    const float amax = ain != ain ? ain : fmaxf(ain, 5.9604645e-8f);
-    const float scale = amax / FMAX, inv = FMAX / amax;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const Q8Out o{out, 0, amax_in, amax_out, scale_out, FMT};
+    const Q8Scale sc = q8_begin(o, blockIdx.x == 0 && threadIdx.x == 0);
     float seen = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
         float v[16];
         load16(x + i * 16, v);
         unsigned w[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float c[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                seen = nanmax(seen, fabsf(v[4 * q + j]));
-                const float sv = v[4 * q + j] * inv;
-                c[j] = sv != sv ? sv : fminf(fmaxf(sv, -FMAX), FMAX);       // a NaN stays a NaN (fminf / fmaxf would clamp it away)
-            }
-            int word = 0;
-            if (FMT == SAM3_FP8_E4M3) {
-                word = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], word, false);
-                word = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], word, true);
-            } else {
-                word = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], word, false);
-                word = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], word, true);
-            }
-            w[q] = (unsigned)word;
-        }
+        for (int q = 0; q < 4; ++q) w[q] = q8_pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], sc, FMT, seen);
         *reinterpret_cast<uint4*>(out + i * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    // one atomic per WORKGROUP: thousands of same-address atomics serialise in L2 (measured: 125 us per call with one per
-    // wave at 8192 waves -- the kernel ran at 1.3 TB/s)
+    // one atomic per WORKGROUP, spread over the amax slots
     __shared__ float wmax[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) seen = nanmax(seen, __shfl_down(seen, o, 64));
+    for (int off = 32; off > 0; off >>= 1) seen = q8_nanmax(seen, __shfl_down(seen, off, 64));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = seen;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float m = nanmax(nanmax(wmax[0], wmax[1]), nanmax(wmax[2], wmax[3]));   // NaN's bit pattern outranks every finite amax
-        atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(m));
+        const float m = q8_nanmax(q8_nanmax(wmax[0], wmax[1]), q8_nanmax(wmax[2], wmax[3]));   // NaN's bit pattern outranks every finite amax
+        atomicMax(reinterpret_cast<unsigned*>(amax_out) + (blockIdx.x & (SAM3_FP8_AMAX_SLOTS - 1)), __float_as_uint(m));
     }
 }
 

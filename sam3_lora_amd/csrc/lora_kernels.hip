@@ -42,6 +42,7 @@
 #include <cstring>
 
 #include "sam3_lora_amd.h"
+#include "fp8_common.inc"
 
 typedef unsigned short bf16_t;  // storage type of a bf16 element
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -150,8 +151,9 @@ struct PackJob {
     long long si, sj;
     int ldd;              // row pitch of dst in elements (0 => J); > J when packing into a slice of a wider buffer
     int f32;
-    int hl;               // bf16 hi + lo image: 1 = rows 16..31 hold the lo parts of rows 0..15 (I == 32), 2 = the same for
-                          // columns (J == 32); Iv / Jv then bound the index inside one half
+    int hl;               // bf16 hi + lo image: 1 = rows 16..31 hold the lo parts of rows 0..15 (I == 32); 2 = columns (J == 32),
+                          // interleaved per 4 rank indices: [hi 4g..4g+3 | lo 4g..4g+3] at columns 8g..8g+7; Iv / Jv then
+                          // bound the rank index
 };
 
 constexpr int PACK_JOBS_MAX = 64;    // 64 x 56 B of kernel arguments per launch
@@ -164,8 +166,10 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)jb.I * jb.J) return;
     const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
-    const int is = jb.hl == 1 ? (i & 15) : i, js = jb.hl == 2 ? (j & 15) : j;       // source index (both halves read the same master)
-    const bool lo = (jb.hl == 1 && i >= 16) || (jb.hl == 2 && j >= 16);
+    // source index (both halves read the same master).  hl == 2 (k_t2's operand rows) interleaves the halves per group of 4
+    // rank indices -- [hi 0..3 | lo 0..3 | hi 4..7 | lo 4..7 | ...] -- so that a lane's hi and lo fragments are ONE 16-byte load
+    const int is = jb.hl == 1 ? (i & 15) : i, js = jb.hl == 2 ? ((j >> 3) * 4 + (j & 3)) : j;
+    const bool lo = (jb.hl == 1 && i >= 16) || (jb.hl == 2 && ((j >> 2) & 1));
     float v = (is < jb.Iv && js < jb.Jv) ? jb.src[is * jb.si + js * jb.sj] : 0.f;
     const long long o = (long long)i * (jb.ldd ? jb.ldd : jb.J) + j;
     if (jb.f32) {
@@ -244,10 +248,23 @@ __device__ __forceinline__ void store_t4(bf16_t* __restrict__ T, bf16_t* __restr
     tb[24] = (bf16_t)(p1 >> 16);
 }
 // HL: the fp32 values v -> hi = bf16(v) as rank tile 0, lo = bf16(v - hi) as rank tile 1 of a rank-32 image
+// The row-major image (k_t2's operand) interleaves the halves per 4 rank indices: T[m][8 g .. 8 g + 3] = hi, [8 g + 4 .. + 7] =
+// lo (g = r0 / 4) -- one 16-byte store here, one 16-byte load per tile in k_t2.
 __device__ __forceinline__ void store_t4_hl(bf16_t* __restrict__ T, bf16_t* __restrict__ TTf, long long m, int r0, f32x4 v) {
     const unsigned h0 = pack2(v[0], v[1]), h1 = pack2(v[2], v[3]);
-    store_t4<2>(T, TTf, m, 0, r0, h0, h1);
-    store_t4<2>(T, TTf, m, 1, r0, pack2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), pack2(v[2] - bf_lo(h1), v[3] - bf_hi(h1)));
+    const unsigned l0 = pack2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), l1 = pack2(v[2] - bf_lo(h1), v[3] - bf_hi(h1));
+    *reinterpret_cast<uint4*>(T + m * 32 + 2 * r0) = make_uint4(h0, h1, l0, l1);
+    const long long blk = m >> 5;
+    const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {        // fragment-major image: rank tile 0 = hi, 1 = lo (k_t3's two A-operands)
+        const unsigned p0 = rt ? l0 : h0, p1 = rt ? l1 : h1;
+        bf16_t* tb = TTf + (((blk * 2 + rt) * 4 + gq) * 16 + r0) * 8 + jq;
+        tb[0] = (bf16_t)(p0 & 0xffffu);
+        tb[8] = (bf16_t)(p0 >> 16);
+        tb[16] = (bf16_t)(p1 & 0xffffu);
+        tb[24] = (bf16_t)(p1 >> 16);
+    }
 }
 
 // PART (small M, r <= 16): blockIdx.y selects a range of K chunks and the workgroup writes its fp32 partial to
@@ -473,10 +490,12 @@ struct YTile<bf16_t> {
             else v[p] = (m < M && col < N) ? (STREAM ? ldg16(src) : ldg16_rmw(src)) : zero4();
         }
     }
-    template <bool FAST, bool DROP, int ACT>
+    // Q8: the tensor the NEXT frozen GEMM consumes (ACT == 1: act(y); ACT == 2: the updated gradient) also leaves as fp8
+    template <bool FAST, bool DROP, int ACT, bool Q8 = false>
     __device__ __forceinline__ void add_store(bf16_t* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
-                                              const DropKey& dk, bf16_t* AUX, long long ldaux, const YTile<bf16_t>& haux) {
+                                              const DropKey& dk, bf16_t* AUX, long long ldaux, const YTile<bf16_t>& haux,
+                                              const Q8Out* q8 = nullptr, const Q8Scale* qs = nullptr, float* seen = nullptr) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
@@ -492,7 +511,16 @@ struct YTile<bf16_t> {
             const bool ok = FAST || (m < M && col < N);
             if (ACT == 2) o = act8(o, haux.v[p], 2);
             if (ok) stg16(Y + m * ldy + col, o);
-            if (ACT == 1 && ok) stg16(AUX + m * ldaux + col, act8(o, o, 1));
+            uint4 a8 = o;
+            if (ACT == 1) {
+                a8 = act8(o, o, 1);
+                if (ok) stg16(AUX + m * ldaux + col, a8);
+            }
+            if (Q8 && ok) {         // the bf16-ROUNDED values, as a separate quantisation pass over the stored tensor would see them
+                const unsigned w0 = q8_pack4(bf_lo(a8.x), bf_hi(a8.x), bf_lo(a8.y), bf_hi(a8.y), *qs, q8->fmt, *seen);
+                const unsigned w1 = q8_pack4(bf_lo(a8.z), bf_hi(a8.z), bf_lo(a8.w), bf_hi(a8.w), *qs, q8->fmt, *seen);
+                *reinterpret_cast<uint2*>(q8->q + m * q8->ld + col) = make_uint2(w0, w1);
+            }
         }
     }
 };
@@ -511,10 +539,12 @@ struct YTile<float> {
             v[p][1] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    template <bool FAST, bool DROP, int ACT>
+    template <bool FAST, bool DROP, int ACT, bool Q8 = false>
     __device__ __forceinline__ void add_store(float* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
-                                              const DropKey& dk, float* AUX, long long ldaux, const YTile<float>& haux) {
+                                              const DropKey& dk, float* AUX, long long ldaux, const YTile<float>& haux,
+                                              const Q8Out* = nullptr, const Q8Scale* = nullptr, float* = nullptr) {
+        static_assert(!Q8, "fp8 outputs ride on bf16 tensors only");
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
@@ -548,11 +578,12 @@ struct YTile<float> {
 };
 
 // HL (RT == 2): W2t = [hi | lo] of the LoRA operand, T = [hi | lo] of t: delta = hi.t_hi + hi.t_lo + lo.t_hi.
-template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false>
+template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false>
 __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
-                                            ReduceRide ride) {
+                                            ReduceRide ride, Q8Out q8) {
+    static_assert(!Q8 || ACT != 0, "the fp8 image is the one of the activation-fused passes");
     static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
     __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
@@ -567,6 +598,9 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
     const int n = lane & 15, g = lane >> 4;
     float* slab = slab_all[wave];
     const int c0 = blockIdx.x * CW;
+    Q8Scale qs{0.f, 0.f};
+    float seen = 0.f;
+    if (Q8) qs = q8_begin(q8, blockIdx.x == 0 && by == 0 && tid == 0);
 
     // W2^T fragments (MFMA A-operand: i = output column, k = rank index), kept for the whole kernel
     uint2 wlo[8], whi[8];
@@ -574,10 +608,16 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
     for (int ct = 0; ct < 8; ++ct) {
         const int col = c0 + ct * 16 + n;
         const bool ok = col < N;
-        wlo[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + g * 4) : make_uint2(0u, 0u);
-        whi[ct] = make_uint2(0u, 0u);
-        if (RT == 2)
-            whi[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + 16 + g * 4) : make_uint2(0u, 0u);
+        wlo[ct] = whi[ct] = make_uint2(0u, 0u);
+        if (HL) {       // interleaved image: this lane's hi and lo quads are adjacent
+            const uint4 w4 = ok ? *reinterpret_cast<const uint4*>(W2t + (long long)col * RP + g * 8) : make_uint4(0u, 0u, 0u, 0u);
+            wlo[ct] = make_uint2(w4.x, w4.y);
+            whi[ct] = make_uint2(w4.z, w4.w);
+        } else {
+            wlo[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + g * 4) : make_uint2(0u, 0u);
+            if (RT == 2)
+                whi[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + 16 + g * 4) : make_uint2(0u, 0u);
+        }
     }
 
     const long long ntiles = (M + 15) / 16, nfull = M / 16;
@@ -587,6 +627,12 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
 
     // T fragment of a tile (MFMA B-operand: k = rank index, n = activation row); T has Mp >= 16*ntiles rows
     auto load_t = [&](long long t, uint2& lo, uint2& hi) {
+        if (HL) {       // (t_hi, t_lo) of this lane's 4 rank indices: one 16-byte load (store_t4_hl's layout)
+            const uint4 t4 = *reinterpret_cast<const uint4*>(T + (t * 16 + n) * RP + g * 8);
+            lo = make_uint2(t4.x, t4.y);
+            hi = make_uint2(t4.z, t4.w);
+            return;
+        }
         lo = *reinterpret_cast<const uint2*>(T + (t * 16 + n) * RP + g * 4);
         hi = make_uint2(0u, 0u);
         if (RT == 2) hi = *reinterpret_cast<const uint2*>(T + (t * 16 + n) * RP + 16 + g * 4);
@@ -639,7 +685,7 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
             if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, tn * 16, col, lane, M, N);
             delta_to_slab(tlo, thi);
             wave_sync();
-            cur.template add_store<true, DROP, ACT>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur);
+            cur.template add_store<true, DROP, ACT, Q8>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
             wave_sync();
         }
     }
@@ -651,9 +697,10 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
         if (ACT == 2) hcur.template load<false, true>(AUX, ldaux, t * 16, col, lane, M, N);
         delta_to_slab(tlo, thi);
         wave_sync();
-        cur.template add_store<false, DROP, ACT>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur);
+        cur.template add_store<false, DROP, ACT, Q8>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
         wave_sync();
     }
+    if (Q8) q8_end_wave(q8, seen, (blockIdx.x + by * gridDim.x) * 4 + wave);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1087,6 +1134,18 @@ int check_act(const void* p, long long ld, int width, int dtype, const char* wha
     return 0;
 }
 
+// fp8 image riding on an activation-fused pass (sam3_lora_fwd_act_q8 / _bwd_act_q8): the hi + lo kernels only (one rank
+// group of <= 16, bf16), and the pass must carry an activation
+int check_q8(const Q8Out* q8, int width, int rank, int dtype, int act) {
+    if (!q8->q || !q8->amax_in || !q8->amax_out || !q8->scale_out) return fail(SAM3_LORA_EINVAL, "fp8 output: NULL pointer");
+    if (q8->fmt != SAM3_FP8_E4M3 && q8->fmt != SAM3_FP8_E5M2) return fail(SAM3_LORA_EINVAL, "fp8 output: unknown format %d", q8->fmt);
+    if (q8->ld < width || (q8->ld & 7) || ((uintptr_t)q8->q & 7)) return fail(SAM3_LORA_EINVAL, "fp8 output: row pitch / base must be 8-byte aligned");
+    if (act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "fp8 output rides on the activation-fused passes only");
+    if (!geo_of(rank, dtype).hl || rank > 32)
+        return fail(SAM3_LORA_ENOTSUP, "fp8 output needs bf16 activations and rank <= 16 (hi + lo kernels)");
+    return 0;
+}
+
 int launch_ok(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SAM3_LORA_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -1298,7 +1357,7 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
 template <typename YT>
 void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT, bool hl,
                hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0,
-               const ReduceRide* ride_in = nullptr) {
+               const ReduceRide* ride_in = nullptr, const Q8Out* q8_in = nullptr) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
     // 3 tiles per wave measured best on MI355X for both N = 4736 and N = 1024 at M = 41472 (sweep 4..48:
@@ -1313,9 +1372,17 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     }
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows);
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
+    const Q8Out q8 = q8_in ? *q8_in : Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
+    if (q8.q) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
+        if (act == 1) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 1, true, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
+                                         (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8);
+        else hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
+                                (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8);
+        return;
+    }
 #define T2_LAUNCH(RTV, DV, AV, HV) \
     hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV, HV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
-                       (YT*)aux, ldaux, ride)
+                       (YT*)aux, ldaux, ride, q8)
 #define T2_RT(RTV, HV)                                                                     \
     do {                                                                               \
         if (act == 1) T2_LAUNCH(RTV, false, 1, HV);            /* forward: no mask on y */   \
@@ -1598,7 +1665,7 @@ int sam3_lora_pack_many(int count, const void* const* A, const void* const* B, v
 static void fwd_group(const void* x, const void* A_g, const void* B_g, bool pre, void* y_inout, void* tT_out, long long M,
                       int in_features, int out_features, int rank, long long ldx, long long ldy, const Strides& s,
                       float scale, const DropKey& dk, int dtype, char* ws, hipStream_t st, int act, void* act_out,
-                      long long ldact) {
+                      long long ldact, const Q8Out* q8 = nullptr) {
     const Geo gq = geo_of(rank, dtype);
     const int RP = gq.RP, RT = gq.RT, hr = gq.hl ? 1 : 0, hc = gq.hl ? 2 : 0;
     const long long Mp = round_up(M, 64);
@@ -1629,19 +1696,20 @@ static void fwd_group(const void* x, const void* A_g, const void* B_g, bool pre,
                           gq.RG == 16 ? (float*)(ws + w.t1p) : nullptr);
     if (stage_on(SAM3_LORA_STAGE_T2))
         launch_t2<bf16_t>(y_inout, ldy, T, (const bf16_t*)W2t, M, out_features, scale, RT, gq.hl, st, DropKey{0u, 0u, 0},
-                          act ? 1 : 0, act_out, ldact);
+                          act ? 1 : 0, act_out, ldact, nullptr, act ? q8 : nullptr);
 }
 
 static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
                     int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
                     float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
-                    void* stream, int act, void* act_out, int64_t ldact) {
+                    void* stream, int act, void* act_out, int64_t ldact, const Q8Out* q8 = nullptr) {
     if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
     const bool pre = (layout & SAM3_LORA_PREPACKED) != 0;
     layout &= ~SAM3_LORA_PREPACKED;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
+    if (q8 && (rc = check_q8(q8, out_features, rank, dtype, act))) return rc;
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if ((rc = check_act(y_inout, ldy, out_features, dtype, "y_inout"))) return rc;
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
@@ -1667,7 +1735,7 @@ static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, 
         // the activation rides on the LAST group's update: by then y holds the complete sum
         const int act_g = (g == ng - 1) ? act : 0;
         fwd_group(x, Ag, Bg, pre, y_inout, tT, M, in_features, out_features, rg, ldx, ldy, s, scaling * inv_keep, dk, dtype,
-                  (char*)workspace, (hipStream_t)stream, act_g, act_out, ldact);
+                  (char*)workspace, (hipStream_t)stream, act_g, act_out, ldact, q8);
         if (pre) blob += packed_layout(in_features, out_features, rg, dtype).total;
         if (tT) tT += saved_t_group_bytes(M, rg, dtype);
     }
@@ -1695,7 +1763,8 @@ int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout
 static void bwd_group(const void* gy, const void* x, const void* tT_saved, const void* A_g, const void* B_g, bool pre,
                       void* gx_inout, float* gA_g, float* gB_g, long long M, int in_features, int out_features, int rank,
                       long long ldgy, long long ldx, long long ldgx, const Strides& s, float scale, const DropKey& dk,
-                      int dtype, int accumulate, char* ws, hipStream_t st, int a2, void* hpre, long long ldpre) {
+                      int dtype, int accumulate, char* ws, hipStream_t st, int a2, void* hpre, long long ldpre,
+                      const Q8Out* q8 = nullptr) {
     const Geo gq = geo_of(rank, dtype);
     const int RP = gq.RP, RT = gq.RT, RG = gq.RG, hr = gq.hl ? 1 : 0, hc = gq.hl ? 2 : 0;
     const bool hl = gq.hl;
@@ -1768,7 +1837,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     const bool riding = want_reduce && !f32 && gx_inout && s2 && !env_flag("SAM3_LORA_NO_RIDE");
     if (!f32 && gx_inout && s2)
         launch_t2<bf16_t>(gx_inout, ldgx, (bf16_t*)(ws + w.gt), (const bf16_t*)W2tb, M, in_features, scale, RT, hl, st, dk, a2, hpre,
-                          ldpre, riding ? &ride : nullptr);
+                          ldpre, riding ? &ride : nullptr, a2 ? q8 : nullptr);
     if (want_reduce && !riding) {
         dim3 grid((unsigned)ride.nblk, 2);
         ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
@@ -1780,13 +1849,16 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
                     float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
                     int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
                     uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
-                    int act, const void* pre_act, int64_t ldpre) {
+                    int act, const void* pre_act, int64_t ldpre, const Q8Out* q8 = nullptr) {
     if (drop_p < 0.f || drop_p > 1.f) { g_err[0] = 0; return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p); }
     g_err[0] = 0;
     int rc;
     const bool pre = (layout & SAM3_LORA_PREPACKED) != 0;
     layout &= ~SAM3_LORA_PREPACKED;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
+    if (q8 && (rc = check_q8(q8, in_features, rank, dtype, act))) return rc;
+    if (q8 && drop_p > 0.f) return fail(SAM3_LORA_ENOTSUP, "fp8 output is not combined with the dropout mask of the input gradient");
+    if (q8 && !gx_inout) return fail(SAM3_LORA_EINVAL, "fp8 output needs gx_inout");
     if ((rc = check_act(gy, ldgy, out_features, dtype, "gy"))) return rc;
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
@@ -1815,7 +1887,7 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
         const int a2 = (act && g == ng - 1) ? 2 : 0;
         bwd_group(gy, x, tT, Ag, Bg, pre, gx_inout, gAg, gBg, M, in_features, out_features, rg, ldgy, ldx, ldgx, s,
                   scaling * inv_keep, dk, dtype, accumulate, (char*)workspace, (hipStream_t)stream, a2,
-                  const_cast<void*>(pre_act), ldpre);
+                  const_cast<void*>(pre_act), ldpre, q8);
         if (pre) blob += packed_layout(in_features, out_features, rg, dtype).total;
         if (tT) tT += saved_t_group_bytes(M, rg, dtype);
     }
@@ -1839,6 +1911,28 @@ int sam3_lora_bwd_act(const void* gy, const void* x, const void* tT_saved, const
     return bwd_impl(gy, x, tT_saved, A, B, gx_inout, gA_accum, gB_accum, M, in_features, out_features, rank, ldgy, ldx, ldgx,
                     layout, scaling, drop_p, seed, offset, dtype, accumulate, workspace, workspace_bytes, stream, act, pre_act,
                     ldpre);
+}
+
+int sam3_lora_fwd_act_q8(const void* x, const void* A, const void* B, void* y_inout, void* tT_out, int64_t M,
+                         int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
+                         float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
+                         void* stream, int act, void* act_out, int64_t ldact, void* q8_out, int64_t ldq, int fmt,
+                         const float* amax_in, float* amax_out, float* scale_out) {
+    const Q8Out q8{(unsigned char*)q8_out, (long long)ldq, amax_in, amax_out, scale_out, fmt};
+    return fwd_impl(x, A, B, y_inout, tT_out, M, in_features, out_features, rank, ldx, ldy, layout, scaling, drop_p, seed,
+                    offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact, &q8);
+}
+
+int sam3_lora_bwd_act_q8(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
+                         float* gA_accum, float* gB_accum, int64_t M, int in_features, int out_features, int rank,
+                         int64_t ldgy, int64_t ldx, int64_t ldgx, int layout, float scaling, float drop_p, uint64_t seed,
+                         uint64_t offset, int dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
+                         int act, const void* pre_act, int64_t ldpre, void* q8_out, int64_t ldq, int fmt,
+                         const float* amax_in, float* amax_out, float* scale_out) {
+    const Q8Out q8{(unsigned char*)q8_out, (long long)ldq, amax_in, amax_out, scale_out, fmt};
+    return bwd_impl(gy, x, tT_saved, A, B, gx_inout, gA_accum, gB_accum, M, in_features, out_features, rank, ldgy, ldx, ldgx,
+                    layout, scaling, drop_p, seed, offset, dtype, accumulate, workspace, workspace_bytes, stream, act, pre_act,
+                    ldpre, &q8);
 }
 
 int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm, int in_features, int out_features,

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include "fp8_common.inc"
 
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
@@ -191,12 +192,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <typename T, int CPL>
+// Q8 (bf16 only): y also leaves as an fp8 image for the frozen GEMM that consumes it (fp8_common.inc)
+template <typename T, int CPL, bool Q8 = false>
 __global__ __launch_bounds__(256) void k_ln_fwd(const T* __restrict__ x, const T* __restrict__ gamma,
                                                 const T* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
-                                                float* __restrict__ rstd, long long M, int C, float eps) {
+                                                float* __restrict__ rstd, long long M, int C, float eps,
+                                                Q8Out q8 = Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0}) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    Q8Scale qs{0.f, 0.f};
+    float seen = 0.f;
+    if (Q8) qs = q8_begin(q8, blockIdx.x == 0 && threadIdx.x == 0);
     if (row >= M) return;
     F8 v[CPL];
     float s = 0.f;
@@ -231,8 +237,15 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const T* __restrict__ x, const T
 #pragma unroll
             for (int j = 0; j < 8; ++j) o.v[j] = (v[i].v[j] - mu) * rs * g.v[j] + b.v[j];
             st8(y + row * C + c, o);
+            if (Q8) {       // the bf16-ROUNDED values, as a separate quantisation pass over y would see them
+                const unsigned p0 = vpack2(o.v[0], o.v[1]), p1 = vpack2(o.v[2], o.v[3]), p2 = vpack2(o.v[4], o.v[5]), p3 = vpack2(o.v[6], o.v[7]);
+                const unsigned w0 = q8_pack4(vlo(p0), vhi(p0), vlo(p1), vhi(p1), qs, q8.fmt, seen);
+                const unsigned w1 = q8_pack4(vlo(p2), vhi(p2), vlo(p3), vhi(p3), qs, q8.fmt, seen);
+                *reinterpret_cast<uint2*>(q8.q + row * q8.ld + c) = make_uint2(w0, w1);
+            }
         }
     }
+    if (Q8) q8_end_wave(q8, seen, (unsigned)(blockIdx.x * 4 + (threadIdx.x >> 6)) >> 2);     // 4 waves of a workgroup share a slot
 }
 
 // gx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gy * gamma,  xhat = (x - mean) * rstd
@@ -283,9 +296,19 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ gy, const 
 
 template <typename T>
 int launch_ln(bool bwd, const void* a, const void* b, const void* gamma, const void* beta, void* out, float* mean,
-              float* rstd, long long M, int C, float eps, hipStream_t st, const void* add = nullptr) {
+              float* rstd, long long M, int C, float eps, hipStream_t st, const void* add = nullptr, const Q8Out* q8 = nullptr) {
     const dim3 grid((unsigned)((M + 3) / 4));
     const int cpl = (C + 511) / 512;
+    if (q8) {       // forward with the fp8 image (bf16 only; checked by the caller)
+#define LNQ_CASE(N) case N: hipLaunchKernelGGL((k_ln_fwd<bf16_t, N, true>), grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)gamma, \
+                                               (const bf16_t*)beta, (bf16_t*)out, mean, rstd, M, C, eps, *q8); break;
+        switch (cpl) {
+            LNQ_CASE(1) LNQ_CASE(2) LNQ_CASE(3) LNQ_CASE(4) LNQ_CASE(5) LNQ_CASE(6) LNQ_CASE(7) LNQ_CASE(8)
+            default: return -22;
+        }
+#undef LNQ_CASE
+        return hipGetLastError() == hipSuccess ? 0 : -5;
+    }
 #define LN_CASE(N)                                                                                                     \
     case N:                                                                                                            \
         if (bwd) hipLaunchKernelGGL((k_ln_bwd<T, N>), grid, dim3(256), 0, st, (const T*)a, (const T*)b, (const T*)gamma, \
@@ -390,6 +413,18 @@ int sam3_vit_layernorm_fwd(const void* x, const void* gamma, const void* beta, v
     if (dtype == 0) return launch_ln<bf16_t>(false, x, nullptr, gamma, beta, y, mean, rstd, M, C, eps, (hipStream_t)stream);
     if (dtype == 1) return launch_ln<float>(false, x, nullptr, gamma, beta, y, mean, rstd, M, C, eps, (hipStream_t)stream);
     return -22;
+}
+
+int sam3_vit_layernorm_fwd_q8(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                              int64_t M, int C, float eps, int dtype, void* q8_out, int64_t ldq, int fmt, const float* amax_in,
+                              float* amax_out, float* scale_out, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || C <= 0 || (C % 8) || C > 4096) return -22;
+    if (dtype != 0) return -95;
+    if (!q8_out || !amax_in || !amax_out || !scale_out || ldq < C || (ldq & 7) || ((uintptr_t)q8_out & 7) ||
+        (fmt != SAM3_FP8_E4M3 && fmt != SAM3_FP8_E5M2))
+        return -22;
+    const Q8Out q8{(unsigned char*)q8_out, (long long)ldq, amax_in, amax_out, scale_out, fmt};
+    return launch_ln<bf16_t>(false, x, nullptr, gamma, beta, y, mean, rstd, M, C, eps, (hipStream_t)stream, nullptr, &q8);
 }
 
 // input gradient only (gamma, beta frozen): gx = (add ? add : 0) + LN'(gy) from gy, x and the saved statistics;

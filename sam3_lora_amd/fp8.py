@@ -24,7 +24,7 @@ import torch
 
 from . import _ffi
 
-__all__ = ["enable_fp8_frozen", "fp8_enabled", "fp8_linear", "fp8_dx", "Fp8Quantizer", "Fp8Weight", "state_for", "eligible", "would_use"]
+__all__ = ["enable_fp8_frozen", "fp8_enabled", "fp8_linear", "fp8_dx", "Fp8Quantizer", "Fp8Weight", "state_for", "eligible", "would_use", "producer_slots", "fp8_linear_q", "fp8_dx_q"]
 
 _STATE = {"on": False}
 _WEIGHTS = {}          # id(weight) -> (weakref to the weight, Fp8Weight); tensors compare element-wise, so not a dict key
@@ -41,24 +41,41 @@ def fp8_enabled() -> bool:
 
 
 class Fp8Quantizer:
-    """One tensor role (e.g. "input of fc1"): delayed-scaling state + the quantise call."""
+    """One tensor role (e.g. "input of fc1"): delayed-scaling state + the quantise call.  The state -- two arrays of
+    ``SAM3_FP8_AMAX_SLOTS`` amax slots used alternately (read by this call / gathered for the next) and the scale -- is also
+    what the PRODUCING kernels take when they write the fp8 image themselves (:meth:`begin`)."""
 
     def __init__(self, fmt: int):
         self.fmt = fmt
-        self.amax = None            # two device scalars used alternately: [read by this call, written for the next]
+        self.amax = None            # [2, SLOTS]: [read by this call, written for the next], alternating
         self.scale = None
         self.k = 0
 
+    @property
+    def torch_dtype(self):
+        return torch.float8_e4m3fn if self.fmt == _ffi.FP8_E4M3 else torch.float8_e5m2
+
+    def begin(self, device) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """(amax to scale with, zeroed amax to gather into, scale slot) for a kernel that produces the tensor and its fp8
+        image in one pass -- or None on the very first use of this role (nothing to scale with yet: that call goes through
+        :meth:`__call__`, which calibrates on the tensor itself)."""
+        if self.amax is None or self.amax.device != device:
+            return None
+        cur, nxt = self.amax[self.k], self.amax[1 - self.k]
+        nxt.zero_()
+        self.k ^= 1
+        return cur, nxt, self.scale
+
     def __call__(self, x2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         lib = _ffi.load()
-        if self.amax is None or self.amax[0].device != x2.device:
-            self.amax = [torch.zeros(1, device=x2.device), torch.zeros(1, device=x2.device)]
+        if self.amax is None or self.amax.device != x2.device:
+            self.amax = torch.zeros(2, _ffi.FP8_AMAX_SLOTS, device=x2.device)
             self.scale = torch.empty(1, device=x2.device)
-            self.amax[0].copy_(x2.detach().abs().max().float())       # first call: calibrate on the tensor itself
+            self.amax[0, 0] = x2.detach().abs().max().float()         # first call: calibrate on the tensor itself
             self.k = 0
         cur, nxt = self.amax[self.k], self.amax[1 - self.k]
         nxt.zero_()
-        fdt = torch.float8_e4m3fn if self.fmt == _ffi.FP8_E4M3 else torch.float8_e5m2
+        fdt = self.torch_dtype
         out = torch.empty(x2.shape, dtype=fdt, device=x2.device)
         rc = lib.sam3_fp8_quantize(x2.data_ptr(), out.data_ptr(), cur.data_ptr(), nxt.data_ptr(), self.scale.data_ptr(),
                                    x2.numel(), 0 if x2.dtype == torch.bfloat16 else 1, self.fmt,
@@ -110,6 +127,34 @@ def fp8_linear(x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> 
     st = state_for(w)
     xq, sx = st.qx(x2)
     return torch._scaled_mm(xq, st.wq.t(), scale_a=sx, scale_b=st.scale, bias=b, out_dtype=torch.bfloat16)
+
+
+def fp8_linear_q(xq: torch.Tensor, sx: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """:func:`fp8_linear` on an input its producer already wrote as e4m3 (``xq`` with scale ``sx``)."""
+    st = state_for(w)
+    return torch._scaled_mm(xq, st.wq.t(), scale_a=sx, scale_b=st.scale, bias=b, out_dtype=torch.bfloat16)
+
+
+def fp8_dx_q(gq: torch.Tensor, sg: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """:func:`fp8_dx` on a gradient its producer already wrote as e5m2."""
+    st = state_for(w)
+    return torch._scaled_mm(gq, st.wtq.t(), scale_a=sg, scale_b=st.scale, out_dtype=torch.bfloat16)
+
+
+def producer_slots(w: torch.Tensor, role: str, rows: int, width: int, device):
+    """For a kernel about to PRODUCE the [rows, width] bf16 input (role "x") or output gradient (role "g") of frozen weight
+    ``w``: ``(image, fmt, amax_in, amax_out, scale)`` to hand to it so that it writes the fp8 image itself -- or None (mode
+    off, widths the fp8 GEMM does not take, or first use of this role: the consumer then quantises separately)."""
+    if not (_STATE["on"] and w.is_cuda and w.dtype == torch.bfloat16 and not w.requires_grad and rows > 0
+            and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 and not torch.is_autocast_enabled("cuda")):
+        return None
+    st = state_for(w)
+    q = st.qx if role == "x" else st.qg
+    slots = q.begin(device)
+    if slots is None:
+        return None
+    image = torch.empty(rows, width, dtype=q.torch_dtype, device=device)
+    return (image, q.fmt) + slots
 
 
 def fp8_dx(gy2: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

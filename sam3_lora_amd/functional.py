@@ -238,12 +238,26 @@ class TransposedCopy:
         return self.t
 
 
-def _frozen_fwd(x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
-    """The frozen layer's GEMM ``x2 @ w^T + b``: hipBLASLt bf16 / fp32, or the fp8 route of sam3_lora_amd.fp8 when enabled."""
+def _frozen_fwd(x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], x_q8=None) -> torch.Tensor:
+    """The frozen layer's GEMM ``x2 @ w^T + b``: hipBLASLt bf16 / fp32, or the fp8 route of sam3_lora_amd.fp8 when enabled.
+    ``x_q8`` = (e4m3 image of x2, its scale, id of the weight it was made for): x2's producer already quantised it."""
     from . import fp8
     if fp8.eligible(x2, w):
+        if x_q8 is not None and x_q8[2] == id(w) and x_q8[0].shape == x2.shape:
+            return fp8.fp8_linear_q(x_q8[0], x_q8[1], w, b)
         return fp8.fp8_linear(x2, w, b)
     return F.linear(x2, w, b)
+
+
+def _fp8_companion(x: torch.Tensor):
+    """The fp8 image a producing kernel attached to its bf16 output (vit.layer_norm_skip), if any."""
+    return getattr(x, "_sam3_fp8", None)
+
+
+def _hl_q8_ok(lora) -> bool:
+    """The activation-fused adapter passes can carry an fp8 image: hi + lo kernels (rank <= 16, not single-rounded)."""
+    import os
+    return int(getattr(lora, "rank", 99)) <= 16 and os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") in ("", "0")
 
 
 def _dx(gy2: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor]) -> torch.Tensor:
@@ -260,10 +274,10 @@ class _FrozenLinearFn(torch.autograd.Function):
     """``F.linear`` with a frozen weight whose backward uses the transposed copy (no weight / bias gradients)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, wt):
+    def forward(ctx, x, weight, bias, wt, x_q8=None):
         ctx.save_for_backward(weight, wt)
         x2 = x.reshape(-1, x.shape[-1])
-        return _frozen_fwd(x2 if x2.is_contiguous() else x2.contiguous(), weight, bias).view(*x.shape[:-1], weight.shape[0])
+        return _frozen_fwd(x2 if x2.is_contiguous() else x2.contiguous(), weight, bias, x_q8).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, gy):
@@ -271,7 +285,7 @@ class _FrozenLinearFn(torch.autograd.Function):
         gy2 = gy.reshape(-1, gy.shape[-1])
         if not gy2.is_contiguous():
             gy2 = gy2.contiguous()
-        return _dx(gy2, weight, wt).view(*gy.shape[:-1], weight.shape[1]), None, None, None
+        return _dx(gy2, weight, wt).view(*gy.shape[:-1], weight.shape[1]), None, None, None, None
 
 
 def frozen_linear(x: torch.Tensor, lin: torch.nn.Linear, cache: TransposedCopy) -> torch.Tensor:
@@ -292,9 +306,10 @@ def frozen_linear(x: torch.Tensor, lin: torch.nn.Linear, cache: TransposedCopy) 
 
 def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tensor, scaling: float, layout: int,
               save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
-              packed: Optional[torch.Tensor] = None, gelu_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+              packed: Optional[torch.Tensor] = None, gelu_out: Optional[torch.Tensor] = None, q8=None) -> Optional[torch.Tensor]:
     """In place: y2[M,out] += scaling * (x2[M,in] @ A_c) @ B_c.  Returns the saved-t blob if asked.
-    ``gelu_out`` ([M,out], same dtype): additionally receives GELU(y2) from the same pass (sam3_lora_fwd_act)."""
+    ``gelu_out`` ([M,out], same dtype): additionally receives GELU(y2) from the same pass (sam3_lora_fwd_act).
+    ``q8`` = ``fp8.producer_slots(...)``: GELU(y2) also leaves as an fp8 image (sam3_lora_fwd_act_q8; fp8 frozen-W mode)."""
     lib = _ffi.load()
     _require_cuda(x2, A, B, y2)
     M, fin = x2.shape
@@ -314,18 +329,26 @@ def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tens
             float(drop_p), int(seed), int(offset), dt, ws.data_ptr(), ws.numel(),
             ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
     if gelu_out is None:
+        if q8 is not None:
+            raise LoRAKernelError("sam3_lora_amd: an fp8 image rides on the GELU-fused pass only")
         _ffi.check(lib.sam3_lora_fwd(*args), "sam3_lora_fwd")
     else:
         if gelu_out.dtype != y2.dtype or gelu_out.shape != y2.shape or gelu_out.stride(1) != 1:
             raise LoRAKernelError("sam3_lora_amd: gelu_out must match y in shape and dtype")
-        _ffi.check(lib.sam3_lora_fwd_act(*args, _ffi.ACT_GELU, gelu_out.data_ptr(), gelu_out.stride(0)), "sam3_lora_fwd_act")
+        if q8 is None:
+            _ffi.check(lib.sam3_lora_fwd_act(*args, _ffi.ACT_GELU, gelu_out.data_ptr(), gelu_out.stride(0)), "sam3_lora_fwd_act")
+        else:
+            img, fmt, a_in, a_out, sc = q8
+            _ffi.check(lib.sam3_lora_fwd_act_q8(*args, _ffi.ACT_GELU, gelu_out.data_ptr(), gelu_out.stride(0), img.data_ptr(),
+                                                img.stride(0), int(fmt), a_in.data_ptr(), a_out.data_ptr(), sc.data_ptr()),
+                       "sam3_lora_fwd_act_q8")
     return tT
 
 
 def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor,
               gx2: Optional[torch.Tensor], gA: Optional[torch.Tensor], gB: Optional[torch.Tensor], scaling: float,
               layout: int, accumulate: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
-              packed: Optional[torch.Tensor] = None, gelu_pre: Optional[torch.Tensor] = None) -> None:
+              packed: Optional[torch.Tensor] = None, gelu_pre: Optional[torch.Tensor] = None, q8=None) -> None:
     """In place: gx2 += lora input-grad; gA/gB (fp32, caller layout) = or += the LoRA weight grads.
     ``gelu_pre`` ([M,in]): the pre-activation whose GELU produced x; gx2 leaves multiplied by GELU'(gelu_pre)
     (sam3_lora_bwd_act)."""
@@ -353,11 +376,19 @@ def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A
             1 if accumulate else 0,
             ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
     if gelu_pre is None:
+        if q8 is not None:
+            raise LoRAKernelError("sam3_lora_amd: an fp8 image rides on the GELU'-fused pass only")
         _ffi.check(lib.sam3_lora_bwd(*args), "sam3_lora_bwd")
     else:
         if gx2 is None or gelu_pre.dtype != x2.dtype or gelu_pre.shape != x2.shape or gelu_pre.stride(1) != 1:
             raise LoRAKernelError("sam3_lora_amd: gelu_pre must match x in shape and dtype, and gx is required")
-        _ffi.check(lib.sam3_lora_bwd_act(*args, _ffi.ACT_GELU, gelu_pre.data_ptr(), gelu_pre.stride(0)), "sam3_lora_bwd_act")
+        if q8 is None:
+            _ffi.check(lib.sam3_lora_bwd_act(*args, _ffi.ACT_GELU, gelu_pre.data_ptr(), gelu_pre.stride(0)), "sam3_lora_bwd_act")
+        else:       # gx2 (the pre-activation gradient) also leaves as an fp8 image for the next input-gradient GEMM
+            img, fmt, a_in, a_out, sc = q8
+            _ffi.check(lib.sam3_lora_bwd_act_q8(*args, _ffi.ACT_GELU, gelu_pre.data_ptr(), gelu_pre.stride(0), img.data_ptr(),
+                                                img.stride(0), int(fmt), a_in.data_ptr(), a_out.data_ptr(), sc.data_ptr()),
+                       "sam3_lora_bwd_act_q8")
 
 
 def merge_weight(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float, layout: int) -> torch.Tensor:
@@ -550,18 +581,23 @@ class _LoRAMlpFn(torch.autograd.Function):
     instead of being elementwise kernels of their own.  Saved: x, the pre-activation h, a = GELU(h), the two t^T."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, A1, B1, s1, W2, b2, A2, B2, s2, layout, drop_p, seed1, seed2, pk1, pk2, Wt1=None, Wt2=None):
+    def forward(ctx, x, W1, b1, A1, B1, s1, W2, b2, A2, B2, s2, layout, drop_p, seed1, seed2, pk1, pk2, Wt1=None, Wt2=None,
+                x_q8=None, q8_ok=False):
         _require_cuda(x, W1, W2, A1, B1, A2, B2)
+        from . import fp8
         cdt = W1.dtype
         x2 = _rows(x if x.dtype == cdt else x.to(cdt))
         need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
         with torch.autocast("cuda", enabled=False):
-            h = _frozen_fwd(x2, W1, b1)
+            h = _frozen_fwd(x2, W1, b1, x_q8)
         a = torch.empty_like(h)
+        # fp8 frozen-W mode: GELU(h) leaves the adapter pass as bf16 (for fc2's adapter) AND as the e4m3 input of fc2's GEMM
+        qa = fp8.producer_slots(W2, "x", h.shape[0], h.shape[1], h.device) if (q8_ok and h.dtype == torch.bfloat16) else None
         t1 = lora_fwd_(x2, _master(A1), _master(B1), h, s1, layout, save_t=need_w, drop_p=drop_p, seed=seed1, packed=pk1,
-                       gelu_out=a)
+                       gelu_out=a, q8=qa)
         with torch.autocast("cuda", enabled=False):
-            y = _frozen_fwd(a, W2, b2)
+            y = fp8.fp8_linear_q(qa[0], qa[4], W2, b2) if qa is not None else _frozen_fwd(a, W2, b2)
+        ctx.q8_ok = q8_ok
         t2 = lora_fwd_(a, _master(A2), _master(B2), y, s2, layout, save_t=need_w, drop_p=drop_p, seed=seed2, packed=pk2)
         ctx.meta = (s1, s2, layout, drop_p, seed1, seed2, x.shape, x.dtype)
         ctx.pk = (pk1, pk2)
@@ -587,25 +623,30 @@ class _LoRAMlpFn(torch.autograd.Function):
             _note_direct(A1, B1, A2, B2)
         else:
             gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
+        from . import fp8
         with torch.autocast("cuda", enabled=False):
             ga = _dx(gy2, W2, ctx.wt[1])                             # frozen GEMM
-        # fc2's adapter backward; its in-place pass over ga also applies GELU'(h): ga leaves as gh
+        # fc2's adapter backward; its in-place pass over ga also applies GELU'(h): ga leaves as gh -- and, in the fp8 frozen-W
+        # mode, as the e5m2 input of fc1's input-gradient GEMM
+        qg = None
+        if need_x and ctx.q8_ok and drop_p == 0.0 and ga.dtype == torch.bfloat16:
+            qg = fp8.producer_slots(W1, "g", ga.shape[0], ga.shape[1], ga.device)
         lora_bwd_(gy2, a, t2, A2m, B2m, ga, gA2, gB2, s2, layout, accumulate=direct, drop_p=drop_p, seed=seed2, packed=pk2,
-                  gelu_pre=h)
+                  gelu_pre=h, q8=qg)
         gx2 = None
         if need_x:
             with torch.autocast("cuda", enabled=False):
-                gx2 = _dx(ga, W1, ctx.wt[0])                         # frozen GEMM
+                gx2 = fp8.fp8_dx_q(qg[0], qg[4], W1) if qg is not None else _dx(ga, W1, ctx.wt[0])     # frozen GEMM
         if need_x or need_w:
             lora_bwd_(ga, x2, t1, A1m, B1m, gx2, gA1, gB1, s1, layout, accumulate=direct, drop_p=drop_p, seed=seed1, packed=pk1)
         gx = gx2.view(x_shape).to(x_dtype) if need_x else None
         if direct:
             z = _zero_grad_like
             return (gx, None, None, z(A1), z(B1), None, None, None, z(A2), z(B2), None, None, None, None, None, None, None,
-                    None, None)
+                    None, None, None, None)
         g = lambda t, p, i: (t.to(p.dtype) if (t is not None and ctx.needs_input_grad[i]) else None)
         return (gx, None, None, g(gA1, A1, 3), g(gB1, B1, 4), None, None, None, g(gA2, A2, 8), g(gB2, B2, 9), None, None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool, wt_caches=None) -> Optional[torch.Tensor]:
@@ -628,8 +669,10 @@ def lora_mlp_gelu(x: torch.Tensor, fc1, fc2, layout: int, training: bool, wt_cac
     pk2 = l2._packed.get(l2.lora_A, l2.lora_B, int(layout), W1.dtype)
     Wt1 = wt_caches[0].get(W1) if wt_caches is not None else None
     Wt2 = wt_caches[1].get(W2) if wt_caches is not None else None
+    from . import fp8
+    q8_ok = fp8.fp8_enabled() and _hl_q8_ok(l1) and _hl_q8_ok(l2)
     return _LoRAMlpFn.apply(x, W1, b1, l1.lora_A, l1.lora_B, float(l1.scaling), W2, b2, l2.lora_A, l2.lora_B,
-                            float(l2.scaling), int(layout), p, seed1, seed2, pk1, pk2, Wt1, Wt2)
+                            float(l2.scaling), int(layout), p, seed1, seed2, pk1, pk2, Wt1, Wt2, _fp8_companion(x), q8_ok)
 
 
 def lora_linear(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], A: torch.Tensor,

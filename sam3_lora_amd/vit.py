@@ -298,7 +298,9 @@ class _FrozenLayerNorm(torch.autograd.Function):
     the fp32 row statistics; no parameter gradients are produced."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, q8=None):
+        """``q8`` = ``fp8.producer_slots(...)`` of the frozen GEMM that consumes the output: its e4m3 image is written by the
+        same pass (fp8 frozen-W mode, ``sam3_vit_layernorm_fwd_q8``)."""
         import ctypes
         from . import _ffi
         lib = _ffi.load()
@@ -309,9 +311,15 @@ class _FrozenLayerNorm(torch.autograd.Function):
         y = torch.empty_like(x2)
         stats = torch.empty(2, M, device=x.device, dtype=torch.float32)
         dt = 0 if x.dtype == torch.bfloat16 else 1
-        rc = lib.sam3_vit_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
-                                        stats[1].data_ptr(), M, C, float(eps), dt,
-                                        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        if q8 is not None and dt == 0:
+            img, fmt, a_in, a_out, sc = q8
+            rc = lib.sam3_vit_layernorm_fwd_q8(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                               stats[1].data_ptr(), M, C, float(eps), dt, img.data_ptr(), img.stride(0), int(fmt),
+                                               a_in.data_ptr(), a_out.data_ptr(), sc.data_ptr(), st)
+        else:
+            rc = lib.sam3_vit_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                            stats[1].data_ptr(), M, C, float(eps), dt, st)
         if rc != 0:
             raise RuntimeError(f"sam3_vit_layernorm_fwd failed ({rc})")
         ctx.save_for_backward(x2, weight, stats)
@@ -333,7 +341,7 @@ class _FrozenLayerNorm(torch.autograd.Function):
                                         ctypes.c_void_p(torch.cuda.current_stream(gy.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"sam3_vit_layernorm_bwd failed ({rc})")
-        return gx.view(shape), None, None, None
+        return gx.view(shape), None, None, None, None
 
 
 class _FrozenLayerNormSkip(torch.autograd.Function):
@@ -342,8 +350,8 @@ class _FrozenLayerNormSkip(torch.autograd.Function):
     sum of the two gradients to a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
-        y = _FrozenLayerNorm.forward(ctx, x, weight, bias, eps)
+    def forward(ctx, x, weight, bias, eps, q8=None):
+        y = _FrozenLayerNorm.forward(ctx, x, weight, bias, eps, q8)
         return x.view_as(x), y
 
     @staticmethod
@@ -354,7 +362,7 @@ class _FrozenLayerNormSkip(torch.autograd.Function):
         x2, weight, stats = ctx.saved_tensors
         M, C, dt, shape = ctx.meta
         if gy is None:
-            return gskip, None, None, None
+            return gskip, None, None, None, None
         gy2 = gy.reshape(M, C)
         gy2 = gy2 if gy2.is_contiguous() else gy2.contiguous()
         add = None
@@ -367,7 +375,7 @@ class _FrozenLayerNormSkip(torch.autograd.Function):
                                             M, C, dt, ctypes.c_void_p(torch.cuda.current_stream(gy.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"sam3_vit_layernorm_bwd_add failed ({rc})")
-        return gx.view(shape), None, None, None
+        return gx.view(shape), None, None, None, None
 
 
 def _ln_fast(norm: nn.Module, x: torch.Tensor) -> bool:
@@ -377,18 +385,40 @@ def _ln_fast(norm: nn.Module, x: torch.Tensor) -> bool:
             and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096 and x.numel() > 0 and not torch.is_autocast_enabled("cuda"))
 
 
-def layer_norm_skip(norm: nn.Module, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``(x, norm(x))`` -- use the returned x for the residual so that both gradients meet inside one kernel."""
+def _q8_for(consumer_weight, x: torch.Tensor):
+    """fp8 frozen-W mode: the slots with which the LayerNorm kernel writes the e4m3 image of its output for the frozen GEMM
+    with weight ``consumer_weight`` (None: mode off / not that kind of consumer / first use of the role)."""
+    if consumer_weight is None or x.dtype != torch.bfloat16:
+        return None
+    from . import fp8
+    if not fp8.fp8_enabled():
+        return None
+    C = x.shape[-1]
+    return fp8.producer_slots(consumer_weight, "x", x.numel() // C, C, x.device)
+
+
+def _attach_q8(y: torch.Tensor, q8, consumer_weight) -> torch.Tensor:
+    if q8 is not None:       # read by functional.frozen_linear / lora_mlp_gelu when y reaches the consumer unchanged
+        y._sam3_fp8 = (q8[0], q8[4], id(consumer_weight))
+    return y
+
+
+def layer_norm_skip(norm: nn.Module, x: torch.Tensor, consumer_weight=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(x, norm(x))`` -- use the returned x for the residual so that both gradients meet inside one kernel.
+    ``consumer_weight``: the frozen weight of the Linear the normalised tensor feeds (fp8 frozen-W mode, see `_q8_for`)."""
     if _ln_fast(norm, x) and x.requires_grad and torch.is_grad_enabled():
-        return _FrozenLayerNormSkip.apply(x, norm.weight, norm.bias, norm.eps)
-    return x, layer_norm(norm, x)
+        q8 = _q8_for(consumer_weight, x)
+        xs, y = _FrozenLayerNormSkip.apply(x, norm.weight, norm.bias, norm.eps, q8)
+        return xs, _attach_q8(y, q8, consumer_weight)
+    return x, layer_norm(norm, x, consumer_weight)
 
 
-def layer_norm(norm: nn.Module, x: torch.Tensor) -> torch.Tensor:
+def layer_norm(norm: nn.Module, x: torch.Tensor, consumer_weight=None) -> torch.Tensor:
     """``norm(x)``; an ``nn.LayerNorm`` over the last dimension whose parameters are frozen and share x's dtype runs
     on the HIP kernels, everything else (Identity, trainable or mixed-dtype norms, CPU) on the module itself."""
     if _ln_fast(norm, x):
-        return _FrozenLayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+        q8 = _q8_for(consumer_weight, x)
+        return _attach_q8(_FrozenLayerNorm.apply(x, norm.weight, norm.bias, norm.eps, q8), q8, consumer_weight)
     return norm(x)
 
 
@@ -440,12 +470,12 @@ class Block(nn.Module):
         if self._fused_windows(x):
             # window blocks without partition / unpartition copies: rows stay in image order through norm1 and qkv,
             # the qkv-split/RoPE kernel gathers them into windows, and the residual add scatters them back
-            xs, h = layer_norm_skip(self.norm1, x)
+            xs, h = layer_norm_skip(self.norm1, x, self._qkv_weight())
             hw = self.attn.forward_windows(h, self.window_size)
             x = _WinResidual.apply(xs, hw, self._drop_path_scale(x), self.window_size)
-            xs, h = layer_norm_skip(self.norm2, x)
+            xs, h = layer_norm_skip(self.norm2, x, self._fc1_weight())
             return self._residual(xs, self.mlp(h))
-        xs, h = layer_norm_skip(self.norm1, x)
+        xs, h = layer_norm_skip(self.norm1, x, self._qkv_weight() if self.window_size == 0 else None)
         if self.window_size > 0:
             H, W = h.shape[1], h.shape[2]
             h, pad_hw = window_partition(h, self.window_size)
@@ -453,8 +483,20 @@ class Block(nn.Module):
         if self.window_size > 0:
             h = window_unpartition(h, self.window_size, pad_hw, (H, W))
         x = self._residual(xs, h)
-        xs, h = layer_norm_skip(self.norm2, x)
+        xs, h = layer_norm_skip(self.norm2, x, self._fc1_weight())
         return self._residual(xs, self.mlp(h))
+
+    def _qkv_weight(self):
+        """The frozen weight norm1's output feeds directly (fp8 frozen-W mode: LayerNorm then writes its e4m3 image)."""
+        q = self.attn.qkv
+        return q.weight if type(q) is nn.Linear and not q.weight.requires_grad else None
+
+    def _fc1_weight(self):
+        ad = self.mlp._adapted() if isinstance(self.mlp, Mlp) else None
+        if ad is not None:
+            return ad[1][0]
+        f1 = getattr(self.mlp, "fc1", None)
+        return f1.weight if type(f1) is nn.Linear and not f1.weight.requires_grad else None
 
     def _drop_path_scale(self, x: torch.Tensor) -> Optional[torch.Tensor]:
         """fp32 [B]: Bernoulli(keep) / keep per image while stochastic depth is active, else None."""

@@ -77,3 +77,112 @@ def test_fp8_frozen_linears_track_the_bf16_build():
     assert not torch.equal(got[0], ref[0])
     again = run()
     assert all(torch.equal(a, b) for a, b in zip(again, ref))
+
+
+def _slot_state(amax_value):
+    from sam3_lora_amd import _ffi
+    amax = torch.zeros(2, _ffi.FP8_AMAX_SLOTS, device=DEV)
+    amax[0, 5] = amax_value                       # any slot: the reader takes the maximum
+    return amax, torch.empty(1, device=DEV)
+
+
+@pytest.mark.parametrize("fmt", ["e4m3", "e5m2"])
+def test_producers_write_the_image_the_separate_quantiser_would(fmt):
+    """The fp8 image a producing kernel writes beside its bf16 output (LayerNorm forward; the GELU- and GELU'-fused adapter
+    passes) == torch's cast of that bf16 output at the delayed scale, bit for bit; the gathered amax == max |output|."""
+    import ctypes
+    from sam3_lora_amd import _ffi
+    from sam3_lora_amd import functional as Fn
+    from sam3_lora_amd import vit as V
+    tdt, code, fmax = (torch.float8_e4m3fn, _ffi.FP8_E4M3, 448.0) if fmt == "e4m3" else (torch.float8_e5m2, _ffi.FP8_E5M2, 57344.0)
+    g = torch.Generator(device=DEV).manual_seed(1)
+
+    def expect(t, amax_prev):
+        return (t.float() * (fmax / amax_prev)).clamp(-fmax, fmax).to(tdt).view(torch.uint8)
+
+    # LayerNorm
+    M, C = 1000, 1024
+    x = torch.randn(M, C, device=DEV, generator=g).bfloat16()
+    w, b = (1 + 0.1 * torch.randn(C, device=DEV, generator=g)).bfloat16(), (0.1 * torch.randn(C, device=DEV, generator=g)).bfloat16()
+    amax, scale = _slot_state(3.0)
+    img = torch.empty(M, C, dtype=tdt, device=DEV)
+    y = V._FrozenLayerNorm.apply(x, w, b, 1e-5, (img, code, amax[0], amax[1], scale))
+    y_plain = V._FrozenLayerNorm.apply(x, w, b, 1e-5)
+    assert torch.equal(y, y_plain)
+    assert torch.equal(img.view(torch.uint8), expect(y, 3.0)) and torch.allclose(scale, torch.tensor([3.0 / fmax], device=DEV))
+    assert float(amax[1].max()) == float(y.float().abs().max())
+    # adapter forward with GELU: the image is GELU(y)'s
+    M, fin, fout, r = 777, 264, 520, 16
+    xa = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    base = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    A, B = torch.randn(fin, r, device=DEV, generator=g) / 16, torch.randn(r, fout, device=DEV, generator=g) / 4
+    yq, act = base.clone(), torch.empty_like(base)
+    amax, scale = _slot_state(2.0)
+    img = torch.empty(M, fout, dtype=tdt, device=DEV)
+    Fn.lora_fwd_(xa, A, B, yq, 2.0, 0, gelu_out=act, q8=(img, code, amax[0], amax[1], scale))
+    y0, act0 = base.clone(), torch.empty_like(base)
+    Fn.lora_fwd_(xa, A, B, y0, 2.0, 0, gelu_out=act0)
+    assert torch.equal(yq, y0) and torch.equal(act, act0)
+    assert torch.equal(img.view(torch.uint8), expect(act, 2.0)) and float(amax[1].max()) == float(act.float().abs().max())
+    # adapter backward with GELU': the image is the pre-activation gradient's
+    gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    h = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    gbase = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    res = []
+    for q8 in (None, "q8"):
+        gx = gbase.clone()
+        gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+        amax, scale = _slot_state(5.0)
+        img = torch.empty(M, fin, dtype=tdt, device=DEV)
+        Fn.lora_bwd_(gy, xa, None, A, B, gx, gA, gB, 2.0, 0, gelu_pre=h, q8=(img, code, amax[0], amax[1], scale) if q8 else None)
+        res.append((gx, gA, gB))
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    assert torch.equal(img.view(torch.uint8), expect(res[1][0], 5.0)) and float(amax[1].max()) == float(res[1][0].float().abs().max())
+    # refused where the image cannot ride: rank > 16, dropout on the input gradient
+    A32, B32 = torch.randn(fin, 32, device=DEV) / 16, torch.randn(32, fout, device=DEV) / 4
+    with pytest.raises(Fn.LoRAKernelError):
+        Fn.lora_fwd_(xa, A32, B32, base.clone(), 2.0, 0, gelu_out=torch.empty_like(base), q8=(img, code, amax[0], amax[1], scale))
+
+
+def test_fused_and_separate_quantisation_give_the_same_training_steps(monkeypatch):
+    """A trunk block (LayerNorm -> attention -> LayerNorm -> LoRA MLP) stepped three times in the fp8 frozen-W mode with the
+    producers writing the fp8 images themselves (from the second step on: the first calibrates) and with every image made by
+    the separate quantiser: outputs and gradients bit-identical -- same values, same delayed scales, fewer passes."""
+    import lora_layers as L
+    from sam3_lora_amd import fp8
+    from sam3_lora_amd import vit as V
+
+    def run(fused):
+        torch.manual_seed(0)
+        blk = V.Block(256, 4, 4.0, True, 0.0, window_size=0, input_size=(8, 8), rope_pt_size=(8, 8), rope_interp=False)
+        blk.mlp.fc1, blk.mlp.fc2 = L.LoRALinear(blk.mlp.fc1, rank=8, alpha=16), L.LoRALinear(blk.mlp.fc2, rank=8, alpha=16)
+        with torch.no_grad():
+            blk.mlp.fc1.lora.lora_B.normal_(0, 0.02), blk.mlp.fc2.lora.lora_B.normal_(0, 0.02)
+        blk.to(DEV)
+        for n, p in blk.named_parameters():
+            if "lora_" not in n:
+                p.requires_grad_(False)
+                p.data = p.data.to(torch.bfloat16)
+        if not fused:
+            monkeypatch.setattr(fp8, "producer_slots", lambda *a, **k: None)
+        fp8.enable_fp8_frozen(True)
+        outs = []
+        try:
+            x = torch.randn(4, 8, 8, 256, device=DEV).bfloat16()
+            for step in range(3):
+                for p in blk.parameters():
+                    p.grad = None
+                xi = (x * (1 + 0.1 * step)).requires_grad_(True)
+                y = blk(xi)
+                (y.float() ** 2).mean().backward()
+                outs.append((y.detach().clone(), xi.grad.clone(), blk.mlp.fc1.lora.lora_A.grad.clone(), blk.mlp.fc2.lora.lora_B.grad.clone()))
+        finally:
+            fp8.enable_fp8_frozen(False)
+            monkeypatch.undo()
+        return outs
+
+    a, b = run(True), run(False)
+    for sa, sb in zip(a, b):
+        for u, v in zip(sa, sb):
+            assert torch.equal(u, v)
+    assert not torch.equal(a[0][0], a[1][0])

@@ -224,10 +224,10 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     path = build.build_library()
     assert os.path.exists(path)
     hdr = open(os.path.join(build.INCLUDE, "sam3_lora_amd.h")).read()
-    declared = set(re.findall(r"\b(sam3_lora_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(sam3_lora_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
     vit_hdr = open(os.path.join(build.INCLUDE, "sam3_vit_amd.h")).read()
-    vit_declared = set(re.findall(r"\b(sam3_vit_[a-z_]+)\s*\(", vit_hdr))
+    vit_declared = set(re.findall(r"\b(sam3_vit_[a-z0-9_]+)\s*\(", vit_hdr))
     assert vit_declared == set(_ffi.VIT_EXPORTS), vit_declared ^ set(_ffi.VIT_EXPORTS)
     loss_hdr = open(os.path.join(build.INCLUDE, "sam3_loss_amd.h")).read()
     loss_declared = set(re.findall(r"\b(sam3_(?:loss|mask_loss|box_pair)_[a-z_]+)\s*\(", loss_hdr))

@@ -335,6 +335,7 @@ def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True)
         matcher = wrapper
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=wd)
     m = {"losses": [], "outputs": {}, "loss_terms": {}, "grads": {}}
+    raw = {}
     for step in range(steps):
         outputs = model(batch)
         targets = [model.back_convert(t) for t in batch.find_targets]
@@ -347,6 +348,7 @@ def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True)
             for k in ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks", "queries", "encoder_hidden_states"):
                 ref = gold[f"lora/{k}"]
                 a = out[k].detach().float().cpu().numpy()
+                raw[k] = a
                 if a.shape != ref.shape:
                     a = a[:, :ref.shape[1]] if a.ndim == 4 else a[::8]
                 m["outputs"][k] = float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12))
@@ -367,7 +369,44 @@ def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True)
         m["losses"].append(loss_dict["core_loss"].item())
     ref = gold["losses"][:steps]
     m["loss_curve_rel"] = [float(v) for v in np.abs(np.array(m["losses"]) - ref) / np.abs(ref)]
+    run_training_steps.last_raw = raw           # first-step output tensors (numpy) of the latest run, for build-vs-build checks
     return m
+
+
+@pytest.mark.gpu
+def test_fp8_frozen_whole_model_step_tracks_the_bf16_build(gold_wide):
+    """BASELINE configs[4]'s mode on the whole (wide-fixture) model: frozen base GEMMs in fp8 (e4m3 weights / activations,
+    e5m2 gradients; every Linear whose widths are multiples of 16), adapters bf16 / fp32 as always, against the SAME model in
+    the bf16 layout -- there is no reference for fp8.  Stated bounds: first-step pred_logits / pred_boxes
+    within 0.15 of max |.| (e4m3 keeps 3 mantissa bits: 2^-4 per element, averaged over K), the four-step loss curve within
+    5 %, matcher indices of the first step identical, everything finite; the numbers are recorded."""
+    from sam3_lora_amd import fp8
+    from sam3_lora_amd.trainer import move_to_device
+    from sam3_lora_amd.vit import to_training_layout
+    dev = torch.device("cuda")
+    res = {}
+    for mode in ("bf16", "fp8"):
+        model = build_wide(gold_wide, act_checkpoint=False, match_in_forward=False)
+        layers = _inject(model, gold_wide, D.LORA_WIDE)
+        model.to(dev).train()
+        to_training_layout(model)
+        fp8.enable_fp8_frozen(mode == "fp8")
+        try:
+            m = run_training_steps(model, layers, gold_wide, move_to_device(make_batch_wide(), dev), D.STEPS, D.LR_WIDE, D.WD)
+            n_fp8 = len(fp8._WEIGHTS)
+        finally:
+            fp8.enable_fp8_frozen(False)
+        res[mode] = (m, dict(run_training_steps.last_raw), n_fp8)
+    (mb, rb, _), (mf, rf, n_fp8) = res["bf16"], res["fp8"]
+    assert n_fp8 >= 40, n_fp8                                   # the trunk's qkv / proj / fc1 / fc2 and the DETR FFNs took the fp8 route
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+    rec = {"fp8_linears": n_fp8, "pred_logits": rel(rf["pred_logits"], rb["pred_logits"]), "pred_boxes": rel(rf["pred_boxes"], rb["pred_boxes"]),
+           "losses_fp8": mf["losses"], "losses_bf16": mb["losses"],
+           "loss_curve_rel": [abs(a - b) / abs(b) for a, b in zip(mf["losses"], mb["losses"])], "indices_equal": mf["indices_equal"]}
+    _record("fp8_vs_bf16_wide", rec)
+    assert all(np.isfinite(mf["losses"])) and mf["indices_equal"]
+    assert rec["pred_logits"] <= 0.15 and rec["pred_boxes"] <= 0.15, rec
+    assert max(rec["loss_curve_rel"]) <= 0.05, rec
 
 
 def _record(name, m):
