@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_fp8_quantize(const XT* __restrict__ x, 
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = seen;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float m = q8_nanmax(q8_nanmax(wmax[0], wmax[1]), q8_nanmax(wmax[2], wmax[3]));   // NaN's bit pattern outranks every finite amax
+        const float m = q8_nanmax(q8_nanmax(wmax[0], wmax[1]), q8_nanmax(wmax[2], wmax[3]));
         atomicMax(reinterpret_cast<unsigned*>(amax_out) + (blockIdx.x & (SAM3_FP8_AMAX_SLOTS - 1)), __float_as_uint(m));
     }
 }

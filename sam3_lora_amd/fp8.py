@@ -71,7 +71,8 @@ class Fp8Quantizer:
         if self.amax is None or self.amax.device != x2.device:
             self.amax = torch.zeros(2, _ffi.FP8_AMAX_SLOTS, device=x2.device)
             self.scale = torch.empty(1, device=x2.device)
-            self.amax[0, 0] = x2.detach().abs().max().float()         # first call: calibrate on the tensor itself
+            # first call: calibrate on the tensor itself (finite values only, as the kernels' running amax)
+            self.amax[0, 0] = torch.nan_to_num(x2.detach().abs().float(), nan=0.0, posinf=0.0).max()
             self.k = 0
         cur, nxt = self.amax[self.k], self.amax[1 - self.k]
         nxt.zero_()

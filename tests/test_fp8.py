@@ -186,3 +186,23 @@ def test_fused_and_separate_quantisation_give_the_same_training_steps(monkeypatc
         for u, v in zip(sa, sb):
             assert torch.equal(u, v)
     assert not torch.equal(a[0][0], a[1][0])
+
+
+def test_non_finite_elements_keep_their_encoding_and_stay_out_of_the_amax():
+    """A NaN element leaves as NaN (a diverged step still shows), but neither NaN nor Inf enters the running amax: tensors carry
+    non-finite values in positions nobody reads (fully masked softmax rows, padded keys), and a NaN amax would turn the next
+    call's scale -- hence the whole tensor -- into NaN."""
+    from sam3_lora_amd import _ffi
+    from sam3_lora_amd.fp8 import Fp8Quantizer
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(64, 1024, device=DEV, generator=g).bfloat16()
+    x[3, 5], x[7, 9], x[9, 1] = float("nan"), float("inf"), 30.0
+    q = Fp8Quantizer(_ffi.FP8_E4M3)
+    out, scale = q(x)
+    assert torch.allclose(scale, torch.tensor([30.0 / 448.0], device=DEV))
+    f = out.float()
+    assert torch.isnan(f[3, 5]) and f[7, 9] == 448.0 and int(torch.isnan(f).sum()) == 1
+    out2, scale2 = q(x * 0.5)                       # scaled with the amax gathered above: finite
+    assert torch.allclose(scale2, torch.tensor([30.0 / 448.0], device=DEV)) and torch.isfinite(scale2).all()
+    out3, scale3 = q(x)
+    assert torch.allclose(scale3, torch.tensor([15.0 / 448.0], device=DEV))
