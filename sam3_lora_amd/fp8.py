@@ -17,6 +17,7 @@ Linears whose widths are multiples of 16 take the fp8 route, everything else kee
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -146,6 +147,8 @@ def producer_slots(w: torch.Tensor, role: str, rows: int, width: int, device):
     """For a kernel about to PRODUCE the [rows, width] bf16 input (role "x") or output gradient (role "g") of frozen weight
     ``w``: ``(image, fmt, amax_in, amax_out, scale)`` to hand to it so that it writes the fp8 image itself -- or None (mode
     off, widths the fp8 GEMM does not take, or first use of this role: the consumer then quantises separately)."""
+    if os.environ.get("SAM3_FP8_SEPARATE_QUANT") == "1":      # A/B knob: every image by the stand-alone quantiser
+        return None
     if not (_STATE["on"] and w.is_cuda and w.dtype == torch.bfloat16 and not w.requires_grad and rows > 0
             and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 and not torch.is_autocast_enabled("cuda")):
         return None
