@@ -21,17 +21,23 @@ extern "C" {
 
 #define SAM3_FP8_E4M3 0   /* OCP e4m3fn, max 448   (activations, weights)   */
 #define SAM3_FP8_E5M2 1   /* OCP e5m2,   max 57344 (gradients)              */
-/* amax state of one tensor role: an array of this many floats; a writer updates ONE slot (one atomic per workgroup / wave,
- * spread over the slots), a reader takes the maximum of all of them */
+/* amax state of one tensor role: SAM3_FP8_AMAX_SLOTS slots, slot s at float index s * SAM3_FP8_AMAX_STRIDE (one 128-byte line
+ * per slot: atomics on the same line serialise like atomics on the same address) -- an array of SAM3_FP8_AMAX_FLOATS floats.
+ * A writer raises ONE slot (at most one atomic per workgroup / wave, spread over the slots), a reader takes the maximum of
+ * all of them; the floats between the slots are never read or written by the kernels. */
 #define SAM3_FP8_AMAX_SLOTS 64
+#define SAM3_FP8_AMAX_STRIDE 32
+#define SAM3_FP8_AMAX_FLOATS (SAM3_FP8_AMAX_SLOTS * SAM3_FP8_AMAX_STRIDE)
 
 const char* sam3_fp8_last_error(void);
 
 /*
  *   scale      = max(max_s amax_in[s], 2^-24) / fmt_max              (written to *scale_out: the dequantisation factor)
- *   out[i]     = fp8( clamp(x[i] / scale, -fmt_max, fmt_max) )       round-to-nearest-even, saturating; NaN stays NaN
- *   amax_out[s] = max(amax_out[s], max_i |x[i]| over the elements slot s's workgroups saw)      (caller zeroes it beforehand)
- * amax_in / amax_out: SAM3_FP8_AMAX_SLOTS floats each.  x: n elements, bf16 (src_dtype 0) or fp32 (1), 16-byte aligned,
+ *   out[i]     = fp8( x[i] / scale )       round-to-nearest-even; a finite value beyond the format's range saturates to
+ *                                          +-fmt_max; NaN stays NaN; +-Inf leaves as the format's non-finite encoding
+ *                                          (e5m2: Inf; e4m3fn has none: NaN)
+ *   amax_out[slot s] = max(amax_out[slot s], max_i |x[i]| over the FINITE elements slot s's workgroups saw)   (caller zeroes it)
+ * amax_in / amax_out: SAM3_FP8_AMAX_FLOATS floats each (layout above).  x: n elements, bf16 (src_dtype 0) or fp32 (1), 16-byte aligned,
  * n % 16 == 0.  out: n bytes, 16-byte aligned.
  *
  * The same protocol is carried by the PRODUCING kernels of this library, which then write the fp8 image beside their bf16

@@ -41,6 +41,8 @@ SEG_EXPORTS = ("sam3_seg_last_error", "sam3_gn_nhwc_supported", "sam3_gn_nhwc_wo
                "sam3_gn_nhwc_bwd", "sam3_rpb_bias_fwd")                                             # include/sam3_seg_amd.h
 FP8_E4M3, FP8_E5M2 = 0, 1
 FP8_AMAX_SLOTS = 64            # SAM3_FP8_AMAX_SLOTS
+FP8_AMAX_STRIDE = 32           # SAM3_FP8_AMAX_STRIDE: floats between two slots (one 128-byte line per slot)
+FP8_AMAX_FLOATS = FP8_AMAX_SLOTS * FP8_AMAX_STRIDE
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
 
 _lib = None

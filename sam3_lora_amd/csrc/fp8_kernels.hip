@@ -45,17 +45,17 @@ __global__ __launch_bounds__(256) void k_fp8_quantize(const XT* __restrict__ x, 
                                                       const float* __restrict__ amax_in, float* __restrict__ amax_out,
                                                       float* __restrict__ scale_out, long long n16) {
     const Q8Out o{out, 0, amax_in, amax_out, scale_out, FMT};
-    const Q8Scale sc = q8_begin(o, blockIdx.x == 0 && threadIdx.x == 0);
+    const Q8Scale sc = q8_begin(o, blockIdx.x == 0 && threadIdx.x == 0, blockIdx.x);
     float seen = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
         float v[16];
         load16(x + i * 16, v);
         unsigned w[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = q8_pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], sc, FMT, seen);
+        for (int q = 0; q < 4; ++q) w[q] = q8_pack4<FMT>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], sc, seen);
         *reinterpret_cast<uint4*>(out + i * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    // one atomic per WORKGROUP, spread over the amax slots
+    // at most one atomic per WORKGROUP, spread over the amax slots
     __shared__ float wmax[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) seen = q8_nanmax(seen, __shfl_down(seen, off, 64));
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_fp8_quantize(const XT* __restrict__ x, 
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = q8_nanmax(q8_nanmax(wmax[0], wmax[1]), q8_nanmax(wmax[2], wmax[3]));
-        atomicMax(reinterpret_cast<unsigned*>(amax_out) + (blockIdx.x & (SAM3_FP8_AMAX_SLOTS - 1)), __float_as_uint(m));
+        q8_raise_slot(amax_out, m, blockIdx.x, sc.have);
     }
 }
 

@@ -491,11 +491,11 @@ struct YTile<bf16_t> {
         }
     }
     // Q8: the tensor the NEXT frozen GEMM consumes (ACT == 1: act(y); ACT == 2: the updated gradient) also leaves as fp8
-    template <bool FAST, bool DROP, int ACT, bool Q8 = false>
+    template <bool FAST, bool DROP, int ACT, bool Q8 = false, int QF = 0>
     __device__ __forceinline__ void add_store(bf16_t* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
                                               const DropKey& dk, bf16_t* AUX, long long ldaux, const YTile<bf16_t>& haux,
-                                              const Q8Out* q8 = nullptr, const Q8Scale* qs = nullptr, float* seen = nullptr) {
+                                              const Q8Out* q8 = nullptr, const Q8Scale* qs = nullptr, unsigned* seen = nullptr) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
@@ -517,9 +517,7 @@ struct YTile<bf16_t> {
                 if (ok) stg16(AUX + m * ldaux + col, a8);
             }
             if (Q8 && ok) {         // the bf16-ROUNDED values, as a separate quantisation pass over the stored tensor would see them
-                const unsigned w0 = q8_pack4(bf_lo(a8.x), bf_hi(a8.x), bf_lo(a8.y), bf_hi(a8.y), *qs, q8->fmt, *seen);
-                const unsigned w1 = q8_pack4(bf_lo(a8.z), bf_hi(a8.z), bf_lo(a8.w), bf_hi(a8.w), *qs, q8->fmt, *seen);
-                *reinterpret_cast<uint2*>(q8->q + m * q8->ld + col) = make_uint2(w0, w1);
+                *reinterpret_cast<uint2*>(q8->q + m * q8->ld + col) = q8_pack8_bf16<QF>(a8, *qs, *seen);
             }
         }
     }
@@ -539,11 +537,11 @@ struct YTile<float> {
             v[p][1] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    template <bool FAST, bool DROP, int ACT, bool Q8 = false>
+    template <bool FAST, bool DROP, int ACT, bool Q8 = false, int QF = 0>
     __device__ __forceinline__ void add_store(float* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
                                               const DropKey& dk, float* AUX, long long ldaux, const YTile<float>& haux,
-                                              const Q8Out* = nullptr, const Q8Scale* = nullptr, float* = nullptr) {
+                                              const Q8Out* = nullptr, const Q8Scale* = nullptr, unsigned* = nullptr) {
         static_assert(!Q8, "fp8 outputs ride on bf16 tensors only");
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -578,7 +576,7 @@ struct YTile<float> {
 };
 
 // HL (RT == 2): W2t = [hi | lo] of the LoRA operand, T = [hi | lo] of t: delta = hi.t_hi + hi.t_lo + lo.t_hi.
-template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false>
+template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0>
 __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
@@ -598,9 +596,10 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
     const int n = lane & 15, g = lane >> 4;
     float* slab = slab_all[wave];
     const int c0 = blockIdx.x * CW;
-    Q8Scale qs{0.f, 0.f};
-    float seen = 0.f;
-    if (Q8) qs = q8_begin(q8, blockIdx.x == 0 && by == 0 && tid == 0);
+    Q8Scale qs{0.f, 0.f, 0u};
+    unsigned seen = 0u;         // packed running amax (q8_pack8_bf16)
+    const unsigned q8_id = (blockIdx.x + by * gridDim.x) * 4 + wave;
+    if (Q8) qs = q8_begin(q8, blockIdx.x == 0 && by == 0 && tid == 0, q8_id);
 
     // W2^T fragments (MFMA A-operand: i = output column, k = rank index), kept for the whole kernel
     uint2 wlo[8], whi[8];
@@ -668,7 +667,9 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
     const long long t_fast_end = colfull ? min(t_end, nfull) : t_begin;   // tiles with no tail at all
     long long t = t_begin;
     if (t < t_fast_end) {
-        // branch-free stream: tile t+4 (and its t fragment, issued first) is in flight while tile t is updated
+        // branch-free stream: tile t+4 (and its t fragment, issued first) is in flight while tile t is updated.  (TWO tiles
+        // ahead -- 124 VGPRs, the same 4 waves per SIMD, twice the bytes in flight -- measured SLOWER on MI355X: 159 vs 132 us
+        // at N = 4736, profiles/r03j_adapter_sweep.json: this stream is not short of outstanding loads.)
         YTile<YT> cur, nxt, hcur, hnxt;      // hcur/hnxt: the pre-activation tile (ACT == 2 only)
         uint2 tlo, thi, nlo, nhi;
         load_t(t, nlo, nhi);
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
             if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, tn * 16, col, lane, M, N);
             delta_to_slab(tlo, thi);
             wave_sync();
-            cur.template add_store<true, DROP, ACT, Q8>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
+            cur.template add_store<true, DROP, ACT, Q8, QF>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
             wave_sync();
         }
     }
@@ -697,10 +698,10 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
         if (ACT == 2) hcur.template load<false, true>(AUX, ldaux, t * 16, col, lane, M, N);
         delta_to_slab(tlo, thi);
         wave_sync();
-        cur.template add_store<false, DROP, ACT, Q8>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
+        cur.template add_store<false, DROP, ACT, Q8, QF>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
         wave_sync();
     }
-    if (Q8) q8_end_wave(q8, seen, (blockIdx.x + by * gridDim.x) * 4 + wave);
+    if (Q8) q8_end_wave(q8, q8_seen16_to_float(seen), q8_id, qs.have);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -881,19 +882,7 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
         colc[cc] = col < N ? col : N - 8;
         cmask[cc] = col < N ? 0xffffffffu : 0u;
     }
-    // B operand of the gt contraction, per lane: B_c[r = n][c0 + cc*128 + ks*32 + g*8 .. +8]; the same for all four
-    // waves and all row steps -> staged once in LDS in fragment order (32 registers per lane otherwise)
-    __shared__ uint4 wbs[NH * 8][64];        // [half][chunk][ks]
-    if (wave < 2 * NH) {
-        const int cc = wave & 1, h = wave >> 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cb = c0 + cc * 128 + ks * 32 + g * 8;
-            wbs[h * 8 + cc * 4 + ks][lane] =
-                and4(*reinterpret_cast<const uint4*>(W1b + (long long)(h * 16 + n) * N + (cb < N ? cb : N - 8)), cb < N ? 0xffffffffu : 0u);
-        }
-    }
-    __syncthreads();
+    __shared__ uint4 wbs[NH * 8][64];        // [half][chunk][ks]: B operand of the gt contraction, staged below
     struct Regs {
         uint4 t[NH];
         Raw8<XT> x[8];
@@ -932,18 +921,16 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const uint4 xa = slab[row * CPR + ((ks * 4 + g) ^ (t3_h(row) << 1))];
-                // D[i = row][n = rank idx] += sum_col gy[row][col] * B_c[rank idx][col]
+                // D[i = rank idx][n = row] += sum_col B_c[rank idx][col] * gy[row][col]: the transposed product, so that a lane
+                // ends with 4 consecutive rank entries of one row -- one 16-byte store, 1 KB contiguous per wave (the other
+                // operand order left 4-byte stores 64 B apart: 780 K partial-line writes per launch at N = 4736)
 #pragma unroll
                 for (int h = 0; h < NH; ++h)
-                    ga[rtile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa),
-                                                                       __builtin_bit_cast(bf16x8, wbs[h * 8 + cc * 4 + ks][lane]),
-                                                                       ga[rtile], 0, 0, 0);
+                    ga[rtile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wbs[h * 8 + cc * 4 + ks][lane]),
+                                                                       __builtin_bit_cast(bf16x8, xa), ga[rtile], 0, 0, 0);
             }
-            if (cc == 1) {
-                float* gp = GTP + ((long long)blockIdx.x * Mp + mb + rtile * 16 + g * 4) * 16 + n;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) gp[jj * 16] = ga[rtile][jj];
-            }
+            if (cc == 1)
+                *reinterpret_cast<f32x4*>(GTP + ((long long)blockIdx.x * Mp + mb + rtile * 16 + n) * 16 + g * 4) = ga[rtile];
         }
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -964,9 +951,21 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
         }
         wave_sync();
     };
+    Regs rA, rB;                   // rA <-> chunk 0, rB <-> chunk 1; one sub-step of prefetch distance
+    if (nst > 0) gload(0, 0, rA);  // in flight while the B_c fragments are staged
+    // B operand of the gt contraction, per lane: B_c[r = n][c0 + cc*128 + ks*32 + g*8 .. +8]; the same for all four
+    // waves and all row steps -> staged once in LDS in fragment order (32 registers per lane otherwise)
+    if (wave < 2 * NH) {
+        const int cc = wave & 1, h = wave >> 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cb = c0 + cc * 128 + ks * 32 + g * 8;
+            wbs[h * 8 + cc * 4 + ks][lane] =
+                and4(*reinterpret_cast<const uint4*>(W1b + (long long)(h * 16 + n) * N + (cb < N ? cb : N - 8)), cb < N ? 0xffffffffu : 0u);
+        }
+    }
+    __syncthreads();
     if (nst > 0) {
-        Regs rA, rB;               // rA <-> chunk 0, rB <-> chunk 1; one sub-step of prefetch distance
-        gload(0, 0, rA);
         for (int s = 0; s < nst; ++s) {
             gload(s, 1, rB);
             stage(s, 0, rA);
@@ -1374,10 +1373,11 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
     const Q8Out q8 = q8_in ? *q8_in : Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
     if (q8.q) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
-        if (act == 1) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 1, true, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
-                                         (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8);
-        else hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
-                                (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8);
+#define T2_Q8(AV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, AV, true, true, FV>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8)
+        if (act == 1) { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(1, SAM3_FP8_E4M3); else T2_Q8(1, SAM3_FP8_E5M2); }
+        else { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(2, SAM3_FP8_E4M3); else T2_Q8(2, SAM3_FP8_E5M2); }
+#undef T2_Q8
         return;
     }
 #define T2_LAUNCH(RTV, DV, AV, HV) \

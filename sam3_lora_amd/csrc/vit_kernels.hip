@@ -193,16 +193,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Q8 (bf16 only): y also leaves as an fp8 image for the frozen GEMM that consumes it (fp8_common.inc)
-template <typename T, int CPL, bool Q8 = false>
+template <typename T, int CPL, bool Q8 = false, int QF = SAM3_FP8_E4M3>
 __global__ __launch_bounds__(256) void k_ln_fwd(const T* __restrict__ x, const T* __restrict__ gamma,
                                                 const T* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
                                                 float* __restrict__ rstd, long long M, int C, float eps,
                                                 Q8Out q8 = Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0}) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    Q8Scale qs{0.f, 0.f};
-    float seen = 0.f;
-    if (Q8) qs = q8_begin(q8, blockIdx.x == 0 && threadIdx.x == 0);
+    Q8Scale qs{0.f, 0.f, 0u};
+    unsigned seen = 0u;         // packed running amax (q8_pack8_bf16)
+    if (Q8) qs = q8_begin(q8, blockIdx.x == 0 && threadIdx.x == 0, blockIdx.x);
     if (row >= M) return;
     F8 v[CPL];
     float s = 0.f;
@@ -238,14 +238,12 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const T* __restrict__ x, const T
             for (int j = 0; j < 8; ++j) o.v[j] = (v[i].v[j] - mu) * rs * g.v[j] + b.v[j];
             st8(y + row * C + c, o);
             if (Q8) {       // the bf16-ROUNDED values, as a separate quantisation pass over y would see them
-                const unsigned p0 = vpack2(o.v[0], o.v[1]), p1 = vpack2(o.v[2], o.v[3]), p2 = vpack2(o.v[4], o.v[5]), p3 = vpack2(o.v[6], o.v[7]);
-                const unsigned w0 = q8_pack4(vlo(p0), vhi(p0), vlo(p1), vhi(p1), qs, q8.fmt, seen);
-                const unsigned w1 = q8_pack4(vlo(p2), vhi(p2), vlo(p3), vhi(p3), qs, q8.fmt, seen);
-                *reinterpret_cast<uint2*>(q8.q + row * q8.ld + c) = make_uint2(w0, w1);
+                const uint4 p = make_uint4(vpack2(o.v[0], o.v[1]), vpack2(o.v[2], o.v[3]), vpack2(o.v[4], o.v[5]), vpack2(o.v[6], o.v[7]));
+                *reinterpret_cast<uint2*>(q8.q + row * q8.ld + c) = q8_pack8_bf16<QF>(p, qs, seen);
             }
         }
     }
-    if (Q8) q8_end_wave(q8, seen, (unsigned)(blockIdx.x * 4 + (threadIdx.x >> 6)) >> 2);     // 4 waves of a workgroup share a slot
+    if (Q8) q8_end_wave(q8, q8_seen16_to_float(seen), blockIdx.x, qs.have);     // the 4 waves of a workgroup share a slot
 }
 
 // gx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gy * gamma,  xhat = (x - mean) * rstd
@@ -300,13 +298,15 @@ int launch_ln(bool bwd, const void* a, const void* b, const void* gamma, const v
     const dim3 grid((unsigned)((M + 3) / 4));
     const int cpl = (C + 511) / 512;
     if (q8) {       // forward with the fp8 image (bf16 only; checked by the caller)
-#define LNQ_CASE(N) case N: hipLaunchKernelGGL((k_ln_fwd<bf16_t, N, true>), grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)gamma, \
-                                               (const bf16_t*)beta, (bf16_t*)out, mean, rstd, M, C, eps, *q8); break;
+#define LNQ_LAUNCH(N, F) hipLaunchKernelGGL((k_ln_fwd<bf16_t, N, true, F>), grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)gamma, \
+                                            (const bf16_t*)beta, (bf16_t*)out, mean, rstd, M, C, eps, *q8)
+#define LNQ_CASE(N) case N: if (q8->fmt == SAM3_FP8_E4M3) LNQ_LAUNCH(N, SAM3_FP8_E4M3); else LNQ_LAUNCH(N, SAM3_FP8_E5M2); break;
         switch (cpl) {
             LNQ_CASE(1) LNQ_CASE(2) LNQ_CASE(3) LNQ_CASE(4) LNQ_CASE(5) LNQ_CASE(6) LNQ_CASE(7) LNQ_CASE(8)
             default: return -22;
         }
 #undef LNQ_CASE
+#undef LNQ_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -5;
     }
 #define LN_CASE(N)                                                                                                     \

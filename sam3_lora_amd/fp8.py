@@ -43,12 +43,12 @@ def fp8_enabled() -> bool:
 
 class Fp8Quantizer:
     """One tensor role (e.g. "input of fc1"): delayed-scaling state + the quantise call.  The state -- two arrays of
-    ``SAM3_FP8_AMAX_SLOTS`` amax slots used alternately (read by this call / gathered for the next) and the scale -- is also
+    ``SAM3_FP8_AMAX_SLOTS`` amax slots (one 128-byte line each) used alternately (read by this call / gathered for the next) and the scale -- is also
     what the PRODUCING kernels take when they write the fp8 image themselves (:meth:`begin`)."""
 
     def __init__(self, fmt: int):
         self.fmt = fmt
-        self.amax = None            # [2, SLOTS]: [read by this call, written for the next], alternating
+        self.amax = None            # [2, SAM3_FP8_AMAX_FLOATS]: [read by this call, written for the next], alternating
         self.scale = None
         self.k = 0
 
@@ -70,7 +70,7 @@ class Fp8Quantizer:
     def __call__(self, x2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         lib = _ffi.load()
         if self.amax is None or self.amax.device != x2.device:
-            self.amax = torch.zeros(2, _ffi.FP8_AMAX_SLOTS, device=x2.device)
+            self.amax = torch.zeros(2, _ffi.FP8_AMAX_FLOATS, device=x2.device)
             self.scale = torch.empty(1, device=x2.device)
             # first call: calibrate on the tensor itself (finite values only, as the kernels' running amax)
             self.amax[0, 0] = torch.nan_to_num(x2.detach().abs().float(), nan=0.0, posinf=0.0).max()

@@ -81,8 +81,8 @@ def test_fp8_frozen_linears_track_the_bf16_build():
 
 def _slot_state(amax_value):
     from sam3_lora_amd import _ffi
-    amax = torch.zeros(2, _ffi.FP8_AMAX_SLOTS, device=DEV)
-    amax[0, 5] = amax_value                       # any slot: the reader takes the maximum
+    amax = torch.zeros(2, _ffi.FP8_AMAX_FLOATS, device=DEV)
+    amax[0, 5 * _ffi.FP8_AMAX_STRIDE] = amax_value     # any slot: the reader takes the maximum
     return amax, torch.empty(1, device=DEV)
 
 
@@ -189,7 +189,8 @@ def test_fused_and_separate_quantisation_give_the_same_training_steps(monkeypatc
 
 
 def test_non_finite_elements_keep_their_encoding_and_stay_out_of_the_amax():
-    """A NaN element leaves as NaN (a diverged step still shows), but neither NaN nor Inf enters the running amax: tensors carry
+    """A NaN element leaves as NaN and an Inf as the format's non-finite encoding (e4m3fn has no Inf: NaN) -- a diverged step
+    still shows -- but neither enters the running amax; a FINITE value beyond the delayed range saturates: tensors carry
     non-finite values in positions nobody reads (fully masked softmax rows, padded keys), and a NaN amax would turn the next
     call's scale -- hence the whole tensor -- into NaN."""
     from sam3_lora_amd import _ffi
@@ -201,8 +202,12 @@ def test_non_finite_elements_keep_their_encoding_and_stay_out_of_the_amax():
     out, scale = q(x)
     assert torch.allclose(scale, torch.tensor([30.0 / 448.0], device=DEV))
     f = out.float()
-    assert torch.isnan(f[3, 5]) and f[7, 9] == 448.0 and int(torch.isnan(f).sum()) == 1
+    assert torch.isnan(f[3, 5]) and torch.isnan(f[7, 9]) and int(torch.isnan(f).sum()) == 2
+    assert f[9, 1] == 448.0
     out2, scale2 = q(x * 0.5)                       # scaled with the amax gathered above: finite
     assert torch.allclose(scale2, torch.tensor([30.0 / 448.0], device=DEV)) and torch.isfinite(scale2).all()
     out3, scale3 = q(x)
     assert torch.allclose(scale3, torch.tensor([15.0 / 448.0], device=DEV))
+    x[11, 2] = -1.0e6                               # finite, far beyond the delayed range: saturates
+    out4, scale4 = q(x)
+    assert torch.allclose(scale4, torch.tensor([30.0 / 448.0], device=DEV)) and out4.float()[11, 2] == -448.0

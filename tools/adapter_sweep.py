@@ -22,7 +22,7 @@ VARIANTS = {
     "no_ride": {"SAM3_LORA_NO_RIDE": "1"},
     "round-2 equivalent (single_round + no_ride)": {"SAM3_LORA_SINGLE_ROUND": "1", "SAM3_LORA_NO_RIDE": "1"},
 }
-KNOBS = ("SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE", "SAM3_LORA_T3E_WGS", "SAM3_LORA_T3_WGS", "SAM3_LORA_T2_TPW")
+KNOBS = ("SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE", "SAM3_LORA_T3E_WGS", "SAM3_LORA_T3_WGS", "SAM3_LORA_T2_TPW", "SAM3_LORA_T2_PF2")
 
 
 def main():
@@ -31,7 +31,11 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--extra", action="append", default=[], help="NAME=K1=V1,K2=V2 additional variant")
+    ap.add_argument("--only-extra", action="store_true", help="default + the --extra variants only")
     args = ap.parse_args()
+    if args.only_extra:
+        for k in list(VARIANTS)[1:]:
+            del VARIANTS[k]
     for e in args.extra:
         name, _, kv = e.partition("=")
         VARIANTS[name] = dict(p.split("=") for p in kv.split(",") if p)
