@@ -235,6 +235,11 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     fp8_hdr = open(os.path.join(build.INCLUDE, "sam3_fp8_amd.h")).read()
     fp8_declared = set(re.findall(r"\b(sam3_fp8_[a-z_]+)\s*\(", fp8_hdr))
     assert fp8_declared == set(_ffi.FP8_EXPORTS), fp8_declared ^ set(_ffi.FP8_EXPORTS)
+    # the amax slot layout the Python side allocates is the one the header states
+    consts = {k: int(v) for k, v in re.findall(r"#define (SAM3_FP8_(?:AMAX_SLOTS|AMAX_STRIDE|E4M3|E5M2))\s+(\d+)", fp8_hdr)}
+    assert consts == {"SAM3_FP8_AMAX_SLOTS": _ffi.FP8_AMAX_SLOTS, "SAM3_FP8_AMAX_STRIDE": _ffi.FP8_AMAX_STRIDE,
+                      "SAM3_FP8_E4M3": _ffi.FP8_E4M3, "SAM3_FP8_E5M2": _ffi.FP8_E5M2}
+    assert _ffi.FP8_AMAX_FLOATS == _ffi.FP8_AMAX_SLOTS * _ffi.FP8_AMAX_STRIDE and _ffi.FP8_AMAX_STRIDE * 4 == 128
     seg_hdr = open(os.path.join(build.INCLUDE, "sam3_seg_amd.h")).read()
     seg_declared = set(re.findall(r"\b(sam3_(?:seg|gn|rpb)_[a-z_]+)\s*\(", seg_hdr))
     assert seg_declared == set(_ffi.SEG_EXPORTS), seg_declared ^ set(_ffi.SEG_EXPORTS)
