@@ -789,6 +789,10 @@ def main():
         if rank == 0:
             ms = dt / args.steps * 1e3
             ips = world * args.batch / (dt / args.steps)
+            which_config = ("BASELINE configs[4]'s adapter / precision / batch at the reference's 1008^2 -- its 1536^2 inputs do not exist "
+                            "in the reference (SURVEY F5)" if (args.rank == 8 and args.batch == 16 and args.fp8_frozen)
+                            else "BASELINE configs[1]" if (args.rank == 16 and args.batch == 8 and not args.fp8_frozen)
+                            else "a variation of BASELINE configs[1]")
             out = {
                 "metric": "training images/sec at 1024^2, SAM3-base r=%d (whole training step)" % args.rank,
                 "value": round(ips, 2), "unit": "images/s",
@@ -796,7 +800,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": args.act_dtype, "data": "synthetic",
                 "config": {"workload": ("" if args.model == "sam3" else "[TINY-WIDTH CONTRACT-TEST MODEL, not the benchmark] ") +
-                                       "full_lora_config.yaml @ r=%d alpha=%d (BASELINE configs[1]): SAM3 image model "
+                                       "full_lora_config.yaml @ r=%d alpha=%d (" + which_config + "): SAM3 image model "
                                        "(840.5M parameters, random seeded init), batch %d/GPU of synthetic 1024^2 images -> "
                                        "1008^2 with 2 boxes + masks each and the prompt 'crack'; forward + Hungarian "
                                        "matching (final + 5 aux outputs) + Sam3LossWrapper (boxes, IA-BCE + presence, "
