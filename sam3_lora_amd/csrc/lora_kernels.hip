@@ -60,6 +60,17 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// XCD-aware tile order.  The dispatcher is observed to place workgroup b (dispatch order: blockIdx.x fastest) on XCD b % 8,
+// and each XCD has its own L2: workgroups that share an operand slice (the column chunks of one row group share its t / gt
+// rows) should sit on ONE XCD, or every XCD fetches the slice again (PMC, profiles/r03_traffic.json: +19-22 MB per launch,
+// 1.1-1.3x the algorithmic bytes on the 1024-wide launches).  This maps dispatch index `orig` of `nwg` workgroups to a tile
+// index such that each XCD owns a CONTIGUOUS range of tile indices (bijective for any nwg); with tiles numbered row-group-major
+// the column chunks of a row group land on the same XCD.  Placement is a speed matter only: results do not depend on it.
+__device__ __forceinline__ unsigned xcd_tile_index(unsigned orig, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // Streamed-once activation reads (k_t1, k_t3, k_t3e, the pre-activation tile of k_t2<ACT=2>, the gt partials) are
 // issued NON-TEMPORAL (`global_load ... nt`): they are consumed exactly once, and keeping them out of L2 / Infinity
 // Cache measured -10 % on the whole adapter step on MI355X (same-box A/B, profiles/r01e_nt_loads.txt: k_t3 96.7 -> 70.9
@@ -580,7 +591,7 @@ template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 
 __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
-                                            ReduceRide ride, Q8Out q8) {
+                                            ReduceRide ride, Q8Out q8, int xcd_order) {
     static_assert(!Q8 || ACT != 0, "the fp8 image is the one of the activation-fused passes");
     static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
@@ -591,15 +602,18 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
             reduce_block(e < ride.nblk ? ride.j0 : ride.j1, e % ride.nblk, ride.scale, ride.accumulate, &slab_all[0][0]);
         return;
     }
-    const unsigned by = blockIdx.y - (unsigned)ride.rows;
+    // body tile (bx = column block, by = row block): all column blocks of a row block on one XCD (they share its T rows)
+    unsigned pbody = (blockIdx.y - (unsigned)ride.rows) * gridDim.x + blockIdx.x;
+    if (xcd_order) pbody = xcd_tile_index(pbody, gridDim.x * (gridDim.y - (unsigned)ride.rows));
+    const unsigned bx = pbody % gridDim.x, by = pbody / gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     float* slab = slab_all[wave];
-    const int c0 = blockIdx.x * CW;
+    const int c0 = bx * CW;
     Q8Scale qs{0.f, 0.f, 0u};
     unsigned seen = 0u;         // packed running amax (q8_pack8_bf16)
-    const unsigned q8_id = (blockIdx.x + by * gridDim.x) * 4 + wave;
-    if (Q8) qs = q8_begin(q8, blockIdx.x == 0 && by == 0 && tid == 0, q8_id);
+    const unsigned q8_id = (bx + by * gridDim.x) * 4 + wave;
+    if (Q8) qs = q8_begin(q8, bx == 0 && by == 0 && tid == 0, q8_id);
 
     // W2^T fragments (MFMA A-operand: i = output column, k = rank index), kept for the whole kernel
     uint2 wlo[8], whi[8];
@@ -719,15 +733,18 @@ __device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) &
 template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false>
 __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
-                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk) {
+                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk, int xcd_order) {
     static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
     constexpr int RTA = HL ? 1 : RT;            // rank tiles of the result
     constexpr int RP = RTA * 16, CW = 128, CPR = 16;
     __shared__ uint4 xs[4][32 * CPR];      // 32 rows x 256 B per wave; reused as the reduction buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int c0 = blockIdx.x * CW;
-    const int rg = (int)blockIdx.y;
+    // tile (column chunk, row group): the chunks of a row group on one XCD (they share its t^T fragments)
+    unsigned ptile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * gridDim.y);
+    const int c0 = (int)(ptile % gridDim.x) * CW;
+    const int rg = (int)(ptile / gridDim.x);
     // rows of this wave: quarter `wave` of [rg*rows_per_wg, +rows_per_wg), rows_per_wg % 128 == 0
     const long long w_begin = (long long)rg * rows_per_wg + (long long)wave * (rows_per_wg / 4);
     long long w_end = w_begin + rows_per_wg / 4;
@@ -862,13 +879,16 @@ template <typename XT, bool HL>
 __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf,
                                              float* __restrict__ Gpart, long long M, long long Mp, int N,
                                              int rows_per_wg, const bf16_t* __restrict__ W1b,
-                                             float* __restrict__ GTP) {
+                                             float* __restrict__ GTP, int xcd_order) {
     constexpr int RP = 16, CPR = 16, NH = HL ? 2 : 1;
     __shared__ uint4 xs[4][32 * CPR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int c0 = blockIdx.x * 256;
-    const int rg = (int)blockIdx.y;
+    unsigned ptile = blockIdx.y * gridDim.x + blockIdx.x;       // tile order as in k_t3
+    if (xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * gridDim.y);
+    const unsigned cpair = ptile % gridDim.x;
+    const int c0 = (int)cpair * 256;
+    const int rg = (int)(ptile / gridDim.x);
     const long long w_begin = (long long)rg * rows_per_wg + (long long)wave * (rows_per_wg / 4);
     long long w_end = w_begin + rows_per_wg / 4;
     if (w_end > Mp) w_end = Mp;
@@ -930,7 +950,7 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
                                                                        __builtin_bit_cast(bf16x8, xa), ga[rtile], 0, 0, 0);
             }
             if (cc == 1)
-                *reinterpret_cast<f32x4*>(GTP + ((long long)blockIdx.x * Mp + mb + rtile * 16 + n) * 16 + g * 4) = ga[rtile];
+                *reinterpret_cast<f32x4*>(GTP + ((long long)cpair * Mp + mb + rtile * 16 + n) * 16 + g * 4) = ga[rtile];
         }
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -1175,7 +1195,8 @@ struct Knob {
 };
 Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", false, 0},   {"SAM3_LORA_T1_NO_SPLIT", false, 0},
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
-                  {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0}};
+                  {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
+                  {"SAM3_LORA_XCD_ORDER", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1199,6 +1220,17 @@ bool env_flag(const char* name) {
 long long env_int(const char* name, long long dflt) {
     const Knob* k = knob(name);
     return (k && k->set) ? k->value : dflt;
+}
+
+// XCD-aware tile order (xcd_tile_index) of k_t2 / k_t3 / k_t3e: on for NARROW launches only.  Measured on MI355X, same box,
+// interleaved rounds (profiles/r03p_xcd_order_sweep.json): at N = 1024 the shared t / gt rows are a fifth of a launch's traffic
+// when every XCD fetches them again, and keeping a row group's column chunks on one XCD gains 3-5 % (k_t2 38.2 -> 36.9 us,
+// k_t3 24.4 -> 23.2, k_t3e 28.2 -> 27.3); at N = 4736 they are 2-4 % of the traffic and eight XCDs streaming eight separate row
+// ranges LOSES more than that (k_t2 132 -> 137 us, and the k_t1 that reads its output next 75 -> 86 us: the rows written last are
+// no longer the ones read first).  SAM3_LORA_XCD_ORDER=0 / 1 forces it off / on everywhere.
+int xcd_order_for(int N) {
+    const long long forced = env_int("SAM3_LORA_XCD_ORDER", -1);
+    return forced >= 0 ? (forced != 0) : (N <= 1024);
 }
 
 // strides of the canonical views A_c[in, r], B_c[r, out] inside the caller's tensors
@@ -1372,9 +1404,10 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows);
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
     const Q8Out q8 = q8_in ? *q8_in : Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
+    const int xcd = xcd_order_for(N);
     if (q8.q) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
 #define T2_Q8(AV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, AV, true, true, FV>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
-                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8)
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd)
         if (act == 1) { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(1, SAM3_FP8_E4M3); else T2_Q8(1, SAM3_FP8_E5M2); }
         else { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(2, SAM3_FP8_E4M3); else T2_Q8(2, SAM3_FP8_E5M2); }
 #undef T2_Q8
@@ -1382,7 +1415,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     }
 #define T2_LAUNCH(RTV, DV, AV, HV) \
     hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV, HV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
-                       (YT*)aux, ldaux, ride, q8)
+                       (YT*)aux, ldaux, ride, q8, xcd)
 #define T2_RT(RTV, HV)                                                                     \
     do {                                                                               \
         if (act == 1) T2_LAUNCH(RTV, false, 1, HV);            /* forward: no mask on y */   \
@@ -1399,10 +1432,11 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
                const T3Plan& p, int RT, bool hl, unsigned stage_bit, hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
     const bool gather = env_flag("SAM3_LORA_T3_GATHER");
+    const int xcd = xcd_order_for(N);
     ProfScope ps(stage_bit, N, st);
 #define T3_LAUNCH(RTV, GV, HV) \
-    do { if (dk.thr) hipLaunchKernelGGL((k_t3<XT, RTV, GV, true, HV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); \
-         else hipLaunchKernelGGL((k_t3<XT, RTV, GV, false, HV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk); } while (0)
+    do { if (dk.thr) hipLaunchKernelGGL((k_t3<XT, RTV, GV, true, HV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk, xcd); \
+         else hipLaunchKernelGGL((k_t3<XT, RTV, GV, false, HV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk, xcd); } while (0)
     if (RT == 1) {
         if (gather) T3_LAUNCH(1, true, false); else T3_LAUNCH(1, false, false);
     } else if (hl) {
@@ -1418,10 +1452,11 @@ template <typename XT>
 void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N,
                     const T3Plan& p, bool hl, const bf16_t* W1b, float* GTP, bf16_t* GT, bf16_t* GTT, hipStream_t st) {
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
+    const int xcd = xcd_order_for(N);
     {
         ProfScope ps(SAM3_LORA_STAGE_T3_GB, N, st);
-        if (hl) hipLaunchKernelGGL((k_t3e<XT, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP);
-        else hipLaunchKernelGGL((k_t3e<XT, false>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP);
+        if (hl) hipLaunchKernelGGL((k_t3e<XT, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP, xcd);
+        else hipLaunchKernelGGL((k_t3e<XT, false>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, W1b, GTP, xcd);
     }
     ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, N, st);
     const dim3 rg((unsigned)((Mp * 4 + 255) / 256));

@@ -724,3 +724,32 @@ def test_riding_reduction_is_bit_identical_to_the_separate_launch(monkeypatch):
     for a, b in zip(outs["1"], outs["0"]):
         assert torch.equal(a, b)
     assert not torch.equal(outs["1"][1], outs["1"][4])          # accumulate mode really added onto the 0.5
+
+
+def test_xcd_aware_tile_order_changes_placement_not_results(monkeypatch):
+    """k_t2 / k_t3 / k_t3e number their tiles so that the column chunks of a row group run on one XCD (narrow launches by
+    default; SAM3_LORA_XCD_ORDER=0 / 1 forces it off / on everywhere): a bijection of the workgroup ids -- forward and backward
+    results are bit-identical either way, at a width that takes the order by default (512) and one that does not (2304), with
+    grids that are not multiples of 8."""
+    g = torch.Generator(device=DEV).manual_seed(6)
+    for fin, fout in ((520, 392), (2304, 264)):
+        M, rank = 3000, 16
+        x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+        gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+        base = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+        A = torch.randn(fin, rank, device=DEV, generator=g) / 16
+        B = torch.randn(rank, fout, device=DEV, generator=g) / 16
+        outs = {}
+        for forced in ("1", "0"):
+            monkeypatch.setenv("SAM3_LORA_XCD_ORDER", forced)
+            _reload_knobs()
+            y = base.clone()
+            Fn.lora_fwd_(x, A, B, y, 2.0, 0)
+            gx = torch.ones(M, fin, device=DEV, dtype=torch.bfloat16)
+            gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+            Fn.lora_bwd_(gy, x, None, A, B, gx, gA, gB, 2.0, 0)
+            outs[forced] = (y, gx, gA, gB)
+        monkeypatch.delenv("SAM3_LORA_XCD_ORDER")
+        _reload_knobs()
+        for a, b in zip(outs["1"], outs["0"]):
+            assert torch.equal(a, b)
