@@ -184,6 +184,26 @@ def time_events(fn, iters, warm=3, reps=5):
     return sum(per) / len(per), per[len(per) // 2], per[0]
 
 
+def workload_label(args, n_adapted, ckpt):
+    """`config.workload` of the JSON line: which BASELINE configuration this run is, and what the step contains."""
+    which_config = ("BASELINE configs[4]'s adapter / precision / batch at the reference's 1008^2 -- its 1536^2 inputs do not exist "
+                    "in the reference (SURVEY F5)" if (args.rank == 8 and args.batch == 16 and args.fp8_frozen)
+                    else "BASELINE configs[1]" if (args.rank == 16 and args.batch == 8 and not args.fp8_frozen)
+                    else "a variation of BASELINE configs[1]")
+    return (("" if args.model == "sam3" else "[TINY-WIDTH CONTRACT-TEST MODEL, not the benchmark] ") +
+            "full_lora_config.yaml @ r=%d alpha=%d (%s): SAM3 image model "
+            "(840.5M parameters, random seeded init), batch %d/GPU of synthetic 1024^2 images -> "
+            "1008^2 with 2 boxes + masks each and the prompt 'crack'; forward + Hungarian "
+            "matching (final + 5 aux outputs) + Sam3LossWrapper (boxes, IA-BCE + presence, "
+            "mask focal + dice, o2m twins) + backward + A/B-gradient all-reduce + AdamW; frozen "
+            "tensors and activations %s, A/B fp32; LoRA on the %d ViT-MLP Linears through the "
+            "HIP adapter path; activation checkpointing %s; matching %s per step%s"
+            % (args.rank, 2 * args.rank, which_config, args.batch, args.act_dtype, n_adapted,
+               "on (per block / layer)" if ckpt else "off (activations kept in HBM)",
+               "twice (model + loop, as the reference)" if args.match_twice else "once",
+               "; frozen base GEMMs in fp8 (e4m3 weights / activations, e5m2 gradients)" if args.fp8_frozen else ""))
+
+
 def committed_traffic(kernel, wg_x):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*traffic.json,
     produced by tools/rocpd_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs
@@ -789,28 +809,13 @@ def main():
         if rank == 0:
             ms = dt / args.steps * 1e3
             ips = world * args.batch / (dt / args.steps)
-            which_config = ("BASELINE configs[4]'s adapter / precision / batch at the reference's 1008^2 -- its 1536^2 inputs do not exist "
-                            "in the reference (SURVEY F5)" if (args.rank == 8 and args.batch == 16 and args.fp8_frozen)
-                            else "BASELINE configs[1]" if (args.rank == 16 and args.batch == 8 and not args.fp8_frozen)
-                            else "a variation of BASELINE configs[1]")
             out = {
                 "metric": "training images/sec at 1024^2, SAM3-base r=%d (whole training step)" % args.rank,
                 "value": round(ips, 2), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": args.act_dtype, "data": "synthetic",
-                "config": {"workload": ("" if args.model == "sam3" else "[TINY-WIDTH CONTRACT-TEST MODEL, not the benchmark] ") +
-                                       "full_lora_config.yaml @ r=%d alpha=%d (" + which_config + "): SAM3 image model "
-                                       "(840.5M parameters, random seeded init), batch %d/GPU of synthetic 1024^2 images -> "
-                                       "1008^2 with 2 boxes + masks each and the prompt 'crack'; forward + Hungarian "
-                                       "matching (final + 5 aux outputs) + Sam3LossWrapper (boxes, IA-BCE + presence, "
-                                       "mask focal + dice, o2m twins) + backward + A/B-gradient all-reduce + AdamW; frozen "
-                                       "tensors and activations %s, A/B fp32; LoRA on the %d ViT-MLP Linears through the "
-                                       "HIP adapter path; activation checkpointing %s; matching %s per step%s"
-                                       % (args.rank, 2 * args.rank, args.batch, args.act_dtype, full.n_adapted,
-                                          "on (per block / layer)" if full.ckpt else "off (activations kept in HBM)",
-                                          "twice (model + loop, as the reference)" if args.match_twice else "once",
-                                          "; frozen base GEMMs in fp8 (e4m3 weights / activations, e5m2 gradients)" if args.fp8_frozen else ""),
+                "config": {"workload": workload_label(args, full.n_adapted, full.ckpt),
                            "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                            "grad_allreduce_bytes": full.reducer.nbytes, "finite": finite,
                            "loss": round(full.last_loss.item(), 4), "adapted_modules": full.n_adapted,

@@ -81,3 +81,18 @@ def test_bare_gpus_2_starts_two_ranks_itself():
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     r = _last_json(p.stdout)
     assert r["n_gpus"] == 2 and r["distributed"]["rank_device_ids"] == [0, 0] and r["config"]["global_batch"] == 2
+
+
+def test_workload_label_names_the_configuration_that_runs():
+    """`config.workload` is built on the CPU path of the contract too: the default is configs[1], r = 8 / batch 16 / fp8 is
+    configs[4]'s mode, anything else is called a variation (a formatting slip here once broke every bench run)."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    base = dict(rank=16, batch=8, fp8_frozen=False, model="sam3", act_dtype="bf16", match_twice=False)
+    a = bench.workload_label(argparse.Namespace(**base), 64, False)
+    assert "r=16 alpha=32 (BASELINE configs[1])" in a and "batch 8/GPU" in a and "64 ViT-MLP" in a and "kept in HBM" in a
+    b = bench.workload_label(argparse.Namespace(**dict(base, rank=8, batch=16, fp8_frozen=True)), 64, False)
+    assert "configs[4]" in b and "r=8 alpha=16" in b and b.endswith("e5m2 gradients)")
+    c = bench.workload_label(argparse.Namespace(**dict(base, batch=4, model="tiny", match_twice=True)), 8, True)
+    assert "variation of BASELINE configs[1]" in c and c.startswith("[TINY-WIDTH") and "twice" in c and "on (per block" in c
