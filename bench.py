@@ -836,8 +836,8 @@ def main():
             ov = overlap_measurement(full, world)
             if rank == 0:
                 out["exchange_overlap"] = ov
-        if not args.no_data_step and not args.full_only:
-            try:
+        if not args.no_data_step and not args.full_only and world == 1:     # auxiliary, N = 1 only: a rank failing alone here would
+            try:                                                             # leave the others in a barrier
                 dsm = data_step_measurement(full, args, world, rank, timed)
             except Exception as e:      # an auxiliary measurement must never cost the bench line
                 dsm = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
@@ -858,7 +858,8 @@ def main():
                     "loss": round(full.last_loss.item(), 4), "loss_bf16_build": round(loss_bf16, 4),
                     "finite": bool(torch.isfinite(full.last_loss).item()),
                     "what": "the same whole training step with the frozen Linears' GEMMs in fp8 (weights e4m3 per-tensor scale, "
-                            "activations e4m3 / gradients e5m2 by the HIP quantiser with delayed scaling, hipBLASLt fp8 MFMA "
+                            "activations e4m3 / gradients e5m2 with delayed scaling -- written by the producing kernels (LayerNorm, the "
+                            "GELU / GELU' adapter passes) where there is one, by the HIP quantiser otherwise; hipBLASLt fp8 MFMA "
                             "through torch._scaled_mm); LoRA branch bf16 / fp32 as before"}
             enable_fp8_frozen(False)
         del full
