@@ -150,7 +150,14 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
  *   sam3_lora_bwd_act: as sam3_lora_bwd, then gx_inout *= act'(pre_act[M, in]) -- for the layer that CONSUMES the
  *                      activation (fc2): gx_inout leaves as the gradient of the producing layer's pre-activation.
  * act: SAM3_LORA_ACT_GELU = exact (erf) GELU, torch.nn.GELU()'s default, evaluated in fp32 on the rounded tensor.
+ *
+ * sam3_lora_bwd_act with x == NULL: "this layer's input IS act(pre_act)" (what sam3_lora_fwd_act wrote as act_out).  The pass
+ * that applies act'(pre_act) then also recomputes act(pre_act) tile by tile and contracts it with gt for gA -- the second full
+ * read of the stored activation (e * M * in bytes) disappears and the caller need not keep the activation for the backward.
+ * Needs tT_saved, gx_inout, and sam3_lora_bwd_act_recomputes_input(rank, dtype, drop_p) != 0 (bf16 hi + lo kernels: rank <= 16,
+ * no dropout); gA then differs from the x-given form only in summation order (fp32, <= 1e-6 relative).
  */
+int sam3_lora_bwd_act_recomputes_input(int rank, int dtype, float drop_p);
 #define SAM3_LORA_ACT_NONE 0
 #define SAM3_LORA_ACT_GELU 1
 int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout, void* tT_out,

@@ -27,7 +27,7 @@ EXPORTS = (
     "sam3_lora_fwd", "sam3_lora_bwd", "sam3_lora_merge", "sam3_lora_debug_set_stages", "sam3_lora_debug_reload_knobs",
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
-    "sam3_lora_fwd_act_q8", "sam3_lora_bwd_act_q8",
+    "sam3_lora_fwd_act_q8", "sam3_lora_bwd_act_q8", "sam3_lora_bwd_act_recomputes_input",
 )
 ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
@@ -95,6 +95,8 @@ def _declare(lib):
     lib.sam3_lora_fwd_act_q8.argtypes = list(lib.sam3_lora_fwd_act.argtypes) + q8_tail
     lib.sam3_lora_bwd_act_q8.restype = c_int
     lib.sam3_lora_bwd_act_q8.argtypes = list(lib.sam3_lora_bwd_act.argtypes) + q8_tail
+    lib.sam3_lora_bwd_act_recomputes_input.restype = c_int
+    lib.sam3_lora_bwd_act_recomputes_input.argtypes = [c_int, c_int, ctypes.c_float]
     lib.sam3_lora_debug_reload_knobs.restype = None
     lib.sam3_lora_debug_reload_knobs.argtypes = []
     lib.sam3_lora_debug_set_stages.restype = ctypes.c_uint

@@ -484,6 +484,9 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceJob j0, ReduceJob j1, floa
     reduce_block(blockIdx.y == 0 ? j0 : j1, blockIdx.x, scale, accumulate, sm);
 }
 
+// LDS swizzle of the row-major bf16 slabs read with ds_read_b64_tr_b16 (k_t3, k_t3e, k_t2's GA tile)
+__device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
 template <typename YT>
 struct YTile;  // 16 rows x 128 cols, lane L owns rows p*4 + (L>>4), cols (L&15)*8 .. +8
 
@@ -502,11 +505,14 @@ struct YTile<bf16_t> {
         }
     }
     // Q8: the tensor the NEXT frozen GEMM consumes (ACT == 1: act(y); ACT == 2: the updated gradient) also leaves as fp8
-    template <bool FAST, bool DROP, int ACT, bool Q8 = false, int QF = 0>
+    // GA (ACT == 2): act(h) of the tile -- the input the GELU'-fused backward's LoRA layer saw in the forward, bit for bit what
+    // k_t2<ACT = 1> stored -- is left in `atile` (bf16 [16 rows][16 chunks of 8], t3_h swizzle) for the gA contraction
+    template <bool FAST, bool DROP, int ACT, bool Q8 = false, int QF = 0, bool GA = false>
     __device__ __forceinline__ void add_store(bf16_t* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
                                               const DropKey& dk, bf16_t* AUX, long long ldaux, const YTile<bf16_t>& haux,
-                                              const Q8Out* q8 = nullptr, const Q8Scale* qs = nullptr, unsigned* seen = nullptr) {
+                                              const Q8Out* q8 = nullptr, const Q8Scale* qs = nullptr, unsigned* seen = nullptr,
+                                              uint4* atile = nullptr) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
@@ -521,6 +527,7 @@ struct YTile<bf16_t> {
             o.w = pack2(bf_lo(v[p].w) + scale * b[2], bf_hi(v[p].w) + scale * b[3]);
             const bool ok = FAST || (m < M && col < N);
             if (ACT == 2) o = act8(o, haux.v[p], 2);
+            if (ACT == 2 && GA) atile[rl * 16 + ((lane & 15) ^ (t3_h(rl) << 1))] = act8(haux.v[p], haux.v[p], 1);   // (zeros beyond M / N: h loads as 0)
             if (ok) stg16(Y + m * ldy + col, o);
             uint4 a8 = o;
             if (ACT == 1) {
@@ -548,12 +555,12 @@ struct YTile<float> {
             v[p][1] = ok ? *reinterpret_cast<const f32x4*>(Y + m * ldy + col + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    template <bool FAST, bool DROP, int ACT, bool Q8 = false, int QF = 0>
+    template <bool FAST, bool DROP, int ACT, bool Q8 = false, int QF = 0, bool GA = false>
     __device__ __forceinline__ void add_store(float* Y, long long ldy, long long m0, int col, int lane,
                                               long long M, int N, const float* slab, int ldw, float scale,
                                               const DropKey& dk, float* AUX, long long ldaux, const YTile<float>& haux,
-                                              const Q8Out* = nullptr, const Q8Scale* = nullptr, unsigned* = nullptr) {
-        static_assert(!Q8, "fp8 outputs ride on bf16 tensors only");
+                                              const Q8Out* = nullptr, const Q8Scale* = nullptr, unsigned* = nullptr, uint4* = nullptr) {
+        static_assert(!Q8 && !GA, "fp8 outputs and the in-pass gA contraction ride on bf16 tensors only");
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rl = p * 4 + (lane >> 4);
@@ -587,15 +594,24 @@ struct YTile<float> {
 };
 
 // HL (RT == 2): W2t = [hi | lo] of the LoRA operand, T = [hi | lo] of t: delta = hi.t_hi + hi.t_lo + lo.t_hi.
-template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0>
-__global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
+// GA (ACT == 2, hi + lo, no dropout): the pass ALSO contracts act(h) -- recomputed from the pre-activation tile it holds anyway --
+// with the gt fragments: GApart[row block][16][N] = sum over the block's rows of gt^T (x) act(h), i.e. the layer's gA partials,
+// which k_t3 otherwise reads the whole stored activation a second time for (394 MB at N = 4736).
+struct GaEmit {
+    const bf16_t* GTTf;     // gt, fragment-major (k_gt_reduce<HL> / store_t4_hl): [32-row step][hi | lo][64 lanes][8]
+    float* part;            // [row blocks][16][N]
+};
+template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false>
+__global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
-                                            ReduceRide ride, Q8Out q8, int xcd_order) {
+                                            ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga) {
+    static_assert(!GA || (ACT == 2 && HL && !DROP && sizeof(YT) == 2), "the in-pass gA contraction: GELU' pass of the hi + lo kernels");
     static_assert(!Q8 || ACT != 0, "the fp8 image is the one of the activation-fused passes");
     static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
     __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
+    __shared__ uint4 atile_all[GA ? 4 : 1][GA ? 16 * 16 : 1];       // GA: act(h) of the wave's tile, bf16
     if (blockIdx.y < (unsigned)ride.rows) {     // riding reduction blocks (scheduled first; see reduce_block)
         const long long e = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         if (e < 2LL * ride.nblk)
@@ -677,6 +693,35 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
             *reinterpret_cast<f32x4*>(slab + n * LDW + ct * 16 + g * 4) = d;
         }
     };
+    // GA: gt fragment of a 16-row tile as the K = 32 A-operand [hi rows 0..15 | lo rows 0..15] (lane (n, g): K slots 8 g .. 8 g + 7),
+    // gathered from the 32-row-step image; the B-operand [act(h) rows 0..15 twice] comes from `atile` by transpose reads
+    uint4* atile = atile_all[GA ? wave : 0];
+    f32x4 gacc[GA ? 8 : 1];
+    if (GA) {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) gacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto load_gt = [&](long long t) -> uint4 {
+        return *reinterpret_cast<const uint4*>(ga.GTTf + ((((t >> 1) * 2 + (g >> 1)) * 4 + (int)(t & 1) * 2 + (g & 1)) * 16 + n) * 8);
+    };
+    auto ga_accumulate = [&](const uint4& gf) {
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const char* base = reinterpret_cast<const char*>(atile);
+        const int rowA = (g & 1) * 8 + (n >> 2), rowB = rowA + 4;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
+            const char* pa = base + ((rowA * 16 + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
+            const char* pb = base + ((rowB * 16 + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            // D[i = rank idx][n = column] += sum_row (gt_hi + gt_lo)[row][i] * act(h)[row][col]
+            gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf), __builtin_bit_cast(bf16x8, both),
+                                                              gacc[ct], 0, 0, 0);
+        }
+    };
     const bool colfull = c0 + CW <= N;
     const long long t_fast_end = colfull ? min(t_end, nfull) : t_begin;   // tiles with no tail at all
     long long t = t_begin;
@@ -686,7 +731,9 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
         // at N = 4736, profiles/r03j_adapter_sweep.json: this stream is not short of outstanding loads.)
         YTile<YT> cur, nxt, hcur, hnxt;      // hcur/hnxt: the pre-activation tile (ACT == 2 only)
         uint2 tlo, thi, nlo, nhi;
+        uint4 gfc = make_uint4(0u, 0u, 0u, 0u), gfn = gfc;
         load_t(t, nlo, nhi);
+        if (GA) gfn = load_gt(t);
         nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
         if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, t * 16, col, lane, M, N);
         for (; t < t_fast_end; t += 4) {
@@ -694,14 +741,17 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
             if (ACT == 2) hcur = hnxt;
             tlo = nlo;
             thi = nhi;
+            gfc = gfn;
             const long long tn = t + 4 < t_fast_end ? t + 4 : t;   // last iteration re-reads its own tile (L2 hit)
             load_t(tn, nlo, nhi);
+            if (GA) gfn = load_gt(tn);
             nxt.template load<true>(Y, ldy, tn * 16, col, lane, M, N);
             if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, tn * 16, col, lane, M, N);
             delta_to_slab(tlo, thi);
             wave_sync();
-            cur.template add_store<true, DROP, ACT, Q8, QF>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
+            cur.template add_store<true, DROP, ACT, Q8, QF, GA>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen, atile);
             wave_sync();
+            if (GA) ga_accumulate(gfc);
         }
     }
     for (; t < t_end; t += 4) {   // ragged tiles (last rows / last column chunk): predicated path
@@ -712,10 +762,31 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
         if (ACT == 2) hcur.template load<false, true>(AUX, ldaux, t * 16, col, lane, M, N);
         delta_to_slab(tlo, thi);
         wave_sync();
-        cur.template add_store<false, DROP, ACT, Q8, QF>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen);
+        cur.template add_store<false, DROP, ACT, Q8, QF, GA>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen, atile);
         wave_sync();
+        if (GA) ga_accumulate(load_gt(t));
     }
     if (Q8) q8_end_wave(q8, q8_seen16_to_float(seen), q8_id, qs.have);
+    if (GA) {   // fixed-order cross-wave sum ((w0 + w1) + w2) + w3 through LDS, as k_t3; wave w writes column tiles 2w, 2w + 1
+        float* red = &slab_all[0][0];           // [4 waves][8 col tiles][64 lanes][4] floats = 32 KB of the 33 KB slab area
+        float* out = ga.part + (long long)by * 16 * N;
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) *reinterpret_cast<f32x4*>(red + ((wave * 8 + ct) * 64 + lane) * 4) = gacc[ct];
+        __syncthreads();
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) {
+            const int ct = wave * 2 + jc;
+            f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ((0 * 8 + ct) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 8 + ct) * 64 + lane) * 4);
+            const int ocol = c0 + ct * 16 + n;
+            if (ocol < N) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = s4[jj];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -726,7 +797,6 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k
 //   (hardware transpose); the A-operand (t^T) arrives fragment-major, 1 KB per step, from T1.
 //   No barrier until the end, where the 4 waves' accumulators are added through LDS in fixed order.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int t3_h(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 // HL (RT == 2): the two fragment blocks of a step are the hi and lo parts of the same 16 rank indices and accumulate
 // into ONE rank tile (RTA = 1): G = t_hi^T X + t_lo^T X.
@@ -1196,7 +1266,7 @@ struct Knob {
 Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", false, 0},   {"SAM3_LORA_T1_NO_SPLIT", false, 0},
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
-                  {"SAM3_LORA_XCD_ORDER", false, 0}};
+                  {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1385,10 +1455,22 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
 }
 
 // `ride`: the reduction blocks of this backward call (see reduce_block); rows == 0 when nothing rides
+// GELU' pass that also contracts act(h) with gt (k_t2<GA>): 48 tiles per workgroup keep the gA partials small (54 row blocks at
+// M = 41,472: 16 MB at N = 4736 -- the plain pass runs 12, whose 216 blocks would write 65 MB)
+constexpr int GA_TILES_PER_WG = 48;
+int ga_row_blocks(long long M) { return (int)(((M + 15) / 16 + GA_TILES_PER_WG - 1) / GA_TILES_PER_WG); }
+// x == NULL in sam3_lora_bwd_act: "the layer's input is act(pre_act)" -- recomputed inside the GELU' pass (k_t2<GA>).  Needs the
+// hi + lo kernels (bf16, one rank group of <= 16), no dropout mask on the branch input.  SAM3_LORA_GA_IN_T2=1 takes the same
+// route when x IS given (A/B of the two forms; the caller then vouches that x == act(pre_act)).
+bool ga_in_pass_supported(int rank, int dtype, float drop_p) {
+    return dtype == SAM3_LORA_BF16 && rank <= 16 && geo_of(rank, dtype).hl && drop_p == 0.f;
+}
+bool ga_in_t2_enabled() { return env_flag("SAM3_LORA_GA_IN_T2"); }
+
 template <typename YT>
 void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT, bool hl,
                hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0,
-               const ReduceRide* ride_in = nullptr, const Q8Out* q8_in = nullptr) {
+               const ReduceRide* ride_in = nullptr, const Q8Out* q8_in = nullptr, const GaEmit* ga_in = nullptr) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
     // 3 tiles per wave measured best on MI355X for both N = 4736 and N = 1024 at M = 41472 (sweep 4..48:
@@ -1396,6 +1478,8 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     long long tiles_per_wg = 12;
     while (tiles_per_wg > 4 && nchunks * ((ntiles + tiles_per_wg - 1) / tiles_per_wg) < 1024) tiles_per_wg -= 4;
     tiles_per_wg = env_int("SAM3_LORA_T2_TPW", tiles_per_wg);
+    if (ga_in) tiles_per_wg = GA_TILES_PER_WG;
+    const GaEmit ga = ga_in ? *ga_in : GaEmit{nullptr, nullptr};
     ReduceRide ride{};
     if (ride_in) {
         ride = *ride_in;
@@ -1407,15 +1491,20 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     const int xcd = xcd_order_for(N);
     if (q8.q) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
 #define T2_Q8(AV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, AV, true, true, FV>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
-                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd)
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
         if (act == 1) { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(1, SAM3_FP8_E4M3); else T2_Q8(1, SAM3_FP8_E5M2); }
         else { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(2, SAM3_FP8_E4M3); else T2_Q8(2, SAM3_FP8_E5M2); }
 #undef T2_Q8
         return;
     }
+    if (ga_in) {    // checked by the caller: bf16, hi + lo, GELU' pass, no dropout mask, no fp8 image
+        hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, false, 0, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
+                           (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga);
+        return;
+    }
 #define T2_LAUNCH(RTV, DV, AV, HV) \
     hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV, HV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
-                       (YT*)aux, ldaux, ride, q8, xcd)
+                       (YT*)aux, ldaux, ride, q8, xcd, ga)
 #define T2_RT(RTV, HV)                                                                     \
     do {                                                                               \
         if (act == 1) T2_LAUNCH(RTV, false, 1, HV);            /* forward: no mask on y */   \
@@ -1551,7 +1640,10 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     w.t = off; off += al256((size_t)Mp * RP * e);
     w.tt = off; off += al256((size_t)RP * Mp * e);
     w.pb = off; off += al256((size_t)(w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR) * RG * out_f * 4);
-    w.pa = off; off += al256((size_t)w.pA.NR * RG * in_f * 4);
+    {
+        const int nra = ga_row_blocks(M);       // k_t2<GA> writes one gA partial per row block of ITS grid
+        w.pa = off; off += al256((size_t)(w.pA.NR > nra ? w.pA.NR : nra) * RG * in_f * 4);
+    }
     {   // gt partials of k_t3e (bf16, r <= 16); the same region serves k_t1's split-K partials at small M
         const size_t a = (dtype != SAM3_LORA_F32 && RG == 16) ? (size_t)w.pE.nchunks * Mp * 16 * 4 : 0;
         const size_t b = t1_part_bytes(Mp, RG, dtype);
@@ -1821,7 +1913,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     }
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
     const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
-    bool one_pass = false;
+    bool one_pass = false, ga_in_pass = false;
     if (f32) {
         const float* T32 = (const float*)tT_saved;
         if (!T32) {     // no saved t: recompute t = drop(x) . A_c
@@ -1855,24 +1947,29 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
                                       RG == 16 ? GTP : nullptr);                                                         // gt = gy . B_c^T
             if (gB_g && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, hl, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         }
-        if (gA_g && s3a) launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
+        // GELU'-fused backward of the hi + lo kernels: gA from act(h) INSIDE the pass over gx (k_t2<GA>), no second read of x
+        ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && !dk.thr && !q8 && (x == nullptr || ga_in_t2_enabled());
+        if (gA_g && s3a && !ga_in_pass)
+            launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
     }
     // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
     const bool want_reduce = (gA_g || gB_g) && stage_on(SAM3_LORA_STAGE_REDUCE);
     ReduceRide ride{};
     if (want_reduce) {
         ride.j0 = ReduceJob{PB, gB_g, one_pass ? w.pE.NR : w.pB.NR, RG, out_features, rank, s.b_sr, s.b_so};
-        ride.j1 = ReduceJob{PA, gA_g, w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
+        ride.j1 = ReduceJob{PA, gA_g, ga_in_pass ? ga_row_blocks(M) : w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
         ride.scale = scale;
         ride.accumulate = accumulate;
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
         ride.nblk = (int)(((nb > na ? nb : na) + 63) / 64);
     }
     // the reduction rides on the bf16 rank-r update of gx (the last kernel of the call) when there is one
-    const bool riding = want_reduce && !f32 && gx_inout && s2 && !env_flag("SAM3_LORA_NO_RIDE");
+    // (with the gA partials produced BY that kernel the sum cannot ride on it: it follows as its own launch)
+    const bool riding = want_reduce && !f32 && gx_inout && s2 && !ga_in_pass && !env_flag("SAM3_LORA_NO_RIDE");
+    const GaEmit ga{(const bf16_t*)(ws + w.gtt), PA};
     if (!f32 && gx_inout && s2)
         launch_t2<bf16_t>(gx_inout, ldgx, (bf16_t*)(ws + w.gt), (const bf16_t*)W2tb, M, in_features, scale, RT, hl, st, dk, a2, hpre,
-                          ldpre, riding ? &ride : nullptr, a2 ? q8 : nullptr);
+                          ldpre, riding ? &ride : nullptr, a2 ? q8 : nullptr, ga_in_pass ? &ga : nullptr);
     if (want_reduce && !riding) {
         dim3 grid((unsigned)ride.nblk, 2);
         ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
@@ -1895,7 +1992,15 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
     if (q8 && drop_p > 0.f) return fail(SAM3_LORA_ENOTSUP, "fp8 output is not combined with the dropout mask of the input gradient");
     if (q8 && !gx_inout) return fail(SAM3_LORA_EINVAL, "fp8 output needs gx_inout");
     if ((rc = check_act(gy, ldgy, out_features, dtype, "gy"))) return rc;
-    if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
+    if (x) {
+        if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
+    } else {        // the layer's input is act(pre_act): recomputed inside the activation-derivative pass
+        if (act != SAM3_LORA_ACT_GELU || !pre_act || !gx_inout || !tT_saved)
+            return fail(SAM3_LORA_EINVAL, "x may be NULL only in sam3_lora_bwd_act with pre_act, gx_inout and the saved t^T given");
+        if (q8 || !ga_in_pass_supported(rank, dtype, drop_p))
+            return fail(SAM3_LORA_ENOTSUP, "x == NULL (input recomputed from pre_act) needs bf16, rank <= 16 with hi + lo operands, "
+                                           "no dropout and no fp8 image (sam3_lora_bwd_act_recomputes_input)");
+    }
     if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
     if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
@@ -1936,6 +2041,10 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
     return bwd_impl(gy, x, tT_saved, A, B, gx_inout, gA_accum, gB_accum, M, in_features, out_features, rank, ldgy, ldx, ldgx,
                     layout, scaling, drop_p, seed, offset, dtype, accumulate, workspace, workspace_bytes, stream,
                     SAM3_LORA_ACT_NONE, nullptr, 0);
+}
+
+int sam3_lora_bwd_act_recomputes_input(int rank, int dtype, float drop_p) {
+    return ga_in_pass_supported(rank, dtype, drop_p) ? 1 : 0;
 }
 
 int sam3_lora_bwd_act(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,

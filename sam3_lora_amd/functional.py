@@ -351,14 +351,21 @@ def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A
               packed: Optional[torch.Tensor] = None, gelu_pre: Optional[torch.Tensor] = None, q8=None) -> None:
     """In place: gx2 += lora input-grad; gA/gB (fp32, caller layout) = or += the LoRA weight grads.
     ``gelu_pre`` ([M,in]): the pre-activation whose GELU produced x; gx2 leaves multiplied by GELU'(gelu_pre)
-    (sam3_lora_bwd_act)."""
+    (sam3_lora_bwd_act).  With ``gelu_pre`` given, ``x2`` may be None: "the input is GELU(gelu_pre)", recomputed inside
+    that pass for gA (:func:`bwd_act_recomputes_input` says when the kernels can)."""
     lib = _ffi.load()
-    _require_cuda(gy2, x2, A, B, gx2, gA, gB)
-    M, fin = x2.shape
+    if x2 is None:
+        if gelu_pre is None or tT is None:
+            raise LoRAKernelError("sam3_lora_amd: x may be None only with gelu_pre and the saved t^T given")
+        shape_src = gelu_pre
+    else:
+        shape_src = x2
+    _require_cuda(gy2, shape_src, A, B, gx2, gA, gB)
+    M, fin = shape_src.shape
     fout = gy2.shape[1]
     rank = _rank_of(A, layout)
-    dt = _dtype_code(x2)
-    if gy2.dtype != x2.dtype or (gx2 is not None and gx2.dtype != x2.dtype):
+    dt = _dtype_code(shape_src)
+    if gy2.dtype != shape_src.dtype or (gx2 is not None and gx2.dtype != shape_src.dtype):
         raise LoRAKernelError("sam3_lora_amd: gy, x and gx must share a dtype")
     for g in (gA, gB):
         if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
@@ -366,21 +373,21 @@ def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A
     nws = lib.sam3_lora_bwd_workspace_bytes(M, fin, fout, rank, dt)
     if nws == 0:
         raise LoRAKernelError(f"sam3_lora_bwd_workspace_bytes: {_ffi.last_error()}")
-    ws = _workspace(x2.device, nws)
-    args = (gy2.data_ptr(), x2.data_ptr(), tT.data_ptr() if tT is not None else None,
+    ws = _workspace(shape_src.device, nws)
+    args = (gy2.data_ptr(), x2.data_ptr() if x2 is not None else None, tT.data_ptr() if tT is not None else None,
             (packed if packed is not None else A).data_ptr(), B.data_ptr(),
             gx2.data_ptr() if gx2 is not None else None,
             gA.data_ptr() if gA is not None else None, gB.data_ptr() if gB is not None else None,
-            M, fin, fout, rank, gy2.stride(0), x2.stride(0), gx2.stride(0) if gx2 is not None else fin,
+            M, fin, fout, rank, gy2.stride(0), x2.stride(0) if x2 is not None else fin, gx2.stride(0) if gx2 is not None else fin,
             layout | (PREPACKED if packed is not None else 0), float(scaling), float(drop_p), int(seed), int(offset), dt,
             1 if accumulate else 0,
-            ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream))
+            ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(shape_src.device).cuda_stream))
     if gelu_pre is None:
         if q8 is not None:
             raise LoRAKernelError("sam3_lora_amd: an fp8 image rides on the GELU'-fused pass only")
         _ffi.check(lib.sam3_lora_bwd(*args), "sam3_lora_bwd")
     else:
-        if gx2 is None or gelu_pre.dtype != x2.dtype or gelu_pre.shape != x2.shape or gelu_pre.stride(1) != 1:
+        if gx2 is None or gelu_pre.dtype != shape_src.dtype or gelu_pre.shape != shape_src.shape or gelu_pre.stride(1) != 1:
             raise LoRAKernelError("sam3_lora_amd: gelu_pre must match x in shape and dtype, and gx is required")
         if q8 is None:
             _ffi.check(lib.sam3_lora_bwd_act(*args, _ffi.ACT_GELU, gelu_pre.data_ptr(), gelu_pre.stride(0)), "sam3_lora_bwd_act")
@@ -389,6 +396,14 @@ def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A
             _ffi.check(lib.sam3_lora_bwd_act_q8(*args, _ffi.ACT_GELU, gelu_pre.data_ptr(), gelu_pre.stride(0), img.data_ptr(),
                                                 img.stride(0), int(fmt), a_in.data_ptr(), a_out.data_ptr(), sc.data_ptr()),
                        "sam3_lora_bwd_act_q8")
+
+
+def bwd_act_recomputes_input(rank: int, dtype: torch.dtype, drop_p: float) -> bool:
+    """Whether :func:`lora_bwd_` with ``gelu_pre`` accepts ``x2=None`` (sam3_lora_bwd_act_recomputes_input): the GELU' pass
+    then recomputes GELU(gelu_pre) for gA, and the caller need not keep the activation for the backward."""
+    if dtype not in (torch.bfloat16, torch.float32):
+        return False
+    return bool(_ffi.load().sam3_lora_bwd_act_recomputes_input(int(rank), 0 if dtype == torch.bfloat16 else 1, float(drop_p)))
 
 
 def merge_weight(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float, layout: int) -> torch.Tensor:
@@ -578,7 +593,8 @@ class _LoRALinearFn(torch.autograd.Function):
 class _LoRAMlpFn(torch.autograd.Function):
     """``fc2(GELU(fc1(x)))`` with both Linears LoRA-adapted, as ONE autograd node: the GELU and its derivative ride
     on the adapters' in-place passes over the [M, hidden] tensor (``sam3_lora_fwd_act`` / ``sam3_lora_bwd_act``)
-    instead of being elementwise kernels of their own.  Saved: x, the pre-activation h, a = GELU(h), the two t^T."""
+    instead of being elementwise kernels of their own.  Saved: x, the pre-activation h, the two t^T -- and a = GELU(h) only
+    where the backward cannot recompute it inside its GELU' pass (dropout, rank > 16, fp32, the fp8 frozen-W mode)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, A1, B1, s1, W2, b2, A2, B2, s2, layout, drop_p, seed1, seed2, pk1, pk2, Wt1=None, Wt2=None,
@@ -602,7 +618,11 @@ class _LoRAMlpFn(torch.autograd.Function):
         ctx.meta = (s1, s2, layout, drop_p, seed1, seed2, x.shape, x.dtype)
         ctx.pk = (pk1, pk2)
         ctx.wt = (Wt1, Wt2)
-        ctx.save_for_backward(x2, h, a, W1, W2, A1, B1, A2, B2, t1, t2)
+        # a = GELU(h) is fc2's input; the backward needs it for gA2 only, and where the kernels can they recompute it from h
+        # inside the pass that applies GELU'(h) (sam3_lora_bwd_act with x == NULL): not saved then (393 MB per block at batch 8)
+        ctx.recompute_a = bool(need_w and t2 is not None and not q8_ok
+                               and bwd_act_recomputes_input(_rank_of(_master(A2), layout), h.dtype, drop_p))
+        ctx.save_for_backward(x2, h, a.new_empty(0) if ctx.recompute_a else a, W1, W2, A1, B1, A2, B2, t1, t2)
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
@@ -631,8 +651,8 @@ class _LoRAMlpFn(torch.autograd.Function):
         qg = None
         if need_x and ctx.q8_ok and drop_p == 0.0 and ga.dtype == torch.bfloat16:
             qg = fp8.producer_slots(W1, "g", ga.shape[0], ga.shape[1], ga.device)
-        lora_bwd_(gy2, a, t2, A2m, B2m, ga, gA2, gB2, s2, layout, accumulate=direct, drop_p=drop_p, seed=seed2, packed=pk2,
-                  gelu_pre=h, q8=qg)
+        lora_bwd_(gy2, None if ctx.recompute_a else a, t2, A2m, B2m, ga, gA2, gB2, s2, layout, accumulate=direct, drop_p=drop_p,
+                  seed=seed2, packed=pk2, gelu_pre=h, q8=qg)
         gx2 = None
         if need_x:
             with torch.autocast("cuda", enabled=False):

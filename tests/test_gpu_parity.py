@@ -753,3 +753,55 @@ def test_xcd_aware_tile_order_changes_placement_not_results(monkeypatch):
         _reload_knobs()
         for a, b in zip(outs["1"], outs["0"]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,fin,fout,rank", [(3000, 264, 520, 16), (1000, 2304, 136, 8), (50, 136, 64, 3)])
+def test_bwd_act_recomputes_its_input_from_the_pre_activation(M, fin, fout, rank):
+    """sam3_lora_bwd_act with x == NULL ("the input is GELU(pre_act)"): the GELU' pass recomputes GELU(h) tile by tile and
+    contracts it with gt for gA, instead of a second read of the stored activation.  Against the x-given form on
+    x = GELU(h) exactly as sam3_lora_fwd_act writes it: gx and gB bit-identical (the same kernels' arithmetic), gA equal up
+    to fp32 summation order (the partials are cut by different row blocks) and to the fp64 oracle; overwrite and accumulate
+    mode; ragged rows and a ragged last column chunk.  Refused where the kernels cannot: rank > 16, dropout, fp32."""
+    assert Fn.bwd_act_recomputes_input(rank, torch.bfloat16, 0.0)
+    assert not Fn.bwd_act_recomputes_input(24, torch.bfloat16, 0.0) and not Fn.bwd_act_recomputes_input(rank, torch.bfloat16, 0.1)
+    assert not Fn.bwd_act_recomputes_input(rank, torch.float32, 0.0)
+    g = torch.Generator(device=DEV).manual_seed(M + rank)
+    h = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    # a = GELU(h) by the library's own forward pass (zero adapter: the update leaves h as it is)
+    a, hh = torch.empty_like(h), h.clone()
+    Fn.lora_fwd_(torch.zeros(M, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(64, rank, device=DEV), torch.zeros(rank, fin, device=DEV),
+                 hh, 2.0, cases.LAYOUT_ROOT, gelu_out=a)
+    assert torch.equal(hh, h)
+    gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    gbase = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    A = torch.randn(fin, rank, device=DEV, generator=g) / fin ** 0.5
+    B = torch.randn(rank, fout, device=DEV, generator=g) / rank ** 0.5
+    y = torch.zeros(M, fout, device=DEV, dtype=torch.bfloat16)
+    tT = Fn.lora_fwd_(a, A, B, y, 2.0, cases.LAYOUT_ROOT, save_t=True)
+    res = {}
+    for mode in ("given", "recomputed"):
+        out = []
+        for accumulate in (False, True):
+            gx = gbase.clone()
+            gA, gB = torch.full_like(A, 0.5), torch.full_like(B, 0.25)
+            Fn.lora_bwd_(gy, a if mode == "given" else None, tT, A, B, gx, gA, gB, 2.0, cases.LAYOUT_ROOT, accumulate=accumulate,
+                         gelu_pre=h)
+            out += [gx, gA, gB]
+        res[mode] = out
+    for i in (0, 2, 3, 5):          # gx, gB
+        assert torch.equal(res["given"][i], res["recomputed"][i])
+    for i in (1, 4):                # gA
+        assert _relmax(res["recomputed"][i].cpu().numpy(), res["given"][i].cpu().numpy()) < 2e-6
+    _, gA_r, _ = O.adapter_backward(gy.float().cpu().numpy(), a.float().cpu().numpy(), A.cpu().numpy(), B.cpu().numpy(), 2.0,
+                                    cases.LAYOUT_ROOT, acc_dtype=np.float64)
+    assert _relmax(res["recomputed"][1].cpu().numpy(), gA_r) < 3e-5
+    # refusals
+    A24, B24 = torch.randn(fin, 24, device=DEV) / 16, torch.randn(24, fout, device=DEV) / 4
+    t24 = Fn.lora_fwd_(a, A24, B24, torch.zeros_like(y), 2.0, cases.LAYOUT_ROOT, save_t=True)
+    with pytest.raises(Fn.LoRAKernelError):
+        Fn.lora_bwd_(gy, None, t24, A24, B24, gbase.clone(), torch.zeros_like(A24), torch.zeros_like(B24), 2.0, cases.LAYOUT_ROOT, gelu_pre=h)
+    with pytest.raises(Fn.LoRAKernelError):
+        Fn.lora_bwd_(gy, None, tT, A, B, gbase.clone(), torch.zeros_like(A), torch.zeros_like(B), 2.0, cases.LAYOUT_ROOT, drop_p=0.1,
+                     seed=3, gelu_pre=h)
+    with pytest.raises(Fn.LoRAKernelError):
+        Fn.lora_bwd_(gy, None, tT, A, B, gbase.clone(), torch.zeros_like(A), torch.zeros_like(B), 2.0, cases.LAYOUT_ROOT)
