@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SAM3_LORA_ABI_VERSION 3
+#define SAM3_LORA_ABI_VERSION 4
 #define SAM3_LORA_MAX_RANK 1024
 
 #define SAM3_LORA_LAYOUT_ROOT 0

@@ -18,7 +18,7 @@ LAYOUT_ROOT = 0
 LAYOUT_PACKAGE = 1
 DT_BF16 = 0
 DT_F32 = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_RANK = 1024
 
 EXPORTS = (

@@ -248,7 +248,7 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     for sym in declared | vit_declared | loss_declared | fp8_declared | seg_declared:
         assert hasattr(lib, sym), sym
     lib2 = _ffi.load()
-    assert lib2.sam3_lora_abi_version() == 3
+    assert lib2.sam3_lora_abi_version() == 4
     # pure host-side argument validation works without a device
     assert lib2.sam3_lora_fwd_workspace_bytes(41472, 1024, 4736, 16, 0) > 0
     assert lib2.sam3_lora_fwd_workspace_bytes(41472, 1023, 4736, 16, 0) == 0
