@@ -1460,7 +1460,7 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
 constexpr int GA_TILES_PER_WG = 48;
 int ga_row_blocks(long long M) { return (int)(((M + 15) / 16 + GA_TILES_PER_WG - 1) / GA_TILES_PER_WG); }
 // x == NULL in sam3_lora_bwd_act: "the layer's input is act(pre_act)" -- recomputed inside the GELU' pass (k_t2<GA>).  Needs the
-// hi + lo kernels (bf16, one rank group of <= 16), no dropout mask on the branch input.  SAM3_LORA_GA_IN_T2=1 takes the same
+// hi + lo kernels (bf16, one rank group of <= 16), no dropout mask on the branch input; combines with the fp8 image.  SAM3_LORA_GA_IN_T2=1 takes the same
 // route when x IS given (A/B of the two forms; the caller then vouches that x == act(pre_act)).
 bool ga_in_pass_supported(int rank, int dtype, float drop_p) {
     return dtype == SAM3_LORA_BF16 && rank <= 16 && geo_of(rank, dtype).hl && drop_p == 0.f;
@@ -1489,7 +1489,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
     const Q8Out q8 = q8_in ? *q8_in : Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
     const int xcd = xcd_order_for(N);
-    if (q8.q) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
+    if (q8.q && !ga_in) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
 #define T2_Q8(AV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, AV, true, true, FV>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
                                          scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
         if (act == 1) { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(1, SAM3_FP8_E4M3); else T2_Q8(1, SAM3_FP8_E5M2); }
@@ -1497,9 +1497,13 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
 #undef T2_Q8
         return;
     }
-    if (ga_in) {    // checked by the caller: bf16, hi + lo, GELU' pass, no dropout mask, no fp8 image
-        hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, false, 0, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
-                           (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga);
+    if (ga_in) {    // checked by the caller: bf16, hi + lo, GELU' pass, no dropout mask
+#define T2_GA(QV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, QV, FV, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
+        if (!q8.q) T2_GA(false, 0);
+        else if (q8.fmt == SAM3_FP8_E4M3) T2_GA(true, SAM3_FP8_E4M3);
+        else T2_GA(true, SAM3_FP8_E5M2);
+#undef T2_GA
         return;
     }
 #define T2_LAUNCH(RTV, DV, AV, HV) \
@@ -1948,7 +1952,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
             if (gB_g && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, hl, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         }
         // GELU'-fused backward of the hi + lo kernels: gA from act(h) INSIDE the pass over gx (k_t2<GA>), no second read of x
-        ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && !dk.thr && !q8 && (x == nullptr || ga_in_t2_enabled());
+        ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && !dk.thr && (x == nullptr || ga_in_t2_enabled());
         if (gA_g && s3a && !ga_in_pass)
             launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
     }
@@ -1997,9 +2001,9 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
     } else {        // the layer's input is act(pre_act): recomputed inside the activation-derivative pass
         if (act != SAM3_LORA_ACT_GELU || !pre_act || !gx_inout || !tT_saved)
             return fail(SAM3_LORA_EINVAL, "x may be NULL only in sam3_lora_bwd_act with pre_act, gx_inout and the saved t^T given");
-        if (q8 || !ga_in_pass_supported(rank, dtype, drop_p))
-            return fail(SAM3_LORA_ENOTSUP, "x == NULL (input recomputed from pre_act) needs bf16, rank <= 16 with hi + lo operands, "
-                                           "no dropout and no fp8 image (sam3_lora_bwd_act_recomputes_input)");
+        if (!ga_in_pass_supported(rank, dtype, drop_p))
+            return fail(SAM3_LORA_ENOTSUP, "x == NULL (input recomputed from pre_act) needs bf16, rank <= 16 with hi + lo operands and "
+                                           "no dropout (sam3_lora_bwd_act_recomputes_input)");
     }
     if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");

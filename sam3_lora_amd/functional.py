@@ -594,7 +594,7 @@ class _LoRAMlpFn(torch.autograd.Function):
     """``fc2(GELU(fc1(x)))`` with both Linears LoRA-adapted, as ONE autograd node: the GELU and its derivative ride
     on the adapters' in-place passes over the [M, hidden] tensor (``sam3_lora_fwd_act`` / ``sam3_lora_bwd_act``)
     instead of being elementwise kernels of their own.  Saved: x, the pre-activation h, the two t^T -- and a = GELU(h) only
-    where the backward cannot recompute it inside its GELU' pass (dropout, rank > 16, fp32, the fp8 frozen-W mode)."""
+    where the backward cannot recompute it inside its GELU' pass (dropout, rank > 16, fp32)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, A1, B1, s1, W2, b2, A2, B2, s2, layout, drop_p, seed1, seed2, pk1, pk2, Wt1=None, Wt2=None,
@@ -620,7 +620,7 @@ class _LoRAMlpFn(torch.autograd.Function):
         ctx.wt = (Wt1, Wt2)
         # a = GELU(h) is fc2's input; the backward needs it for gA2 only, and where the kernels can they recompute it from h
         # inside the pass that applies GELU'(h) (sam3_lora_bwd_act with x == NULL): not saved then (393 MB per block at batch 8)
-        ctx.recompute_a = bool(need_w and t2 is not None and not q8_ok
+        ctx.recompute_a = bool(need_w and t2 is not None
                                and bwd_act_recomputes_input(_rank_of(_master(A2), layout), h.dtype, drop_p))
         ctx.save_for_backward(x2, h, a.new_empty(0) if ctx.recompute_a else a, W1, W2, A1, B1, A2, B2, t1, t2)
         return y.view(*x.shape[:-1], y.shape[-1])

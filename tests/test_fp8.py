@@ -211,3 +211,31 @@ def test_non_finite_elements_keep_their_encoding_and_stay_out_of_the_amax():
     x[11, 2] = -1.0e6                               # finite, far beyond the delayed range: saturates
     out4, scale4 = q(x)
     assert torch.allclose(scale4, torch.tensor([30.0 / 448.0], device=DEV)) and out4.float()[11, 2] == -448.0
+
+
+def test_fp8_image_and_recomputed_input_ride_on_the_same_pass():
+    """sam3_lora_bwd_act_q8 with x == NULL: the GELU' pass writes the e5m2 image AND recomputes GELU(h) for gA.  Image, gx and gB
+    bit-identical to the x-given call, gA equal up to summation order."""
+    from sam3_lora_amd import _ffi
+    from sam3_lora_amd import functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, fin, fout, r = 1500, 520, 264, 16
+    h = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    a, hh = torch.empty_like(h), h.clone()
+    Fn.lora_fwd_(torch.zeros(M, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(64, r, device=DEV), torch.zeros(r, fin, device=DEV),
+                 hh, 2.0, 0, gelu_out=a)
+    gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    gbase = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    A, B = torch.randn(fin, r, device=DEV, generator=g) / 16, torch.randn(r, fout, device=DEV, generator=g) / 4
+    tT = Fn.lora_fwd_(a, A, B, torch.zeros(M, fout, device=DEV, dtype=torch.bfloat16), 2.0, 0, save_t=True)
+    res = []
+    for x in (a, None):
+        gx = gbase.clone()
+        gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+        amax, scale = _slot_state(4.0)
+        img = torch.empty(M, fin, dtype=torch.float8_e5m2, device=DEV)
+        Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, 2.0, 0, gelu_pre=h, q8=(img, _ffi.FP8_E5M2, amax[0], amax[1], scale))
+        res.append((gx, gB, img.view(torch.uint8), amax[1].max().clone(), gA))
+    for u, v in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(u, v)
+    assert ((res[0][4] - res[1][4]).abs().max() / res[0][4].abs().max()).item() < 2e-6
