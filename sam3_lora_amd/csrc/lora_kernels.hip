@@ -676,8 +676,8 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) 
             } else if (HL) {
                 // (w_hi, w_lo) . (t_hi, t_hi)  +  (w_hi, w_lo) . (t_lo, 0)  =  w_hi t_hi + w_lo t_hi + w_hi t_lo   (lo.lo is below
                 // fp32 resolution).  Both are the K = 32 form on the SAME A-operand quad (the rank-32 kernel's registers: no extra
-                // operand registers).  A K = 16 MFMA for the third product measured WRONG results on MI355X when it followed
-                // the K = 32 one on the same accumulator (hipcc 7.2 emits the pair back to back: profiles/r03b_mfma_k16_after_k32.txt) -- one opcode only.
+                // operand registers).  (An earlier build used a K = 16 MFMA for the third product and was wrong; a stand-alone probe shows
+                // the instruction pair itself is fine -- profiles/r03b_mfma_k16_after_k32.txt.  One MFMA shape per chain is kept as the simpler form.)
                 const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
                 const uint4 tb = make_uint4(tlo.x, tlo.y, tlo.x, tlo.y);
                 const uint4 tc = make_uint4(thi.x, thi.y, 0u, 0u);
