@@ -676,8 +676,10 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) 
             } else if (HL) {
                 // (w_hi, w_lo) . (t_hi, t_hi)  +  (w_hi, w_lo) . (t_lo, 0)  =  w_hi t_hi + w_lo t_hi + w_hi t_lo   (lo.lo is below
                 // fp32 resolution).  Both are the K = 32 form on the SAME A-operand quad (the rank-32 kernel's registers: no extra
-                // operand registers).  (An earlier build used a K = 16 MFMA for the third product and was wrong; a stand-alone probe shows
-                // the instruction pair itself is fine -- profiles/r03b_mfma_k16_after_k32.txt.  One MFMA shape per chain is kept as the simpler form.)
+                // operand registers).  NOT a K = 16 MFMA for the third product: hipcc 7.2 emits v_mfma_f32_16x16x16_bf16 directly behind
+                // the v_mfma_f32_16x16x32_bf16 whose result it accumulates onto, without wait states, and MI355X then returns wrong,
+                // run-to-run varying sums (reproduced stand-alone: tools/probes/mfma_chain_probe.hip, profiles/r03b_mfma_k16_after_k32.txt;
+                // 16 s_nop states by hand, or an unrelated MFMA in between, make it exact).  One MFMA shape per accumulator chain.
                 const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
                 const uint4 tb = make_uint4(tlo.x, tlo.y, tlo.x, tlo.y);
                 const uint4 tc = make_uint4(thi.x, thi.y, 0u, 0u);

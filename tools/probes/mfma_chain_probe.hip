@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int MODE>   // 0: chained back to back; 1: chained with 8 tiles in flight (as the failing kernel: 8 independent chains)
+template <int MODE>   // 0: the compiler interleaves the eight chains; 1: each dependent pair adjacent; 2: adjacent + 16 s_nop states
 __global__ void k(const uint4* A8, const uint4* B8, const uint2* A4, const uint2* B4, f32x4* chained, f32x4* split, int iters) {
     const int lane = threadIdx.x, blk = blockIdx.x;
     f32x4 c[8], s[8];
@@ -24,8 +24,11 @@ __global__ void k(const uint4* A8, const uint4* B8, const uint2* A4, const uint2
             const uint4 a8 = A8[idx], b8 = B8[idx];
             const uint2 a4 = A4[idx], b4 = B4[idx];
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (MODE >= 1) __builtin_amdgcn_sched_barrier(0);     // MODE 1 / 2: the dependent pair ADJACENT in the instruction stream
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), d, 0, 0, 0);
+            if (MODE == 2) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MODE 2: sixteen wait states between them, by hand
             d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a4), __builtin_bit_cast(s16x4, b4), d, 0, 0, 0);
+            if (MODE >= 1) __builtin_amdgcn_sched_barrier(0);
             c[j] = d;
             f32x4 e = {0.f, 0.f, 0.f, 0.f}, f = {0.f, 0.f, 0.f, 0.f};
             e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), e, 0, 0, 0);
@@ -57,17 +60,21 @@ int main() {
     hipMemcpy(A8, ha8.data(), n * 16, hipMemcpyHostToDevice); hipMemcpy(B8, hb8.data(), n * 16, hipMemcpyHostToDevice);
     hipMemcpy(A4, ha4.data(), n * 8, hipMemcpyHostToDevice); hipMemcpy(B4, hb4.data(), n * 8, hipMemcpyHostToDevice);
     std::vector<float> hc(n * 4), hs(n * 4);
-    for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64), 0, 0, A8, B8, A4, B4, C, S, iters);
-        hipDeviceSynchronize();
-        hipMemcpy(hc.data(), C, n * 16, hipMemcpyDeviceToHost); hipMemcpy(hs.data(), S, n * 16, hipMemcpyDeviceToHost);
-        double worst = 0, mx = 0; long bad = 0;
-        for (long i = 0; i < (long)n * 4; ++i) {
-            const double d = fabs((double)hc[i] - hs[i]);
-            worst = d > worst ? d : worst; mx = fabs(hs[i]) > mx ? fabs(hs[i]) : mx;
-            if (d > 1e-3) ++bad;
+    for (int mode = 0; mode < 3; ++mode) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64), 0, 0, A8, B8, A4, B4, C, S, iters);
+            if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(64), 0, 0, A8, B8, A4, B4, C, S, iters);
+            if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64), 0, 0, A8, B8, A4, B4, C, S, iters);
+            hipDeviceSynchronize();
+            hipMemcpy(hc.data(), C, n * 16, hipMemcpyDeviceToHost); hipMemcpy(hs.data(), S, n * 16, hipMemcpyDeviceToHost);
+            double worst = 0, mx = 0; long bad = 0;
+            for (long i = 0; i < (long)n * 4; ++i) {
+                const double d = fabs((double)hc[i] - hs[i]);
+                worst = d > worst ? d : worst; mx = fabs(hs[i]) > mx ? fabs(hs[i]) : mx;
+                if (d > 1e-3) ++bad;
+            }
+            printf("mode %d run %d: max |chained - split| = %.3e (max |value| %.2f), elements off by > 1e-3: %ld of %ld\n", mode, rep, worst, mx, bad, (long)n * 4);
         }
-        printf("run %d: max |chained - split| = %.3e (max |value| %.2f), elements off by > 1e-3: %ld of %ld\n", rep, worst, mx, bad, (long)n * 4);
     }
     return 0;
 }
