@@ -1259,7 +1259,7 @@ DropKey make_dropkey(float p, uint64_t seed, uint64_t offset, int width, float* 
 }
 
 // Tuning / validation knobs come from the environment ONCE (first use, or sam3_lora_debug_reload_knobs): no getenv on
-// the launch path.  Seven names, looked up by pointer-stable literals through a tiny table.
+// the launch path.  A dozen names, looked up by pointer-stable literals through a tiny table.
 struct Knob {
     const char* name;
     bool set;
