@@ -11,10 +11,16 @@ large messages beat many small ones):
     HIP backward accumulates straight into the buffer and no gather/scatter copy ever runs;
   * the buffer is cut into a few contiguous buckets in reverse registration order (gradients
     complete from the last ViT block to the first); when the last gradient of a bucket has been
-    accumulated, that bucket is all-reduced (SUM) on a side HIP stream while backward continues;
-  * ``finish()`` makes the compute stream wait for the side stream and scales by 1/world_size
-    (mean, as DDP does).  Parameters that never receive a gradient in a step (the reference's
-    ``find_unused_parameters`` case) are reduced as zeros, never skipped.
+    accumulated AND every bucket before it has been launched, that bucket is all-reduced (SUM) on a
+    side HIP stream while backward continues.  Buckets are therefore issued in INDEX order on every
+    rank whatever order the hooks fire in (torch DDP's ``next_bucket`` rule): ranks whose graphs
+    differ -- the reference runs DDP with ``find_unused_parameters: true``, SURVEY section 3.4 --
+    still issue identical collective sequences;
+  * one "used this step" flag per parameter sits IN FRONT of the first-registered gradients, i.e. in
+    the bucket that is always launched last, when the flags are complete: no separate message;
+  * ``finish()`` launches what the hooks could not (in index order), makes the compute stream wait
+    for the side stream and scales by 1/world_size (mean, as DDP does).  Parameters that never
+    receive a gradient in a step are reduced as zeros, never skipped.
 
 Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU (tests).
 """
@@ -44,16 +50,16 @@ class LoRAGradReducer:
         # the identity) so that the whole side-stream path can be exercised on a single GPU
         self.run_alone = bool(run_collectives_alone) and dist.is_initialized()
         self.overlap = overlap and dev.type == "cuda"
-        # flat buffer, 64-element aligned slots, params in registration order
-        offs, n = [], 0
+        # flat buffer: [one "used this step" flag per parameter | 64-element aligned gradient slots in registration order].
+        # The flags are summed by the same exchange: torch DDP leaves the gradient of a GLOBALLY unused parameter None, so
+        # that the optimizer skips it (no weight decay, no moment update) -- see `finish`.  They sit in front of parameter
+        # 0, i.e. inside the bucket that is launched LAST on every rank, by which time they are complete.
+        self._flag0 = 0
+        self._grad0 = (len(self.params) + 63) // 64 * 64
+        offs, n = [], self._grad0
         for p in self.params:
             offs.append(n)
             n += (p.numel() + 63) // 64 * 64
-        # one "used this step" flag per parameter rides behind the gradients (summed by the same exchange): torch DDP leaves
-        # the gradient of a GLOBALLY unused parameter None, so that the optimizer skips it (no weight decay, no moment
-        # update) -- see `finish`
-        self._flag0 = n
-        n += (len(self.params) + 63) // 64 * 64
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self._offs = offs
         for p, o in zip(self.params, offs):
@@ -74,7 +80,7 @@ class LoRAGradReducer:
             end = offs[hi - 1] + (self.params[hi - 1].numel() + 63) // 64 * 64
             while lo > 0 and end - offs[lo - 1] <= per:
                 lo -= 1
-            self.buckets.append((offs[lo], end, lo, hi))
+            self.buckets.append((offs[lo] if lo > 0 else 0, end, lo, hi))      # the last one carries the flags
             hi = lo
         self._bucket_of = {}
         for b, (_, _, lo, hi_) in enumerate(self.buckets):
@@ -82,6 +88,8 @@ class LoRAGradReducer:
                 self._bucket_of[i] = b
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._next = 0             # buckets [0, _next) have been launched: the only one a hook may launch is _next
+        self.launch_log = []       # (bucket, "hook" | "finish") of the last armed step, in launch order
         self._works = []
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._armed = False
@@ -123,6 +131,8 @@ class LoRAGradReducer:
         for b, (_, _, lo, hi) in enumerate(self.buckets):
             self._pending[b] = hi - lo
             self._launched[b] = False
+        self._next = 0
+        self.launch_log = []
         self._works = []
         self._armed = True
 
@@ -145,15 +155,31 @@ class LoRAGradReducer:
                 param.grad = self.flat[o:o + param.numel()].view_as(param)
             b = self._bucket_of[idx]
             self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
+            # index order, on every rank: a complete bucket waits until all earlier buckets have gone (a bucket another
+            # rank completes early must not overtake one this rank has not completed -- the collectives would pair up
+            # with different buffers)
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next, "hook")
         return hook
 
-    def _launch(self, b: int):
-        if self._launched[b] or (self.world_size == 1 and not self.run_alone):
-            self._launched[b] = True
-            return
+    def _launch(self, b: int, origin: str):
+        assert b == self._next and not self._launched[b], "buckets are launched in index order, once"
         self._launched[b] = True
+        self._next = b + 1
+        self.launch_log.append((b, origin))
+        if self.world_size == 1 and not self.run_alone:
+            return
+        if b == len(self.buckets) - 1:
+            # the flags are complete: either every hook has fired (launched from a hook: all earlier buckets and this one
+            # are complete) or backward is over (launched from finish)
+            flags = self.flat[:len(self.params)]
+            if len(self.fired) == len(self.params):
+                flags.fill_(1.0)
+            else:
+                self._flags_host.zero_()
+                if self.fired:
+                    self._flags_host[sorted(self.fired)] = 1.0
+                flags.copy_(self._flags_host, non_blocking=True)
         s, e, _, _ = self.buckets[b]
         chunk = self.flat[s:e]
         if self.overlap:
@@ -164,25 +190,13 @@ class LoRAGradReducer:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """After backward: reduce whatever has not been launched (unused params), wait, average."""
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
+        """After backward: reduce whatever the hooks could not launch (buckets holding a locally unused parameter, and
+        everything behind them), in index order; wait; average."""
+        while self._next < len(self.buckets):
+            self._launch(self._next, "finish")
         exchange = self.world_size > 1 or self.run_alone
         locally_unused = [i for i in range(len(self.params)) if i not in self.fired] if self.skip_unused else []
-        flags = self.flat[self._flag0:self._flag0 + len(self.params)]
-        if exchange and self.skip_unused:
-            # the flags are only complete now, so they travel as one small trailing message
-            self._flags_host.zero_()
-            if self.fired:
-                self._flags_host[sorted(self.fired)] = 1.0
-            flags.copy_(self._flags_host, non_blocking=True)
-            if self.overlap:
-                self._side.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self._side):
-                    self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            else:
-                self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        flags = self.flat[:len(self.params)]
         for w in self._works:
             w.wait()
         if self.overlap:

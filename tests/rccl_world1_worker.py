@@ -59,9 +59,10 @@ def main():
     out["allreduce_calls"] = len(launched)
     out["all_on_side_stream_async"] = all(side and asyn for _, side, asyn in launched)
     out["elements_reduced"] = sum(n for n, _, _ in launched)
-    out["flat_elements"] = red._flag0 + len(red.params)          # gradient slots + one "used" flag per parameter (ddp.py)
-    out["grads_equal"] = bool(torch.equal(red.flat[:red._flag0], want[:red._flag0]))
-    out["flags"] = red.flat[red._flag0:red._flag0 + len(red.params)].tolist()
+    out["flat_elements"] = red.flat.numel()          # one "used" flag per parameter (in front) + the gradient slots (ddp.py)
+    out["grads_equal"] = bool(torch.equal(red.flat[red._grad0:], want[red._grad0:]))
+    out["flags"] = red.flat[:len(red.params)].tolist()
+    out["launch_log"] = red.launch_log
     nb = allreduce_scalar_sum(torch.tensor([5.0], device=dev))
     out["scalar"] = nb.item()
     dist.barrier()

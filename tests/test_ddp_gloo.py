@@ -109,11 +109,134 @@ def test_reducer_single_process_views_and_buckets():
     (params[0].sum() * 2 + params[1].sum() * 3).backward()
     red.finish()
     assert torch.all(params[0].grad == 2) and torch.all(params[1].grad == 3)
-    assert params[0].grad.data_ptr() == red.flat.data_ptr()
+    assert params[0].grad.data_ptr() == red.flat.data_ptr() + 4 * red._grad0     # the "used" flags sit in front
     assert red.nbytes >= 4 * (1600 + 4800)
     # set_to_none style replacement is folded back into the flat buffer
     red.zero_grad()
     params[0].grad = None
     (params[0].sum() * 5).backward()
     red.finish()
-    assert torch.all(red.flat[:1600] == 5)
+    assert torch.all(red.flat[red._grad0:red._grad0 + 1600] == 5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ranks whose graphs differ (the reference runs DDP with find_unused_parameters: true; e.g. the
+# geometry encoder's adapters only run when a batch carries box prompts).  Buckets must be issued in index order on
+# every rank whatever order their hooks complete in; VERDICT r3 weak #1 reproduced a gloo "collective mismatch" abort
+# with exactly the first case below.
+
+def _divergent_worker(rank, world, port, q, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sam3_lora_amd.ddp import LoRAGradReducer
+        torch.manual_seed(7)
+        calls = []
+        orig = dist.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append(t.numel())
+            return orig(t, *a, **k)
+        if case == "two_buckets":
+            # two single-parameter buckets of 600 and 700 elements; rank r backpropagates through parameter r % 2 only
+            params = [torch.nn.Parameter(torch.randn(600)), torch.nn.Parameter(torch.randn(700))]
+            used = {r: [r % 2] for r in range(world)}
+        else:
+            # six single-parameter buckets, every rank uses a different subset (parameter 5: nobody)
+            params = [torch.nn.Parameter(torch.randn(520 + 8 * i)) for i in range(6)]
+            sets = [[0, 3], [4], [1, 2, 4], [0, 1, 2, 3, 4], [2], [], [3, 0], [1]]
+            used = {r: sets[r % len(sets)] for r in range(world)}
+        red = LoRAGradReducer(params, bucket_bytes=2048)
+        assert len(red.buckets) == len(params)
+        dist.all_reduce = spy
+        ok = True
+        for step in range(3):
+            red.zero_grad()
+            mine = used[(rank + step) % world]                 # the unused sets move from rank to rank between steps
+            if mine:
+                sum((params[i] * float(rank + 1 + i)).sum() for i in mine).backward()
+            red.finish()
+            ok = ok and [b for b, _ in red.launch_log] == list(range(len(red.buckets)))
+            for i, p in enumerate(params):
+                users = [r for r in range(world) if i in used[(r + step) % world]]
+                if not users:
+                    ok = ok and p.grad is None
+                else:
+                    want = sum(float(r + 1 + i) for r in users) / world
+                    ok = ok and p.grad is not None and bool(torch.allclose(p.grad, torch.full_like(p, want)))
+        dist.all_reduce = orig
+        # identical collective sequences on every rank: one message per bucket per step, same sizes in the same order
+        sizes = torch.tensor(calls, dtype=torch.int64)
+        every = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(every, sizes)
+        ok = ok and len(calls) == 3 * len(red.buckets) and all(torch.equal(every[0], e) for e in every)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world(target, world, extra=()):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=150) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world,case", [(2, "two_buckets"), (4, "subsets"), (8, "subsets")])
+def test_ranks_with_different_unused_sets_issue_identical_collectives(world, case):
+    _run_world(_divergent_worker, world, (case,))
+
+
+def _hook_order_worker(rank, world, port, q):
+    """All parameters used on all ranks, but the hooks complete the buckets in a different order on every rank (manual
+    notify in a rank-dependent permutation): the launch order must still be the index order, and a bucket completed early
+    must wait for its predecessors."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sam3_lora_amd.ddp import LoRAGradReducer
+        params = [torch.nn.Parameter(torch.zeros(530 + 4 * i)) for i in range(5)]
+        red = LoRAGradReducer(params, bucket_bytes=2048)
+        red.zero_grad()
+        g = torch.Generator().manual_seed(rank)
+        order = torch.randperm(len(params), generator=g).tolist()
+        seen = []
+        for i in order:
+            params[i].grad.add_(float(rank + 1) * (i + 1))
+            red.notify(params[i])
+            seen.append([b for b, _ in red.launch_log])
+        # after each notify the launched buckets are a prefix 0..k-1 of the index order
+        ok = all(s == list(range(len(s))) for s in seen)
+        red.finish()
+        ok = ok and [b for b, _ in red.launch_log] == list(range(len(red.buckets)))
+        ok = ok and all(torch.allclose(p.grad, torch.full_like(p, (i + 1) * (world + 1) / 2)) for i, p in enumerate(params))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 4])
+def test_buckets_launch_in_index_order_whatever_order_the_hooks_fire_in(world):
+    _run_world(_hook_order_worker, world)
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [4, 8])
+def test_reducer_world4_and_world8_gloo(world):
+    """The world-2 protocol test (buckets, no-sync micro-batches, broadcast, used flags, notify) at 4 and 8 ranks, so that the
+    first real 8-GPU run is not also the first 8-rank run."""
+    _run_world(_worker, world)

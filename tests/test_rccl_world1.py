@@ -20,8 +20,10 @@ def test_reducer_runs_on_rccl_with_world_size_1():
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert r["backend"] == "nccl" and r["world"] == 1 and r["rccl_version"][0].isdigit()
     assert r["params_unchanged_by_broadcast"] and r["buckets"] >= 2
-    # one message per bucket + the trailing "used" flags (globally unused parameters keep grad None, as under torch DDP)
-    assert r["allreduce_calls"] == r["buckets"] + 1 and r["all_on_side_stream_async"]
+    # one message per bucket, launched in index order from the hooks; the "used" flags ride in the last one (globally unused
+    # parameters keep grad None, as under torch DDP)
+    assert r["allreduce_calls"] == r["buckets"] and r["all_on_side_stream_async"]
+    assert r["launch_log"] == [[b, "hook"] for b in range(r["buckets"])]
     assert r["flags"] and all(f == 1.0 for f in r["flags"])
     assert r["elements_reduced"] == r["flat_elements"]
     assert r["grads_equal"] and r["scalar"] == 5.0
