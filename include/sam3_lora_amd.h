@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SAM3_LORA_ABI_VERSION 4
+#define SAM3_LORA_ABI_VERSION 5
 #define SAM3_LORA_MAX_RANK 1024
 
 #define SAM3_LORA_LAYOUT_ROOT 0
@@ -200,6 +200,27 @@ int sam3_lora_bwd_act_q8(const void* gy, const void* x, const void* tT_saved, co
                          void* q8_out, int64_t ldq, int fmt, const float* amax_in, float* amax_out, float* scale_out);
 
 /*
+ * The adapter INSIDE the frozen GEMM: one MFMA kernel for the whole adapted Linear,
+ *
+ *     y_out[M, out] = x[M, in] @ W[out, in]^T + bias[out] + scaling * (drop(x) @ A_c) @ B_c         act_out = act(y_out)
+ *
+ * with fp32 accumulation of all three terms and ONE rounding to bf16 -- lora_layers.py:87-91 (LoRALinear.forward:
+ * original_layer(x) + lora(x)) and, with act = SAM3_LORA_ACT_GELU, the fc1 -> GELU site of sam3/model/vitdet.py:585-590.
+ * Against the frozen-GEMM-then-sam3_lora_fwd_act pair, [M, out] is written once per tensor and never re-read in the forward.
+ * W (row pitch ldw elements) and bias (or NULL) are the frozen layer's parameters in the activation dtype; A / B / layout /
+ * tT_out / dropout arguments as sam3_lora_fwd (the rank-r intermediate t = drop(x) A_c still comes from one pass over x, and
+ * rides into the GEMM as one more K step against the hi + lo image of scaling * B_c).  y_out need not be initialised.
+ * Supported (sam3_lora_linear_fwd_supported != 0): SAM3_LORA_BF16, rank <= 32, in_features a multiple of 64, out_features a
+ * multiple of 8; SAM3_LORA_ENOTSUP otherwise -- the caller then runs its GEMM and sam3_lora_fwd / _fwd_act.
+ */
+int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, int dtype);
+size_t sam3_lora_linear_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype);
+int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
+                         int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldw, int64_t ldy,
+                         int layout, float scaling, float drop_p, uint64_t seed, uint64_t offset, int dtype,
+                         void* workspace, size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact);
+
+/*
  * Merge for adapter-free inference: Wm[out, in] = W[out, in] + scaling * (A_c @ B_c)^T, fp32.
  * Replaces sam3_lora/lora/lora_layer.py:81-88 (merge_weights) and :160-178.
  */
@@ -220,11 +241,13 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
 #define SAM3_LORA_STAGE_T3_GA 16u   /* k_t3     : gA partials = gt^T.x                          */
 #define SAM3_LORA_STAGE_REDUCE 32u  /* fixed-order sum of the partials into gA/gB: rides on the backward's k_t2 launch (bf16, gx wanted), k_reduce otherwise */
 #define SAM3_LORA_STAGE_GT_REDUCE 64u /* k_gt_reduce : chunk sum of the gt partials k_t3 emitted (r <= 16)  */
+#define SAM3_LORA_STAGE_FUSED 128u  /* k_fused_linear : frozen GEMM + rank-r K step + bias + activation (sam3_lora_linear_fwd) */
 #define SAM3_LORA_STAGE_ALL 0xffffffffu
 unsigned sam3_lora_debug_set_stages(unsigned mask);
 
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
- * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE) are read from the
+ * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_SYNC,
+ * SAM3_LORA_FUSED_WGS) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);

@@ -18,7 +18,7 @@ LAYOUT_ROOT = 0
 LAYOUT_PACKAGE = 1
 DT_BF16 = 0
 DT_F32 = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_RANK = 1024
 
 EXPORTS = (
@@ -28,6 +28,7 @@ EXPORTS = (
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
     "sam3_lora_fwd_act_q8", "sam3_lora_bwd_act_q8", "sam3_lora_bwd_act_recomputes_input",
+    "sam3_lora_linear_fwd", "sam3_lora_linear_fwd_supported", "sam3_lora_linear_fwd_workspace_bytes",
 )
 ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
@@ -44,6 +45,7 @@ FP8_AMAX_SLOTS = 64            # SAM3_FP8_AMAX_SLOTS
 FP8_AMAX_STRIDE = 32           # SAM3_FP8_AMAX_STRIDE: floats between two slots (one 128-byte line per slot)
 FP8_AMAX_FLOATS = FP8_AMAX_SLOTS * FP8_AMAX_STRIDE
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
+STAGE_GT_REDUCE, STAGE_FUSED = 64, 128
 
 _lib = None
 _lock = threading.Lock()
@@ -95,6 +97,19 @@ def _declare(lib):
     lib.sam3_lora_fwd_act_q8.argtypes = list(lib.sam3_lora_fwd_act.argtypes) + q8_tail
     lib.sam3_lora_bwd_act_q8.restype = c_int
     lib.sam3_lora_bwd_act_q8.argtypes = list(lib.sam3_lora_bwd_act.argtypes) + q8_tail
+    lib.sam3_lora_linear_fwd_supported.restype = c_int
+    lib.sam3_lora_linear_fwd_supported.argtypes = [c_int, c_int, c_int, c_int]
+    lib.sam3_lora_linear_fwd_workspace_bytes.restype = c_size_t
+    lib.sam3_lora_linear_fwd_workspace_bytes.argtypes = [c_int64, c_int, c_int, c_int, c_int]
+    lib.sam3_lora_linear_fwd.restype = c_int
+    lib.sam3_lora_linear_fwd.argtypes = [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,   # x, W, bias, A, B, y_out, tT_out
+        c_int64, c_int, c_int, c_int,                          # M, in, out, rank
+        c_int64, c_int64, c_int64, c_int, c_float,             # ldx, ldw, ldy, layout, scaling
+        c_float, c_uint64, c_uint64, c_int,                    # drop_p, seed, offset, dtype
+        c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
+        c_int, c_void_p, c_int64,                              # act, act_out, ldact
+    ]
     lib.sam3_lora_bwd_act_recomputes_input.restype = c_int
     lib.sam3_lora_bwd_act_recomputes_input.argtypes = [c_int, c_int, ctypes.c_float]
     lib.sam3_lora_debug_reload_knobs.restype = None

@@ -1128,6 +1128,8 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ W, cons
 // ==========================================================================================
 // host side: C-ABI
 // ==========================================================================================
+#include "fused_linear.inc"
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -1268,7 +1270,8 @@ struct Knob {
 Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", false, 0},   {"SAM3_LORA_T1_NO_SPLIT", false, 0},
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
-                  {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0}};
+                  {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_SYNC", false, 0},
+                  {"SAM3_LORA_FUSED_WGS", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -2083,6 +2086,120 @@ int sam3_lora_bwd_act_q8(const void* gy, const void* x, const void* tT_saved, co
     return bwd_impl(gy, x, tT_saved, A, B, gx_inout, gA_accum, gB_accum, M, in_features, out_features, rank, ldgy, ldx, ldgx,
                     layout, scaling, drop_p, seed, offset, dtype, accumulate, workspace, workspace_bytes, stream, act, pre_act,
                     ldpre, &q8);
+}
+
+// ---- the adapter inside the frozen GEMM (fused_linear.inc)
+static int fused_cu_count() {
+    static std::atomic<int> n{0};
+    int v = n.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        v = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+        n.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, int dtype) {
+    return dtype == SAM3_LORA_BF16 && rank >= 1 && rank <= 32 && in_features > 0 && out_features > 0 &&
+           in_features % fl::BK == 0 && out_features % 8 == 0;
+}
+
+size_t sam3_lora_linear_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
+    if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
+    if (!sam3_lora_linear_fwd_supported(in_features, out_features, rank, dtype)) return 0;
+    return fwd_ws(M, in_features, out_features, rank, dtype).total + al256((size_t)out_features * 64 * 2);
+}
+
+int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
+                         int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldw, int64_t ldy,
+                         int layout, float scaling, float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace,
+                         size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact) {
+    g_err[0] = 0;
+    if (drop_p < 0.f || drop_p > 1.f) return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p);
+    int rc;
+    const bool pre = (layout & SAM3_LORA_PREPACKED) != 0;
+    layout &= ~SAM3_LORA_PREPACKED;
+    if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
+    if (!sam3_lora_linear_fwd_supported(in_features, out_features, rank, dtype))
+        return fail(SAM3_LORA_ENOTSUP, "fused linear: bf16 activations, rank <= 32, in_features %% %d == 0 (got in %d, rank %d, dtype %d)",
+                    fl::BK, in_features, rank, dtype);
+    if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
+    if ((rc = check_act(W, ldw, in_features, dtype, "W"))) return rc;
+    if ((rc = check_act(y_out, ldy, out_features, dtype, "y_out"))) return rc;
+    if (bias && ((uintptr_t)bias & 7)) return fail(SAM3_LORA_EINVAL, "bias must be 8-byte aligned");
+    if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
+    if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
+    if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
+    if (act && (rc = check_act(act_out, ldact, out_features, dtype, "act_out"))) return rc;
+    if (tT_out && ((uintptr_t)tT_out & 15)) return fail(SAM3_LORA_EINVAL, "tT_out must be 16-byte aligned");
+    if (256LL * ldx * 2 >= (1LL << 31) || 256LL * ldw * 2 >= (1LL << 31) || 256LL * ldy * 2 >= (1LL << 31) || (act && 256LL * ldact * 2 >= (1LL << 31)))
+        return fail(SAM3_LORA_ENOTSUP, "fused linear: row pitches beyond 4 M elements are not addressable by the tile descriptors");
+    const FwdWs w = fwd_ws(M, in_features, out_features, rank, dtype);
+    const size_t need = w.total + al256((size_t)out_features * 64 * 2);
+    if (!workspace || workspace_bytes < need)
+        return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float inv_keep;
+    const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
+    const Strides s = strides_of(layout, in_features, out_features, rank);
+    const Geo gq = geo_of(rank, dtype);
+    const int RP = gq.RP, RT = gq.RT, hr = gq.hl ? 1 : 0, hc = gq.hl ? 2 : 0;
+    const long long Mp = round_up(M, 64);
+    const PackedLayout pl = packed_layout(in_features, out_features, rank, dtype);
+    void* W1 = pre ? (void*)((char*)A + pl.w1) : (void*)(ws + w.w1);
+    void* W2t = pre ? (void*)((char*)A + pl.w2t) : (void*)(ws + w.w2t);
+    if (!pre && stage_on(SAM3_LORA_STAGE_PACK)) {
+        PackJob ja{(const float*)A, W1, RP, in_features, rank, in_features, s.a_sr, s.a_si, 0, 0, hr};
+        PackJob jb{(const float*)B, W2t, out_features, RP, out_features, rank, s.b_so, s.b_sr, 0, 0, hc};
+        launch_pack(ja, jb, st);
+    }
+    bf16_t* T = (bf16_t*)(ws + w.t);
+    bf16_t* TT = tT_out ? (bf16_t*)tT_out : (bf16_t*)(ws + w.tt);
+    bf16_t* Wext = (bf16_t*)(ws + w.total);
+    if (stage_on(SAM3_LORA_STAGE_T1))
+        launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1, T, TT, M, Mp, in_features, RT, gq.hl, st, dk,
+                          gq.RG == 16 ? (float*)(ws + w.t1p) : nullptr);
+    if (stage_on(SAM3_LORA_STAGE_PACK)) {
+        ProfScope ps(SAM3_LORA_STAGE_PACK, out_features, st);
+        const int groups = gq.hl ? 4 : 8;
+        hipLaunchKernelGGL(fl::k_wext, dim3((unsigned)((out_features * groups + 255) / 256)), dim3(256), 0, st, (const bf16_t*)W2t, Wext,
+                           out_features, RP, gq.hl ? 1 : 0, scaling * inv_keep);
+    }
+    if (stage_on(SAM3_LORA_STAGE_FUSED)) {
+        fl::Args fa;
+        fa.X = (const bf16_t*)x; fa.ldx = ldx;
+        fa.W = (const bf16_t*)W; fa.ldw = ldw;
+        fa.T = T; fa.Wext = Wext;
+        fa.bias = (const bf16_t*)bias;
+        fa.Y = (bf16_t*)y_out; fa.ldy = ldy;
+        fa.A = (bf16_t*)act_out; fa.lda = ldact;
+        fa.M = M; fa.Mp = Mp; fa.N = out_features; fa.K = in_features;
+        fa.tiles_m = (int)((M + fl::BM - 1) / fl::BM);
+        fa.tiles_n = (out_features + fl::BN - 1) / fl::BN;
+        const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
+        long long grid = env_int("SAM3_LORA_FUSED_WGS", fused_cu_count());
+        if (grid > ntiles) grid = ntiles;
+        if (grid < 1) grid = 1;
+        const int sync = (int)env_int("SAM3_LORA_FUSED_SYNC", 1);
+        const int trow = RP * 2;
+        ProfScope ps(SAM3_LORA_STAGE_FUSED, out_features, st);
+#define SAM3_FL_LAUNCH(ACT_, SYNC_, TROW_) \
+        hipLaunchKernelGGL((fl::k_fused_linear<ACT_, SYNC_, TROW_>), dim3((unsigned)grid), dim3(fl::NTHREADS), 0, st, fa)
+        if (act) {
+            if (trow == 64) { if (sync) SAM3_FL_LAUNCH(1, 1, 64); else SAM3_FL_LAUNCH(1, 0, 64); }
+            else { if (sync) SAM3_FL_LAUNCH(1, 1, 32); else SAM3_FL_LAUNCH(1, 0, 32); }
+        } else {
+            if (trow == 64) { if (sync) SAM3_FL_LAUNCH(0, 1, 64); else SAM3_FL_LAUNCH(0, 0, 64); }
+            else { if (sync) SAM3_FL_LAUNCH(0, 1, 32); else SAM3_FL_LAUNCH(0, 0, 32); }
+        }
+#undef SAM3_FL_LAUNCH
+    }
+    return launch_ok("sam3_lora_linear_fwd");
 }
 
 int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm, int in_features, int out_features,

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import _ffi
 from ._ffi import DT_BF16, DT_F32, LAYOUT_PACKAGE, LAYOUT_ROOT, PREPACKED, LoRAKernelError
 
-__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "LAYOUT_ROOT", "LAYOUT_PACKAGE",
+__all__ = ["lora_linear", "lora_fwd_", "lora_bwd_", "lora_linear_fwd_", "linear_fwd_supported", "set_fused_linear", "fused_linear_enabled", "merge_weight", "pack_operands", "PackedOperands", "lora_mlp_gelu", "TransposedCopy", "frozen_linear", "LAYOUT_ROOT", "LAYOUT_PACKAGE",
            "enable_direct_grad_accumulation", "direct_grad_accumulation", "pack_operands_many", "repack_adapters"]
 
 _ws_lock = threading.Lock()
@@ -345,6 +345,66 @@ def lora_fwd_(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, y2: torch.Tens
     return tT
 
 
+_FUSED = {"on": None}     # None: follow SAM3_LORA_FUSED_LINEAR in the environment (read once)
+
+
+def set_fused_linear(on: Optional[bool]) -> None:
+    """Route the fc1 -> GELU site of the fused MLP node through ``sam3_lora_linear_fwd`` (the adapter inside the frozen GEMM,
+    SURVEY 8f-1) instead of hipBLASLt + ``sam3_lora_fwd_act``.  ``None`` restores the environment default."""
+    _FUSED["on"] = on
+
+
+def fused_linear_enabled() -> bool:
+    if _FUSED["on"] is None:
+        import os
+        _FUSED["on"] = os.environ.get("SAM3_LORA_FUSED_LINEAR", "0") not in ("", "0")
+    return bool(_FUSED["on"])
+
+
+def linear_fwd_supported(fin: int, fout: int, rank: int, dtype) -> bool:
+    """Whether :func:`lora_linear_fwd_` takes this shape (sam3_lora_linear_fwd_supported)."""
+    if dtype != torch.bfloat16:
+        return False
+    return bool(_ffi.load().sam3_lora_linear_fwd_supported(int(fin), int(fout), int(rank), DT_BF16))
+
+
+def lora_linear_fwd_(x2: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor,
+                     scaling: float, layout: int, save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
+                     packed: Optional[torch.Tensor] = None, gelu: bool = False, y_out: Optional[torch.Tensor] = None,
+                     gelu_out: Optional[torch.Tensor] = None):
+    """The whole adapted Linear as ONE kernel (sam3_lora_linear_fwd): ``y = x2 @ W^T + bias + scaling * (drop(x2) @ A_c) @ B_c``
+    with fp32 accumulation of all three terms and one rounding; ``gelu=True`` also returns GELU(y) from the same pass.
+    Returns ``(y, gelu_out or None, saved-t blob or None)``."""
+    lib = _ffi.load()
+    _require_cuda(x2, W, A, B, bias)
+    M, fin = x2.shape
+    fout = W.shape[0]
+    rank = _rank_of(A, layout)
+    dt = _dtype_code(x2)
+    if W.dtype != x2.dtype or (bias is not None and bias.dtype != x2.dtype) or W.shape[1] != fin or W.stride(1) != 1:
+        raise LoRAKernelError("sam3_lora_amd: x, W and bias must share a dtype; W is [out, in] with unit column stride")
+    if bias is not None and not bias.is_contiguous():
+        bias = bias.contiguous()
+    nws = lib.sam3_lora_linear_fwd_workspace_bytes(M, fin, fout, rank, dt)
+    if nws == 0:
+        raise LoRAKernelError(f"sam3_lora_linear_fwd_workspace_bytes: {_ffi.last_error() or 'shape / dtype not supported'}")
+    ws = _workspace(x2.device, nws)
+    y = y_out if y_out is not None else torch.empty(M, fout, dtype=x2.dtype, device=x2.device)
+    a = None
+    if gelu:
+        a = gelu_out if gelu_out is not None else torch.empty_like(y)
+    tT = saved_t_like(M, rank, x2.device, dt) if save_t else None
+    rc = lib.sam3_lora_linear_fwd(
+        x2.data_ptr(), W.data_ptr(), bias.data_ptr() if bias is not None else None,
+        (packed if packed is not None else A).data_ptr(), B.data_ptr(), y.data_ptr(), tT.data_ptr() if tT is not None else None,
+        M, fin, fout, rank, x2.stride(0), W.stride(0), y.stride(0), layout | (PREPACKED if packed is not None else 0),
+        float(scaling), float(drop_p), int(seed), int(offset), dt, ws.data_ptr(), ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream),
+        _ffi.ACT_GELU if gelu else _ffi.ACT_NONE, a.data_ptr() if a is not None else None, a.stride(0) if a is not None else 0)
+    _ffi.check(rc, "sam3_lora_linear_fwd")
+    return y, a, tT
+
+
 def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor,
               gx2: Optional[torch.Tensor], gA: Optional[torch.Tensor], gB: Optional[torch.Tensor], scaling: float,
               layout: int, accumulate: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
@@ -604,13 +664,21 @@ class _LoRAMlpFn(torch.autograd.Function):
         cdt = W1.dtype
         x2 = _rows(x if x.dtype == cdt else x.to(cdt))
         need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
-        with torch.autocast("cuda", enabled=False):
-            h = _frozen_fwd(x2, W1, b1, x_q8)
-        a = torch.empty_like(h)
-        # fp8 frozen-W mode: GELU(h) leaves the adapter pass as bf16 (for fc2's adapter) AND as the e4m3 input of fc2's GEMM
-        qa = fp8.producer_slots(W2, "x", h.shape[0], h.shape[1], h.device) if (q8_ok and h.dtype == torch.bfloat16) else None
-        t1 = lora_fwd_(x2, _master(A1), _master(B1), h, s1, layout, save_t=need_w, drop_p=drop_p, seed=seed1, packed=pk1,
-                       gelu_out=a, q8=qa)
+        fused1 = (fused_linear_enabled() and not q8_ok and not fp8.eligible(x2, W1)
+                  and linear_fwd_supported(W1.shape[1], W1.shape[0], _rank_of(_master(A1), layout), cdt))
+        if fused1:
+            # frozen GEMM + rank-r K step + bias + GELU in ONE kernel -- h and a are written once, never re-read
+            qa = None
+            h, a, t1 = lora_linear_fwd_(x2, W1, b1, _master(A1), _master(B1), s1, layout, save_t=need_w, drop_p=drop_p,
+                                        seed=seed1, packed=pk1, gelu=True)
+        else:
+            with torch.autocast("cuda", enabled=False):
+                h = _frozen_fwd(x2, W1, b1, x_q8)
+            a = torch.empty_like(h)
+            # fp8 frozen-W mode: GELU(h) leaves the adapter pass as bf16 (for fc2's adapter) AND as the e4m3 input of fc2's GEMM
+            qa = fp8.producer_slots(W2, "x", h.shape[0], h.shape[1], h.device) if (q8_ok and h.dtype == torch.bfloat16) else None
+            t1 = lora_fwd_(x2, _master(A1), _master(B1), h, s1, layout, save_t=need_w, drop_p=drop_p, seed=seed1, packed=pk1,
+                           gelu_out=a, q8=qa)
         with torch.autocast("cuda", enabled=False):
             y = fp8.fp8_linear_q(qa[0], qa[4], W2, b2) if qa is not None else _frozen_fwd(a, W2, b2)
         ctx.q8_ok = q8_ok

@@ -1,0 +1,195 @@
+"""
+GPU parity of SURVEY 8(f)-1, the adapter INSIDE the frozen GEMM (``sam3_lora_linear_fwd``, csrc/fused_linear.inc):
+
+    y = x W^T + b + s (drop(x) A_c) B_c           a = GELU(y)                lora_layers.py:87-91 + vitdet.py:585-590
+
+against the fp64 numpy oracle (oracle/lora_oracle.py: ``lora_linear_forward``) on the same bf16 inputs.  Bar (bf16, r <= 16,
+hi + lo images): every output element within ONE bf16 rounding of the fp64 value (``_one_rounding``) -- tighter than the
+GEMM-then-adapter pair, which rounds the frozen GEMM's output before the branch is added; 16 < r <= 32 (single-rounded
+images): 1e-2 of max.  The saved t^T is bit-identical to ``sam3_lora_fwd``'s, so the backward is unchanged.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lora_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from sam3_lora_amd import functional as Fn
+    from sam3_lora_amd import _ffi
+
+DEV = "cuda:0"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def _reload():
+    _ffi.load().sam3_lora_debug_reload_knobs()
+
+
+@pytest.fixture(autouse=True)
+def _knobs_back():
+    yield
+    if torch.cuda.is_available():
+        for k in ("SAM3_LORA_FUSED_SYNC", "SAM3_LORA_FUSED_WGS", "SAM3_LORA_SINGLE_ROUND"):
+            os.environ.pop(k, None)
+        _reload()
+        Fn.set_fused_linear(None)
+
+
+def _one_rounding(got, ref, slack=3e-5):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    bound = 2.0 ** -8 * np.abs(ref) + slack * np.abs(ref).max()
+    bad = np.abs(got - ref) > bound
+    assert not bad.any(), (int(bad.sum()), float((np.abs(got - ref) / (np.abs(ref).max() + 1e-30)).max()))
+
+
+def _case(M, fin, fout, rank, layout, seed, bias=True):
+    rng = np.random.default_rng(seed)
+    x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    W = O.bf16_round((rng.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32))
+    b = O.bf16_round((rng.standard_normal(fout) * 0.1).astype(np.float32)) if bias else None
+    A = (rng.uniform(-1, 1, (fin, rank) if layout == 0 else (rank, fin)) / np.sqrt(rank)).astype(np.float32)
+    B = (rng.standard_normal((rank, fout) if layout == 0 else (fout, rank)) * 0.05).astype(np.float32)
+    return x, W, b, A, B
+
+
+# ragged everything: M not a multiple of 256 (or 16), N with a partial 256-tile and a partial 64-column wave tile, K = 1..3 steps
+SHAPES = [(1000, 128, 520, 16, 0), (1000, 128, 520, 16, 1), (37, 64, 8, 4, 0), (513, 192, 776, 8, 1), (256, 64, 256, 16, 0),
+          (300, 128, 264, 1, 0)]
+
+
+@pytest.mark.parametrize("M,fin,fout,rank,layout", SHAPES)
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("packed", [False, True])
+def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, layout, gelu, packed):
+    x, W, b, A, B = _case(M, fin, fout, rank, layout, seed=M + rank)
+    s = 1.7
+    want = O.lora_linear_forward(x, W, b, A, B, s, layout, acc_dtype=np.float64)
+    dA, dB = _t(A), _t(B)
+    blob = Fn.pack_operands(dA, dB, layout) if packed else None
+    y, a, tT = Fn.lora_linear_fwd_(_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), dA, dB, s, layout,
+                                   save_t=True, packed=blob, gelu=gelu)
+    _one_rounding(y.float().cpu().numpy(), want)
+    if gelu:
+        _one_rounding(a.float().cpu().numpy(), torch.nn.functional.gelu(y.double()).cpu().numpy(), slack=1e-6)
+    # the saved t^T is what sam3_lora_fwd saves: the backward is unchanged
+    y2 = torch.zeros_like(y)
+    tT2 = Fn.lora_fwd_(_t(x, torch.bfloat16), dA, dB, y2, s, layout, save_t=True, packed=blob)
+    assert torch.equal(tT, tT2)
+
+
+def test_no_bias_and_rank_32_single_rounded_images():
+    M, fin, fout = 700, 128, 520
+    for rank, tol in ((32, 1e-2), (24, 1e-2)):
+        x, W, _, A, B = _case(M, fin, fout, rank, 0, seed=rank, bias=False)
+        want = O.lora_linear_forward(x, W, None, A, B, 2.0, 0, acc_dtype=np.float64)
+        y, _, _ = Fn.lora_linear_fwd_(_t(x, torch.bfloat16), _t(W, torch.bfloat16), None, _t(A), _t(B), 2.0, 0)
+        err = np.abs(y.float().cpu().numpy() - want).max() / np.abs(want).max()
+        assert err < tol, err
+    # r <= 16 with the single-rounded images (SAM3_LORA_SINGLE_ROUND=1): the [M][16] row image of t
+    os.environ["SAM3_LORA_SINGLE_ROUND"] = "1"
+    _reload()
+    x, W, b, A, B = _case(M, fin, fout, 16, 0, seed=5)
+    want = O.lora_linear_forward(x, W, b, A, B, 2.0, 0, acc_dtype=np.float64)
+    y, _, _ = Fn.lora_linear_fwd_(_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), 2.0, 0)
+    assert np.abs(y.float().cpu().numpy() - want).max() / np.abs(want).max() < 1e-2
+
+
+def test_dropout_on_the_branch_input_only():
+    M, fin, fout, rank, s, p, seed = 777, 128, 520, 16, 2.0, 0.2, 99
+    x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=11)
+    mask = O.dropout_scale_mask(M, fin, p, seed)
+    want = O.base_linear(x, W, b, np.float64) + O.adapter_delta(x, A, B, s, 0, drop_scale_mask=mask, acc_dtype=np.float64)
+    y, _, _ = Fn.lora_linear_fwd_(_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), s, 0,
+                                  drop_p=p, seed=seed)
+    _one_rounding(y.float().cpu().numpy(), want)
+
+
+def test_persistent_tile_walk_and_sync_modes_are_bit_identical():
+    """12 tiles on 1 / 3 / 5 / 256 workgroups (tiles per workgroup: 12, 4, 2-3, 1) and both barrier forms: the same bits."""
+    M, fin, fout, rank = 1000, 192, 776, 16
+    x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=3)
+    args = (_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), 2.0, 0)
+    outs = []
+    for wgs in ("1", "3", "5", "256"):
+        for sync in ("0", "1"):
+            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_SYNC"] = wgs, sync
+            _reload()
+            for _ in range(3):              # repeated: a race between DMA and read would show as run-to-run differences
+                y, a, _ = Fn.lora_linear_fwd_(*args, gelu=True)
+                outs.append((y.clone(), a.clone()))
+    for y, a in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(a, outs[0][1])
+    want = O.lora_linear_forward(x, W, b, A, B, 2.0, 0, acc_dtype=np.float64)
+    _one_rounding(outs[0][0].float().cpu().numpy(), want)
+
+
+def test_fused_linear_at_configs1_fc1_shape():
+    """BASELINE configs[1]: M = 8 x 5184, fc1 1024 -> 4736, r = 16: sampled rows against fp64 on the GPU (the oracle's
+    expression in torch.float64), all columns; a = GELU(h); bit-reproducible run to run."""
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M, fin, fout, rank, s = 41472, 1024, 4736, 16, 2.0
+    x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    W = (torch.randn(fout, fin, device=DEV, generator=g) / 32).bfloat16()
+    b = (torch.randn(fout, device=DEV, generator=g) * 0.1).bfloat16()
+    A = (torch.rand(fin, rank, device=DEV, generator=g) - 0.5) / 2
+    B = torch.randn(rank, fout, device=DEV, generator=g) * 0.05
+    y, a, _ = Fn.lora_linear_fwd_(x, W, b, A, B, s, 0, gelu=True)
+    y2, a2, _ = Fn.lora_linear_fwd_(x, W, b, A, B, s, 0, gelu=True)
+    assert torch.equal(y, y2) and torch.equal(a, a2)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (1500,), generator=torch.Generator().manual_seed(1))]).to(DEV)
+    xd = x[rows].double()
+    want = xd @ W.double().t() + b.double() + s * ((xd @ A.double()) @ B.double())
+    _one_rounding(y[rows].float().cpu().numpy(), want.cpu().numpy())
+    _one_rounding(a[rows].float().cpu().numpy(), torch.nn.functional.gelu(y[rows].double()).cpu().numpy(), slack=1e-6)
+    assert torch.isfinite(y).all() and torch.isfinite(a).all()
+
+
+def test_mlp_node_with_the_fused_fc1_matches_the_two_pass_form():
+    """``lora_mlp_gelu`` with SAM3_LORA_FUSED_LINEAR on / off: the fused fc1 differs from hipBLASLt + sam3_lora_fwd_act by the one
+    rounding it does NOT do (the frozen GEMM's output before the branch is added): outputs and gradients agree to bf16 noise."""
+    import lora_layers as L
+    torch.manual_seed(0)
+    fin, hid, M = 256, 1024, 1500
+    fc1, fc2 = torch.nn.Linear(fin, hid), torch.nn.Linear(hid, fin)
+    m1, m2 = L.LoRALinear(fc1, rank=16, alpha=32), L.LoRALinear(fc2, rank=16, alpha=32)
+    for m in (m1, m2):
+        m.to(DEV)
+        m.original_layer.to(torch.bfloat16)
+        m.original_layer.weight.requires_grad_(False), m.original_layer.bias.requires_grad_(False)
+        with torch.no_grad():
+            m.lora.lora_B.normal_(0, 0.05)
+    x0 = torch.randn(M, fin, device=DEV).bfloat16()
+    gy = torch.randn(M, fin, device=DEV).bfloat16()
+    res = {}
+    for on in (False, True):
+        Fn.set_fused_linear(on)
+        x = x0.clone().requires_grad_(True)
+        for m in (m1, m2):
+            m.lora.lora_A.grad = m.lora.lora_B.grad = None
+        y = Fn.lora_mlp_gelu(x, (m1.original_layer.weight, m1.original_layer.bias, m1.lora),
+                             (m2.original_layer.weight, m2.original_layer.bias, m2.lora), Fn.LAYOUT_ROOT, True)
+        assert y is not None
+        y.backward(gy)
+        res[on] = [y.detach().float(), x.grad.float()] + [p.grad.clone() for m in (m1, m2) for p in (m.lora.lora_A, m.lora.lora_B)]
+    for u, v, tol in zip(res[False], res[True], (1.5e-2, 1.5e-2, 5e-3, 5e-3, 5e-3, 5e-3)):
+        assert (u - v).abs().max() / v.abs().max() < tol, ((u - v).abs().max() / v.abs().max()).item()
+
+
+def test_unsupported_shapes_say_so():
+    lib = _ffi.load()
+    assert lib.sam3_lora_linear_fwd_supported(1024, 4736, 16, 0) == 1
+    assert lib.sam3_lora_linear_fwd_supported(1000, 4736, 16, 0) == 0      # K not a multiple of 64
+    assert lib.sam3_lora_linear_fwd_supported(1024, 4736, 33, 0) == 0      # more than one rank group
+    assert lib.sam3_lora_linear_fwd_supported(1024, 4736, 16, 1) == 0      # fp32 activations
+    x = torch.zeros(64, 1000, device=DEV, dtype=torch.bfloat16)
+    W = torch.zeros(64, 1000, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(Fn.LoRAKernelError):
+        Fn.lora_linear_fwd_(x, W, None, torch.zeros(1000, 4, device=DEV), torch.zeros(4, 64, device=DEV), 1.0, 0)
