@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--fp8-frozen", action="store_true",
                     help="headline step with fp8 frozen-W base GEMMs (BASELINE configs[4] mode; default: measured as a sub-object)")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 frozen-W sub-measurement")
+    ap.add_argument("--no-fused-ab", action="store_true", help="skip the fused-fc1 on/off sub-measurement")
     ap.add_argument("--model", choices=["sam3", "tiny"], default="sam3",
                     help="tiny: the parity fixture's widths at 112^2 (contract tests only; the line says so)")
     return ap.parse_args()
@@ -843,6 +844,26 @@ def main():
                 dsm = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             if rank == 0:
                 out["data_step"] = dsm
+        if not args.fp8_frozen and args.act_dtype == "bf16" and not args.no_fused_ab:
+            # SURVEY 8(f)-1 A/B inside the same process: the whole step with the fc1 -> GELU site through sam3_lora_linear_fwd
+            # (the adapter inside the frozen GEMM) and through hipBLASLt + sam3_lora_fwd_act; whichever is NOT the default here
+            from sam3_lora_amd.functional import fused_linear_enabled, set_fused_linear
+            dflt = fused_linear_enabled()
+            set_fused_linear(not dflt)
+            try:
+                for _ in range(2):
+                    full.step()
+                u_steps = max(3, min(args.steps, 6))
+                dtu = timed(full.step, u_steps)
+                if rank == 0:
+                    out["fused_linear"] = {
+                        "default_on": dflt, "this_variant_on": not dflt,
+                        "value": round(world * args.batch * u_steps / dtu, 2), "unit": "images/s",
+                        "ms_per_step": round(dtu / u_steps * 1e3, 3), "steps": u_steps, "loss": round(full.last_loss.item(), 4),
+                        "what": "the same whole training step with the OTHER setting of SAM3_LORA_FUSED_LINEAR: on = fc1 + adapter + "
+                                "bias + GELU as one MFMA kernel (sam3_lora_linear_fwd), off = hipBLASLt GEMM + sam3_lora_fwd_act"}
+            finally:
+                set_fused_linear(dflt)
         if not args.no_fp8 and not args.fp8_frozen and args.act_dtype == "bf16":
             # BASELINE configs[4]'s mode on the same workload: frozen base GEMMs on the fp8 MFMA kernels
             loss_bf16 = full.last_loss.item()

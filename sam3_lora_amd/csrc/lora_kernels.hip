@@ -1270,8 +1270,8 @@ struct Knob {
 Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", false, 0},   {"SAM3_LORA_T1_NO_SPLIT", false, 0},
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
-                  {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_SYNC", false, 0},
-                  {"SAM3_LORA_FUSED_WGS", false, 0}};
+                  {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
+                  {"SAM3_LORA_FUSED_ORDER", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -2181,21 +2181,19 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
         fa.M = M; fa.Mp = Mp; fa.N = out_features; fa.K = in_features;
         fa.tiles_m = (int)((M + fl::BM - 1) / fl::BM);
         fa.tiles_n = (out_features + fl::BN - 1) / fl::BN;
+        fa.order = (int)env_int("SAM3_LORA_FUSED_ORDER", 0);
         const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
         long long grid = env_int("SAM3_LORA_FUSED_WGS", fused_cu_count());
         if (grid > ntiles) grid = ntiles;
         if (grid < 1) grid = 1;
-        const int sync = (int)env_int("SAM3_LORA_FUSED_SYNC", 1);
         const int trow = RP * 2;
         ProfScope ps(SAM3_LORA_STAGE_FUSED, out_features, st);
-#define SAM3_FL_LAUNCH(ACT_, SYNC_, TROW_) \
-        hipLaunchKernelGGL((fl::k_fused_linear<ACT_, SYNC_, TROW_>), dim3((unsigned)grid), dim3(fl::NTHREADS), 0, st, fa)
+#define SAM3_FL_LAUNCH(ACT_, TROW_) \
+        hipLaunchKernelGGL((fl::k_fused_linear<ACT_, TROW_>), dim3((unsigned)grid), dim3(fl::NTHREADS), 0, st, fa)
         if (act) {
-            if (trow == 64) { if (sync) SAM3_FL_LAUNCH(1, 1, 64); else SAM3_FL_LAUNCH(1, 0, 64); }
-            else { if (sync) SAM3_FL_LAUNCH(1, 1, 32); else SAM3_FL_LAUNCH(1, 0, 32); }
+            if (trow == 64) SAM3_FL_LAUNCH(1, 64); else SAM3_FL_LAUNCH(1, 32);
         } else {
-            if (trow == 64) { if (sync) SAM3_FL_LAUNCH(0, 1, 64); else SAM3_FL_LAUNCH(0, 0, 64); }
-            else { if (sync) SAM3_FL_LAUNCH(0, 1, 32); else SAM3_FL_LAUNCH(0, 0, 32); }
+            if (trow == 64) SAM3_FL_LAUNCH(0, 64); else SAM3_FL_LAUNCH(0, 32);
         }
 #undef SAM3_FL_LAUNCH
     }

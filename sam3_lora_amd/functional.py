@@ -350,14 +350,17 @@ _FUSED = {"on": None}     # None: follow SAM3_LORA_FUSED_LINEAR in the environme
 
 def set_fused_linear(on: Optional[bool]) -> None:
     """Route the fc1 -> GELU site of the fused MLP node through ``sam3_lora_linear_fwd`` (the adapter inside the frozen GEMM,
-    SURVEY 8f-1) instead of hipBLASLt + ``sam3_lora_fwd_act``.  ``None`` restores the environment default."""
+    SURVEY 8f-1) instead of hipBLASLt + ``sam3_lora_fwd_act``.  On by default where the kernel applies (bf16, rank <= 32, in_features a
+    multiple of 64; measured on MI355X at the benchmark's fc1 site: 528 us against 584 us, profiles/r04a_fused_linear_probe.json;
+    whole step 239.0 against 241.0 ms, profiles/r04c_bench_full_ab.json); ``SAM3_LORA_FUSED_LINEAR=0`` or ``set_fused_linear(False)``
+    selects the two-pass form.  ``None`` restores the environment default."""
     _FUSED["on"] = on
 
 
 def fused_linear_enabled() -> bool:
     if _FUSED["on"] is None:
         import os
-        _FUSED["on"] = os.environ.get("SAM3_LORA_FUSED_LINEAR", "0") not in ("", "0")
+        _FUSED["on"] = os.environ.get("SAM3_LORA_FUSED_LINEAR", "1") not in ("", "0")
     return bool(_FUSED["on"])
 
 

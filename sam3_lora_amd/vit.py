@@ -603,14 +603,60 @@ def sam3_vit(**overrides) -> ViT:
     return ViT(**overrides)
 
 
-def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloat16) -> nn.Module:
-    """MI355X training layout: every frozen tensor in bf16, trainable (LoRA) tensors stay fp32."""
-    for p in model.parameters():
-        if not p.requires_grad and p.dtype.is_floating_point:
+# Sub-modules of the SAM3 image model that stay in fp32 inside the bf16 training layout ("islands"): the DETR decoder with its
+# box / presence heads and the scoring head -- 21 M parameters on 200-400 queries, a negligible share of the step's bytes and
+# FLOPs, and the place where the matcher's cost and the box regression are formed.  torch.autocast, the reference's own
+# mixed-precision mode, keeps exactly this kind of state (residuals, LayerNorm, small heads) in fp32.  Measured on MI355X against the
+# reference's fp32 run: profiles/r04e_bf16_islands.json.
+DEFAULT_FP32_ISLANDS = ("transformer.decoder", "dot_prod_scoring")
+_ISLAND_CONSUMERS = ("segmentation_head",)      # bf16 modules that take an island's fp32 outputs (the decoder's queries)
+
+
+def _tree_cast(obj, dtype):
+    if isinstance(obj, torch.Tensor):
+        if obj.dtype in (torch.float32, torch.bfloat16) and obj.dtype != dtype:
+            return obj.to(dtype)
+        return obj
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_tree_cast(o, dtype) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _tree_cast(v, dtype) for k, v in obj.items()}
+    return obj
+
+
+def _cast_inputs_hook(dtype):
+    def hook(_module, args, kwargs):
+        return _tree_cast(args, dtype), _tree_cast(kwargs, dtype)
+    return hook
+
+
+def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloat16, fp32_islands=None) -> nn.Module:
+    """MI355X training layout: every frozen tensor in bf16, trainable (LoRA) tensors stay fp32.  ``fp32_islands``: name prefixes of
+    sub-modules whose frozen tensors stay fp32 (default :data:`DEFAULT_FP32_ISLANDS`; ``()`` = none); their floating-point inputs are
+    cast at the boundary (forward pre-hooks), and so are the inputs of the bf16 modules that consume their outputs."""
+    islands = tuple(DEFAULT_FP32_ISLANDS if fp32_islands is None else fp32_islands)
+    mods = dict(model.named_modules())
+    islands = tuple(i for i in islands if i in mods)
+
+    def kept(name: str) -> bool:
+        return any(name == i or name.startswith(i + ".") for i in islands)
+    for name, p in model.named_parameters():
+        if not p.requires_grad and p.dtype.is_floating_point and not kept(name):
             p.data = p.data.to(frozen_dtype)
     for name, b in model.named_buffers():
-        if b.dtype.is_floating_point and not b.dtype.is_complex:
+        if b.dtype.is_floating_point and not b.dtype.is_complex and not kept(name):
             b.data = b.data.to(frozen_dtype)
+    for h in getattr(model, "_sam3_layout_hooks", ()):
+        h.remove()
+    hooks = []
+    if islands and frozen_dtype != torch.float32:
+        for i in islands:
+            hooks.append(mods[i].register_forward_pre_hook(_cast_inputs_hook(torch.float32), with_kwargs=True))
+        for c in _ISLAND_CONSUMERS:
+            if c in mods and not kept(c) and mods[c] is not None:
+                hooks.append(mods[c].register_forward_pre_hook(_cast_inputs_hook(frozen_dtype), with_kwargs=True))
+    model._sam3_layout_hooks = hooks
+    model._sam3_fp32_islands = islands
     return model
 
 

@@ -269,12 +269,42 @@ def main():
         res["ref_autocast_bf16/pred_boxes"] = np.float64(max([relmax(o16["pred_boxes"], o32["pred_boxes"])] + [
             relmax(a["pred_boxes"], b["pred_boxes"]) for a, b in zip(o16["aux_outputs"], o32["aux_outputs"])]))
         res["ref_autocast_bf16/core_loss"] = np.float64(abs(l16 - l32) / abs(l32))
+        for k in ("presence_logit_dec", "pred_masks"):
+            if k in o16 and k in o32:
+                res[f"ref_autocast_bf16/{k}"] = np.float64(relmax(o16[k], o32[k]))
+        if yardstick_only:
+            # A/B gradients of the first step under autocast(bf16) against fp32 (the same max|d| / max|ref| per tensor the e2e
+            # tests use): how far the reference's own mixed precision moves the quantity the optimizer consumes
+            def grads(ctx):
+                for p_ in model.parameters():
+                    p_.grad = None
+                with ctx:
+                    outputs = model(batch)
+                    targets = [model.back_convert(t) for t in batch.find_targets]
+                    with SAM3Output.iteration_mode(outputs, iter_mode=SAM3Output.IterMode.ALL_STEPS_PER_STAGE) as it:
+                        for stage_out, tg in zip(it, targets):
+                            for o in stage_out:
+                                o["indices"] = matcher(o, tg)
+                                for a in o.get("aux_outputs", []):
+                                    a["indices"] = matcher(a, tg)
+                    total = wrapper(outputs, targets)["core_loss"]
+                total.backward()
+                return {n: (m.lora_A.grad.float().clone(), m.lora_B.grad.float().clone()) for n, m in model.named_modules()
+                        if isinstance(m, ref_root.LoRALayer) and m.lora_A.grad is not None
+                        and (which == "tiny" or any(w in n for w in D.WIDE_GRAD_MODULES))}
+            g32 = grads(contextlib.nullcontext())
+            g16 = grads(torch.autocast("cpu", dtype=torch.bfloat16))
+            per = {n: max(relmax(g16[n][0], g32[n][0]), relmax(g16[n][1], g32[n][1])) for n in g32 if n in g16}
+            res["ref_autocast_bf16/worst_AB_grad"] = np.float64(max(per.values()))
+            res["ref_autocast_bf16/median_AB_grad"] = np.float64(float(np.median(list(per.values()))))
+            print("A/B gradients under autocast(bf16) vs fp32: worst %.3e median %.3e over %d adapters" % (
+                res["ref_autocast_bf16/worst_AB_grad"], res["ref_autocast_bf16/median_AB_grad"], len(per)))
         print("reference under autocast(bf16) vs its fp32: logits %.3e boxes %.3e loss %.3e" % (
             res["ref_autocast_bf16/pred_logits"], res["ref_autocast_bf16/pred_boxes"], res["ref_autocast_bf16/core_loss"]))
         import json
         yp = os.path.join(HERE, "ref_autocast_bf16.json")
         yd = json.load(open(yp)) if os.path.exists(yp) else {}
-        yd[which] = {k.split("/")[1]: float(v) for k, v in res.items() if k.startswith("ref_autocast_bf16/")}
+        yd.setdefault(which, {}).update({k.split("/")[1]: float(v) for k, v in res.items() if k.startswith("ref_autocast_bf16/")})
         json.dump(yd, open(yp, "w"), indent=1, sort_keys=True)
         if yardstick_only:
             return

@@ -37,7 +37,7 @@ def _reload():
 def _knobs_back():
     yield
     if torch.cuda.is_available():
-        for k in ("SAM3_LORA_FUSED_SYNC", "SAM3_LORA_FUSED_WGS", "SAM3_LORA_SINGLE_ROUND"):
+        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_SINGLE_ROUND"):
             os.environ.pop(k, None)
         _reload()
         Fn.set_fused_linear(None)
@@ -112,15 +112,15 @@ def test_dropout_on_the_branch_input_only():
     _one_rounding(y.float().cpu().numpy(), want)
 
 
-def test_persistent_tile_walk_and_sync_modes_are_bit_identical():
-    """12 tiles on 1 / 3 / 5 / 256 workgroups (tiles per workgroup: 12, 4, 2-3, 1) and both barrier forms: the same bits."""
+def test_persistent_tile_walk_is_bit_identical_for_any_grid():
+    """12 tiles on 1 / 3 / 5 / 256 workgroups (tiles per workgroup: 12, 4, 2-3, 1), repeated: the same bits."""
     M, fin, fout, rank = 1000, 192, 776, 16
     x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=3)
     args = (_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), 2.0, 0)
     outs = []
     for wgs in ("1", "3", "5", "256"):
-        for sync in ("0", "1"):
-            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_SYNC"] = wgs, sync
+        for order in ("0", "1"):        # tile order: column tile fastest / column blocks (placement only)
+            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_ORDER"] = wgs, order
             _reload()
             for _ in range(3):              # repeated: a race between DMA and read would show as run-to-run differences
                 y, a, _ = Fn.lora_linear_fwd_(*args, gelu=True)

@@ -279,7 +279,7 @@ def _rel(a, ref):
 @pytest.mark.parametrize("ckpt", [True, False])
 def test_training_step_through_hip_adapters_matches_reference(gold, ckpt):
     """The loop of train_sam3_lora_native.py:887-943 on this library's model with the root injector's adapters on the
-    HIP path (fp32 activations; the kernels contract in bf16 with fp32 accumulation): forward outputs, matcher indices
+    HIP path (fp32 activations: the exact-fp32 kernels, v_mfma_f32_16x16x4_f32, fp32 intermediates): forward outputs, matcher indices
     (bit-exact), every entry of the loss dictionary, A/B gradients, A/B after AdamW, four-step loss curve."""
     from sam3_lora_amd.trainer import match_all_steps, move_to_device
     dev = torch.device("cuda")
@@ -436,28 +436,32 @@ def test_wide_training_step_fp32_matches_reference(gold_wide):
     assert max(m["loss_curve_rel"]) <= 1e-3, (m["losses"], m["loss_curve_rel"])
 
 
-# bf16 layout (frozen tensors and activations bf16, A/B fp32 -- what bench.py runs) against the reference's fp32 CPU run.
-# Measured on MI355X (profiles/r03_parity_bf16_*.json): pred_logits 1.6e-2 / 1.5e-2 (tiny / wide), pred_boxes 1.1e-3 / 1.2e-2,
-# core_loss 1.0e-3 / 7e-3.  tools/bf16_parity_probe.py attributes it (profiles/r03_bf16_parity_probe.json): the SAME numbers come
-# out with the adapter branch evaluated by torch in fp32 on the same bf16 activations (1.5e-2 / 1.6e-2 on the logits) and with
-# round 2's single-rounded kernels -- the residual is the bf16 storage of the trunk's activations and PyTorch-ROCm's bf16 GEMMs /
-# attention, not the adapter path (whose own error is bounded at the kernel level: one rounding of the bf16 output,
-# test_gpu_parity.py::test_hi_lo_*).  Yardstick: the reference's own mixed-precision mode -- its model under
-# torch.autocast(bf16) against its fp32 forward (tests/golden/ref_autocast_bf16.json, written by make_e2e_golden.py) -- moves its
-# own logits by 8.8e-3 / 1.8e-2, boxes by 8e-4 / 8e-3, loss by 1.4e-4 / 4.4e-2.  north_star's 1e-3 on the logits is met by the
-# fp32 layout (measured 8e-7, test_wide_training_step_fp32_matches_reference); in a bf16-activation layout no adapter
-# implementation can meet it.  Bounds below = measured x 2.
-BF16_BOUNDS = {"tiny": dict(logits=3e-2, boxes=3e-3, loss=3e-3, curve=3e-3), "wide": dict(logits=3e-2, boxes=2.5e-2, loss=1.5e-2, curve=1.5e-2)}
+# bf16 layout (frozen tensors and activations bf16, A/B fp32; the DETR decoder + scoring head stay fp32 -- vit.DEFAULT_FP32_ISLANDS;
+# what bench.py runs) against the reference's fp32 CPU run.  The bar is the reference's OWN mixed-precision mode: its model under
+# torch.autocast(bf16) against its fp32 run (tests/golden/ref_autocast_bf16.json, written by make_e2e_golden.py --yardstick:
+# tiny / wide logits 8.8e-3 / 1.8e-2, boxes 8.2e-4 / 8.3e-3, presence logit 1.7e-2 / 8.4e-3, masks 2.1e-2 / 2.5e-2, loss 1.4e-4 /
+# 4.4e-2, worst A/B gradient 0.175 / 0.54).  Every asserted quantity must be within 1.0x of that yardstick (masks 2x: the mask
+# head stays bf16 -- in fp32 it would cost more than the whole adapter path; gradients 1.25x on `tiny`, where this build sits at
+# 0.9x and the frozen GEMMs' stream-K reductions move it by a few per cent run to run).  Measured on MI355X
+# (profiles/r04e_bf16_islands.json): logits 6.5e-3 / 8.6e-3, boxes 2.4e-4 / 1.8e-3, presence 5.6e-3 / 2.3e-3, masks 3.1e-2 / 2.3e-2,
+# loss 7e-6 / 2.1e-3, gradients 0.156 / 0.085; with everything in bf16 (round 3): 1.6e-2 / 1.5e-2, 1.1e-3 / 1.2e-2, 5.5e-2 / 2.3e-2.
+# The A/B gradients are far more sensitive than the outputs in EVERY implementation (the reference's own autocast: 17 % / 54 %):
+# the loss is non-smooth (L1 sign, ReLU gates, GIoU branches, the assignment itself), so a 1e-3 move of a box flips gradient
+# components.  north_star's 1e-3 on the logits is met by the fp32 layout (measured 9e-7,
+# test_wide_training_step_fp32_matches_reference).
+def _yardstick(which):
+    import json
+    return json.load(open(os.path.join(os.path.dirname(GOLD), "ref_autocast_bf16.json")))[which]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["tiny", "wide"])
 def test_bf16_training_layout_against_reference(which, gold, gold_wide):
-    """Frozen tensors and activations in bf16 (the benchmark's layout), A/B fp32: pred_logits / pred_boxes of the final and
-    auxiliary outputs, every loss term and the loss curve against the reference's fp32 run, element-wise, with the measured
-    numbers recorded; matcher indices of the first step identical."""
+    """The benchmark's layout: pred_logits / pred_boxes of the final and auxiliary outputs, the presence logit, the masks, the
+    loss, the loss curve AND the A/B gradients against the reference's fp32 run, each bounded by the reference's own
+    autocast(bf16) deviation; matcher indices of the first step identical."""
     from sam3_lora_amd.trainer import move_to_device
-    from sam3_lora_amd.vit import to_training_layout
+    from sam3_lora_amd.vit import DEFAULT_FP32_ISLANDS, to_training_layout
     dev = torch.device("cuda")
     g = gold if which == "tiny" else gold_wide
     if which == "tiny":
@@ -468,23 +472,46 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
         layers, batch = _inject(model, g, D.LORA_WIDE), make_batch_wide()
     model.to(dev).train()
     to_training_layout(model)
+    assert tuple(model._sam3_fp32_islands) == tuple(DEFAULT_FP32_ISLANDS)
+    assert model.transformer.decoder.norm.weight.dtype == torch.float32
+    assert model.transformer.encoder.layers[0].norm1.weight.dtype == torch.bfloat16
     m = run_training_steps(model, layers, g, move_to_device(batch, dev), D.STEPS, D.CONFIGS[which][3], D.WD)
-    import json
-    yard = json.load(open(os.path.join(os.path.dirname(GOLD), "ref_autocast_bf16.json")))[which]
+    yard = _yardstick(which)
     m["reference_autocast_bf16_vs_its_fp32"] = yard
     _record(f"bf16_{which}", m)
     out = model(move_to_device(batch, dev)).output[0][0]
     assert out["pred_masks"].dtype == torch.bfloat16 and out["encoder_hidden_states"].dtype == torch.bfloat16
     # scores and boxes leave in fp32 (matcher cost, box losses)
     assert out["pred_logits"].dtype == out["pred_boxes"].dtype == out["presence_logit_dec"].dtype == torch.float32
-    b = BF16_BOUNDS[which]
     assert m["indices_equal"]
     logit_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_logits"))
     box_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes"))
-    assert logit_err <= b["logits"], m["outputs"]
-    assert box_err <= b["boxes"], m["outputs"]
-    assert m["loss_terms"]["core_loss"] <= b["loss"], m["loss_terms"]
-    assert max(m["loss_curve_rel"]) <= b["curve"], (m["losses"], m["loss_curve_rel"])
+    assert logit_err <= yard["pred_logits"], (logit_err, yard)
+    assert box_err <= yard["pred_boxes"], (box_err, yard)
+    assert m["outputs"]["presence_logit_dec"] <= yard["presence_logit_dec"], (m["outputs"], yard)
+    assert m["outputs"]["pred_masks"] <= 2.0 * yard["pred_masks"], (m["outputs"], yard)
+    assert m["loss_terms"]["core_loss"] <= max(yard["core_loss"], 1e-3), (m["loss_terms"]["core_loss"], yard)
+    assert max(m["loss_curve_rel"]) <= max(yard["core_loss"], 3e-3), (m["losses"], m["loss_curve_rel"])
+    assert len(m["grads"]) >= 6
+    assert max(m["grads"].values()) <= 1.25 * yard["worst_AB_grad"], (m["grads"], yard)
+
+
+@pytest.mark.gpu
+def test_all_bf16_layout_is_still_selectable_and_worse(gold):
+    """``to_training_layout(model, fp32_islands=())`` = round 3's layout (decoder and scoring head in bf16 too): it runs, and its
+    presence logit and boxes are several times further from the reference than with the default islands."""
+    from sam3_lora_amd.trainer import move_to_device
+    from sam3_lora_amd.vit import to_training_layout
+    dev = torch.device("cuda")
+    errs = {}
+    for islands in (None, ()):
+        model = build(gold, act_checkpoint=False, match_in_forward=False)
+        layers = _inject(model, gold)
+        model.to(dev).train()
+        to_training_layout(model, fp32_islands=islands)
+        m = run_training_steps(model, layers, gold, move_to_device(make_batch(), dev), 1, D.CONFIGS["tiny"][3], D.WD)
+        errs[islands] = (m["outputs"]["presence_logit_dec"], max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes")))
+    assert errs[()][0] > 2 * errs[None][0] and errs[()][1] > 2 * errs[None][1], errs
 
 
 @pytest.mark.gpu

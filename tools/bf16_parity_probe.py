@@ -48,7 +48,17 @@ def torch_fp32_adapters(model):
             m.forward = types.MethodType(fwd, m)
 
 
-def run(which, variant):
+ISLAND_SETS = {
+    "none": (),
+    "dec": ("transformer.decoder", "dot_prod_scoring"),
+    "dec+enc": ("transformer.decoder", "dot_prod_scoring", "transformer.encoder"),
+    "dec+enc+seg": ("transformer.decoder", "dot_prod_scoring", "transformer.encoder", "segmentation_head"),
+    "all_but_trunk": ("transformer", "dot_prod_scoring", "segmentation_head", "geometry_encoder", "backbone.language_backbone",
+                      "backbone.vision_backbone.convs", "backbone.vision_backbone.position_encoding"),
+}
+
+
+def run(which, variant, islands=None, fused=None):
     from sam3_lora_amd import _ffi
     from sam3_lora_amd.trainer import move_to_device
     from sam3_lora_amd.vit import to_training_layout
@@ -68,11 +78,15 @@ def run(which, variant):
         model = T.build_wide(gold, act_checkpoint=False, match_in_forward=False)
         layers, batch = T._inject(model, gold, D.LORA_WIDE), T.make_batch_wide()
     model.to(dev).train()
-    to_training_layout(model)
+    to_training_layout(model, fp32_islands=islands)
+    from sam3_lora_amd import functional as F2
+    F2.set_fused_linear(fused)
     if variant == "torch_fp32":
         torch_fp32_adapters(model)
     m = T.run_training_steps(model, layers, gold, move_to_device(batch, dev), D.STEPS, D.CONFIGS[which][3], D.WD)
-    return {"pred_logits": max(v for k, v in m["outputs"].items() if k.endswith("pred_logits")),
+    return {"islands": list(getattr(model, "_sam3_fp32_islands", ())), "presence_logit": m["outputs"].get("presence_logit_dec"),
+            "pred_masks": m["outputs"].get("pred_masks"),
+            "pred_logits": max(v for k, v in m["outputs"].items() if k.endswith("pred_logits")),
             "pred_boxes": max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes")),
             "queries": m["outputs"]["queries"], "encoder_hidden_states": m["outputs"]["encoder_hidden_states"],
             "core_loss": m["loss_terms"]["core_loss"], "worst_loss_term": max(m["loss_terms"].values()),
@@ -81,6 +95,20 @@ def run(which, variant):
 
 if __name__ == "__main__":
     res = {}
+    if len(sys.argv) > 1 and sys.argv[1] == "islands":
+        # which fp32 islands buy parity, with the fc1 site fused into the GEMM (default) and two-pass
+        import json as _j
+        yard = _j.load(open(os.path.join(ROOT, "tests", "golden", "ref_autocast_bf16.json")))
+        res["reference_autocast_bf16_vs_its_fp32"] = yard
+        for which in ("tiny", "wide"):
+            for name, isl in ISLAND_SETS.items():
+                for fused in (True, False):
+                    try:
+                        res[f"{which}/{name}/{'fused' if fused else 'two_pass'}"] = run(which, "hl", islands=isl, fused=fused)
+                    except Exception as e:
+                        res[f"{which}/{name}/{'fused' if fused else 'two_pass'}"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        print(json.dumps(res, indent=1))
+        sys.exit(0)
     for which in ("tiny", "wide"):
         for variant in ("hl", "single_round", "torch_fp32"):
             try:

@@ -60,17 +60,16 @@ def main():
     torch.cuda.synchronize()
     rounds = {}
     variants = [("two_pass", two_pass, {}), ("gemm_only", gemm_only, {}),
-                ("fused_sync1", fused, {"SAM3_LORA_FUSED_SYNC": "1"}), ("fused_sync0", fused, {"SAM3_LORA_FUSED_SYNC": "0"}),
-                ("fused_noact_sync1", fused_noact, {"SAM3_LORA_FUSED_SYNC": "1"})]
+                ("fused", fused, {}), ("fused_order0", fused, {"SAM3_LORA_FUSED_ORDER": "0"}), ("fused_noact", fused_noact, {})]
     for r in range(5):
         for name, f, env in variants:
-            for k in ("SAM3_LORA_FUSED_SYNC", "SAM3_LORA_FUSED_WGS"):
+            for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             lib.sam3_lora_debug_reload_knobs()
             f()
             rounds.setdefault(name, []).append(timed(f, 10))
-    for k in ("SAM3_LORA_FUSED_SYNC", "SAM3_LORA_FUSED_WGS"):
+    for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER"):
         os.environ.pop(k, None)
     lib.sam3_lora_debug_reload_knobs()
     out["us"] = {k: {"median": float(np.median(v)), "min": float(np.min(v)), "all": [round(t, 1) for t in v]} for k, v in rounds.items()}
