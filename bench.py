@@ -51,9 +51,9 @@ def parse():
                     help="activation dtype (f32 = the reference's un-autocast precision; contracted as bf16 on the MFMAs)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=0,
-                    help="cpu_baseline by SURVEY 8(d)'s c1 protocol in full: 1 warm-up + N timed B=2 CPU steps (minutes); "
-                         "default 0 = bounded sample")
+    ap.add_argument("--cpu-steps", type=int, default=2,
+                    help="cpu_baseline by SURVEY 8(d)'s c1 protocol: 1 warm-up + N timed B=2 CPU steps (default 2: ~5 minutes of "
+                         "host time on rank 0); 0 = one bounded step")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--trunk", action="store_true", help="also time the ViT trunk alone (with / without recompute)")
     ap.add_argument("--trunk-steps", type=int, default=3)
@@ -270,9 +270,15 @@ def insitu_kernels(w, steps=2):
         v.sort()
         avg = sum(v) / len(v)
         nb = alg_bytes(k, dim)
-        rows.append(dict(kernel=k, dim=dim, launches=len(v), algorithmic_bytes=nb, avg_us=round(avg, 2),
-                         median_us=round(v[len(v) // 2], 2), min_us=round(v[0], 2), total_us=round(sum(v), 1),
-                         GBps=round(nb / avg / 1e3, 1)))
+        row = dict(kernel=k, dim=dim, launches=len(v), algorithmic_bytes=nb, avg_us=round(avg, 2),
+                   median_us=round(v[len(v) // 2], 2), min_us=round(v[0], 2), total_us=round(sum(v), 1),
+                   GBps=round(nb / avg / 1e3, 1))
+        if k in ("k_gt_reduce", "k_reduce", "k_pack"):
+            # their inputs are partials / masters the previous kernel just wrote: served from L2 / Infinity Cache (PMC:
+            # profiles/*traffic.json, k_gt_reduce@4736 fetches 36 MB of the 104 MB it reads), so bytes / time is not an HBM rate
+            row["GBps"] = None
+            row["note"] = "reads cache-resident partials: not an HBM stream (see profiles/*_traffic.json for its PMC bytes)"
+        rows.append(row)
     rows.sort(key=lambda r_: -r_["total_us"])
     return rows
 
@@ -669,6 +675,8 @@ class FullStep:
         self.reducer.zero_grad()
         with self._direct(True):
             loss.backward()
+        if getattr(self, "backward_end_event", None) is not None:
+            self.backward_end_event.record(torch.cuda.current_stream(self.dev))
         mark("backward")
         self.reducer.finish()
         self.opt.step()
@@ -924,7 +932,7 @@ def main():
         rows = insitu_kernels(w)          # every rank (the instrumented steps contain the all-reduce)
     if rank == 0 and not args.no_roofline:
         ops = op_table(w, args.kernel_iters)
-        dom = rows[0]             # largest share of the step's kernel time
+        dom = next(r_ for r_ in rows if r_["GBps"] is not None)      # largest share of the step's kernel time
         dimname = {"k_t1": "K", "k_t2": "N", "k_t3": "N"}.get(dom["kernel"], "dim")
         default_wl = args.batch == 8 and args.rank == 16 and args.act_dtype == "bf16" and args.blocks == N_BLOCKS
         tr = committed_traffic(dom["kernel"], (dom["dim"] + 127) // 128 if dom["kernel"] == "k_t2" else -1) if default_wl else None
@@ -1021,6 +1029,20 @@ def overlap_measurement(full, world):
         return (time.perf_counter() - t0) / n * 1e3
 
     overlapped = run(3)
+    # where each bucket's all-reduce sits relative to the END of backward on the GPU's clock (HIP events on the side stream and on
+    # the compute stream): negative start = launched while backward was still running, i.e. hidden behind it
+    buckets = None
+    if red.overlap:
+        red.trace = True
+        full.backward_end_event = torch.cuda.Event(enable_timing=True)
+        full.step()
+        torch.cuda.synchronize()
+        red.trace = False
+        ev = full.backward_end_event
+        full.backward_end_event = None
+        buckets = [{"bucket": b, "origin": o, "bytes": 4 * (red.buckets[b][1] - red.buckets[b][0]),
+                    "start_ms_after_backward_end": round(ev.elapsed_time(e0), 3), "end_ms_after_backward_end": round(ev.elapsed_time(e1), 3)}
+                   for (b, e0, e1), (_, o) in zip(red.launch_events, red.launch_log)]
     saved = red.overlap
     red.overlap = False
     exposed = run(3)
@@ -1036,7 +1058,8 @@ def overlap_measurement(full, world):
     o, e, a = (float(v) for v in t.tolist())
     return {"world": world, "step_ms_overlapped": round(o, 2), "step_ms_exposed": round(e, 2),
             "allreduce_alone_ms": round(a, 3), "bytes": red.nbytes,
-            "hidden_ms": round(max(e - o, 0.0), 3)}
+            "hidden_ms": round(max(e - o, 0.0), 3), "buckets_rank0": buckets,
+            "collectives_per_step": len(red.buckets)}
 
 
 if __name__ == "__main__":

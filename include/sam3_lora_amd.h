@@ -178,7 +178,7 @@ int sam3_lora_bwd_act(const void* gy, const void* x, const void* tT_saved, const
  * fp8 frozen-W mode (include/sam3_fp8_amd.h): the same two calls, and the tensor the NEXT frozen GEMM consumes -- act_out
  * (forward: fc2's input) resp. gx_inout after the activation derivative (backward: the input of fc1's input-gradient GEMM) --
  * also leaves as an fp8 image q8_out[M, width] (row pitch ldq bytes), quantised from the bf16-ROUNDED values with the delayed
- * scale of sam3_fp8_quantize's protocol (amax_in / amax_out: SAM3_FP8_AMAX_SLOTS floats each; scale_out: 1 float; fmt:
+ * scale of sam3_fp8_quantize's protocol (amax_in / amax_out: SAM3_FP8_AMAX_FLOATS floats each -- SAM3_FP8_AMAX_SLOTS slots, one 128-byte line per slot, sam3_fp8_amd.h; scale_out: 1 float; fmt:
  * SAM3_FP8_E4M3 / SAM3_FP8_E5M2): bit-identical to running sam3_fp8_quantize over that tensor afterwards, without the extra
  * read + write pass.  bf16 activations, rank <= 16, act == SAM3_LORA_ACT_GELU, and (backward) drop_p == 0; SAM3_LORA_ENOTSUP
  * otherwise -- the caller then quantises separately.

@@ -47,7 +47,7 @@ int sam3_vit_win_residual(const void* x, const void* h, const float* scale, void
 int sam3_vit_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                            int64_t M, int C, float eps, int dtype, void* stream);
 /* fp8 frozen-W mode: the forward also writes y's fp8 image for the frozen GEMM that consumes it (the qkv / fc1 inputs), with
- * the delayed-scaling protocol of sam3_fp8_amd.h (amax_in / amax_out: SAM3_FP8_AMAX_SLOTS floats).  bf16 only (-95 else). */
+ * the delayed-scaling protocol of sam3_fp8_amd.h (amax_in / amax_out: SAM3_FP8_AMAX_FLOATS floats each: SAM3_FP8_AMAX_SLOTS slots, one 128-byte line per slot).  bf16 only (-95 else). */
 int sam3_vit_layernorm_fwd_q8(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                               int64_t M, int C, float eps, int dtype, void* q8_out, int64_t ldq, int fmt, const float* amax_in,
                               float* amax_out, float* scale_out, void* stream);

@@ -1958,7 +1958,9 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         }
         // GELU'-fused backward of the hi + lo kernels: gA from act(h) INSIDE the pass over gx (k_t2<GA>), no second read of x
         ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && !dk.thr && (x == nullptr || ga_in_t2_enabled());
-        if (gA_g && s3a && !ga_in_pass)
+        // (x == NULL with the in-pass form switched off by a partial debug stage mask: nothing can read the input -- skip, the
+        // header says a partial mask leaves the outputs meaningless)
+        if (gA_g && s3a && !ga_in_pass && x)
             launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
     }
     // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]

@@ -90,6 +90,8 @@ class LoRAGradReducer:
         self._launched = [False] * len(self.buckets)
         self._next = 0             # buckets [0, _next) have been launched: the only one a hook may launch is _next
         self.launch_log = []       # (bucket, "hook" | "finish") of the last armed step, in launch order
+        self.trace = False         # profiling aid: HIP events around every bucket's all-reduce on the side stream (bench.py)
+        self.launch_events = []    # per launch of the last armed step: (bucket, start event, end event) when `trace`
         self._works = []
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._armed = False
@@ -133,6 +135,7 @@ class LoRAGradReducer:
             self._launched[b] = False
         self._next = 0
         self.launch_log = []
+        self.launch_events = []
         self._works = []
         self._armed = True
 
@@ -185,7 +188,13 @@ class LoRAGradReducer:
         if self.overlap:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
+                if self.trace:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._side)
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.trace:
+                    e1.record(self._side)
+                    self.launch_events.append((b, e0, e1))
         else:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -255,9 +255,10 @@ def _fp8_companion(x: torch.Tensor):
 
 
 def _hl_q8_ok(lora) -> bool:
-    """The activation-fused adapter passes can carry an fp8 image: hi + lo kernels (rank <= 16, not single-rounded)."""
-    import os
-    return int(getattr(lora, "rank", 99)) <= 16 and os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") in ("", "0")
+    """The activation-fused adapter passes can carry an fp8 image: hi + lo kernels (rank <= 16, not single-rounded).  The LIBRARY
+    is asked (its knob table is latched at first launch; re-reading the environment here could disagree with it, and the q8 entry
+    points would then return ENOTSUP after the delayed-scaling state had already been flipped)."""
+    return bool(_ffi.load().sam3_lora_bwd_act_recomputes_input(int(getattr(lora, "rank", 99)), DT_BF16, 0.0))
 
 
 def _dx(gy2: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor]) -> torch.Tensor:
@@ -297,10 +298,10 @@ def frozen_linear(x: torch.Tensor, lin: torch.nn.Linear, cache: TransposedCopy) 
     if frozen and x.requires_grad and torch.is_grad_enabled():
         # the transposed copy serves the bf16 / fp32 TN-form backward; the fp8 route keeps its own e4m3 transpose, so skip it
         # only for the layers that actually take that route
-        return _FrozenLinearFn.apply(x, w, lin.bias, None if fp8.would_use(x, w) else cache.get(w))
+        return _FrozenLinearFn.apply(x, w, lin.bias, None if fp8.would_use(x, w) else cache.get(w), _fp8_companion(x))
     if frozen and fp8.fp8_enabled():        # no gradient needed (first block, eval): still the fp8 GEMM
         x2 = x.reshape(-1, x.shape[-1])
-        return _frozen_fwd(x2 if x2.is_contiguous() else x2.contiguous(), w, lin.bias).view(*x.shape[:-1], w.shape[0])
+        return _frozen_fwd(x2 if x2.is_contiguous() else x2.contiguous(), w, lin.bias, _fp8_companion(x)).view(*x.shape[:-1], w.shape[0])
     return lin(x)
 
 

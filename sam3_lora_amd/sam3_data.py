@@ -443,11 +443,33 @@ class ShardedLoader:
                     raise item
                 batch, ev = item
                 if ev is not None:
-                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    # The tensors were allocated on the copy stream's pool.  Tell the caching allocator that the CONSUMER's
+                    # stream uses them: without this, dropping the batch hands the blocks straight back to the copy stream,
+                    # and the producer's next H2D copy may overwrite memory that queued main-stream kernels (the loss
+                    # backward's saved target masks) still read.
+                    _record_stream(batch, cur)
                 yield batch
         finally:
             stop.set()
             pool.shutdown(wait=False, cancel_futures=True)
+
+
+def _record_stream(obj, stream) -> None:
+    """``Tensor.record_stream(stream)`` on every CUDA tensor of a (nested) batch structure."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda and obj.numel() > 0:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for x in obj:
+            _record_stream(x, stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif hasattr(obj, "__dataclass_fields__"):
+        for f in obj.__dataclass_fields__:
+            _record_stream(getattr(obj, f), stream)
 
 
 # --------------------------------------------------------------------------------------------------- COCO data --

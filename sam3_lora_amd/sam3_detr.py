@@ -507,7 +507,7 @@ class TransformerDecoder(nn.Module):
         elif self.boxRPB == "both":
             dx, dy = torch.cat([dx, log_scale(dx)], dim=-1), torch.cat([dy, log_scale(dy)], dim=-1)
         ckpt = self.training and self.use_act_checkpoint and torch.is_grad_enabled()
-        wd = self.norm.weight.dtype
+        wd = self.boxRPB_embed_x.layers[0].weight.dtype        # the bias is made in the dtype of the cross-attention that takes it
         bx = _maybe_checkpoint(ckpt, self.boxRPB_embed_x, dx.to(wd))           # [B, Q, W, heads]
         by = _maybe_checkpoint(ckpt, self.boxRPB_embed_y, dy.to(wd))           # [B, Q, H, heads]
         # head-major COPIES of the two small terms: as permuted views the broadcast add below would inherit their
@@ -540,7 +540,7 @@ class TransformerDecoder(nn.Module):
                 return False
             if l1.weight.dtype not in (torch.bfloat16, torch.float32):
                 return False
-        return self.boxRPB_embed_x.layers[0].weight.dtype == self.boxRPB_embed_y.layers[0].weight.dtype == self.norm.weight.dtype
+        return self.boxRPB_embed_x.layers[0].weight.dtype == self.boxRPB_embed_y.layers[0].weight.dtype
 
     def _rpb_kernel(self, reference_boxes: torch.Tensor, H: int, W: int, presence_row: bool) -> torch.Tensor:
         import ctypes

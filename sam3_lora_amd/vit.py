@@ -609,7 +609,14 @@ def sam3_vit(**overrides) -> ViT:
 # mixed-precision mode, keeps exactly this kind of state (residuals, LayerNorm, small heads) in fp32.  Measured on MI355X against the
 # reference's fp32 run: profiles/r04e_bf16_islands.json.
 DEFAULT_FP32_ISLANDS = ("transformer.decoder", "dot_prod_scoring")
+# ... except the memory-side work inside the decoder ("holes", fnmatch patterns): each layer's IMAGE cross-attention (K / V projections
+# of all 5184 x batch memory tokens, the SDPA against them) and the two MLPs of the box-relative position bias that feeds it (a
+# [batch x heads, queries, 5184] tensor per layer: 266 MB in bf16).  In fp32 these cost 4 % of the whole step (250.7 against 241 ms,
+# profiles/r04f_bench_full_islands.json); the query stream they update -- 200-400 rows -- keeps its fp32 residuals, norms, self-
+# attention, FFN and heads, so the rounding of a layer's attention output enters as a bf16-relative error of that UPDATE only.
+DEFAULT_FP32_HOLES = ("transformer.decoder.layers.*.cross_attn", "transformer.decoder.boxRPB_embed_x", "transformer.decoder.boxRPB_embed_y")
 _ISLAND_CONSUMERS = ("segmentation_head",)      # bf16 modules that take an island's fp32 outputs (the decoder's queries)
+_ISLAND_ENTRY_SKIP = {"transformer.decoder": ("memory", "pos")}     # arguments only the holes consume: not cast at the island's entry
 
 
 def _tree_cast(obj, dtype):
@@ -624,21 +631,28 @@ def _tree_cast(obj, dtype):
     return obj
 
 
-def _cast_inputs_hook(dtype):
+def _cast_inputs_hook(dtype, skip=()):
     def hook(_module, args, kwargs):
-        return _tree_cast(args, dtype), _tree_cast(kwargs, dtype)
+        return _tree_cast(args, dtype), {k: (v if k in skip else _tree_cast(v, dtype)) for k, v in kwargs.items()}
     return hook
 
 
-def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloat16, fp32_islands=None) -> nn.Module:
+def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloat16, fp32_islands=None, fp32_holes=None) -> nn.Module:
     """MI355X training layout: every frozen tensor in bf16, trainable (LoRA) tensors stay fp32.  ``fp32_islands``: name prefixes of
-    sub-modules whose frozen tensors stay fp32 (default :data:`DEFAULT_FP32_ISLANDS`; ``()`` = none); their floating-point inputs are
-    cast at the boundary (forward pre-hooks), and so are the inputs of the bf16 modules that consume their outputs."""
+    sub-modules whose frozen tensors stay fp32 (default :data:`DEFAULT_FP32_ISLANDS`; ``()`` = none), ``fp32_holes``: fnmatch patterns
+    of sub-modules INSIDE an island that follow ``frozen_dtype`` after all (default :data:`DEFAULT_FP32_HOLES`).  Floating-point inputs
+    are cast at every such boundary (forward pre-hooks), and so are the inputs of the bf16 modules that consume an island's outputs."""
+    import fnmatch
     islands = tuple(DEFAULT_FP32_ISLANDS if fp32_islands is None else fp32_islands)
     mods = dict(model.named_modules())
     islands = tuple(i for i in islands if i in mods)
+    hole_pats = tuple(DEFAULT_FP32_HOLES if fp32_holes is None else fp32_holes)
+    holes = tuple(n for n in mods if any(fnmatch.fnmatchcase(n, p) for p in hole_pats)
+                  and any(n.startswith(i + ".") for i in islands))
 
     def kept(name: str) -> bool:
+        if any(name == h or name.startswith(h + ".") for h in holes):
+            return False
         return any(name == i or name.startswith(i + ".") for i in islands)
     for name, p in model.named_parameters():
         if not p.requires_grad and p.dtype.is_floating_point and not kept(name):
@@ -651,12 +665,16 @@ def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloa
     hooks = []
     if islands and frozen_dtype != torch.float32:
         for i in islands:
-            hooks.append(mods[i].register_forward_pre_hook(_cast_inputs_hook(torch.float32), with_kwargs=True))
+            skip = _ISLAND_ENTRY_SKIP.get(i, ()) if any(h.startswith(i + ".") for h in holes) else ()
+            hooks.append(mods[i].register_forward_pre_hook(_cast_inputs_hook(torch.float32, skip), with_kwargs=True))
+        for h in holes:
+            hooks.append(mods[h].register_forward_pre_hook(_cast_inputs_hook(frozen_dtype), with_kwargs=True))
         for c in _ISLAND_CONSUMERS:
             if c in mods and not kept(c) and mods[c] is not None:
                 hooks.append(mods[c].register_forward_pre_hook(_cast_inputs_hook(frozen_dtype), with_kwargs=True))
     model._sam3_layout_hooks = hooks
     model._sam3_fp32_islands = islands
+    model._sam3_fp32_holes = holes
     return model
 
 

@@ -69,7 +69,34 @@ WIDE_RES = 224
 LORA_WIDE = dict(LORA, rank=16, alpha=32)
 LR_WIDE = 1e-4          # a step size at which four AdamW steps of this model descend smoothly (1e-3 overshoots: the curve
                         # then amplifies 1e-6 differences to 3e-3 by the fourth step even in fp32)
-CONFIGS = {"tiny": (TINY, RES, LORA, LR), "wide": (WIDE, WIDE_RES, LORA_WIDE, LR_WIDE)}
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The REAL model size: exactly the dimensions of sam3/model_builder.py:69-187,486-495 -- 1008^2 input, 72 x 72
+# token grid, 1024-wide trunk of depth 32 with 24 x 24 windows and global blocks (7, 15, 23, 31), tiled absolute position table
+# (pretrain 336), interpolated RoPE, 256-wide DETR with 6 + 6 layers and 200 queries, 24-layer 1024-wide text tower with the
+# 49,408-entry vocabulary and 32 positions (the toy tokenizer's ids are a subset of it) -- dropout / DropPath 0, ONE image (the
+# first sample: 2 boxes), weights and adapters by name-seeded draws (nothing stored but buffers), the root injector with
+# configs/full_lora_config.yaml's target list at BASELINE configs[1]'s rank 16 / alpha 32 (-> the 64 ViT-MLP adapters), one step.
+FULL = dict(
+    vit=dict(img_size=1008, pretrain_img_size=336, patch_size=14, embed_dim=1024, depth=32, num_heads=16, mlp_ratio=4.625,
+             drop_path_rate=0.0, window_size=24, global_att_blocks=(7, 15, 23, 31)),
+    d_model=256, heads=8, ffn=2048, dropout=0.0, enc_layers=6, dec_layers=6, num_queries=200, geo_layers=3,
+    text=dict(width=1024, heads=16, layers=24, context_length=32, vocab_size=49408), scoring_hidden=2048, roi_size=7)
+FULL_RES = 1008
+FULL_SAMPLES = SAMPLES[:1]
+LORA_FULL = dict(rank=16, alpha=32, dropout=0.0, target_modules=["q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2"],
+                 apply_to_vision_encoder=True, apply_to_text_encoder=True, apply_to_geometry_encoder=True,
+                 apply_to_detr_encoder=True, apply_to_detr_decoder=True, apply_to_mask_decoder=True)
+# adapters whose gradients are stored in full; every other adapter stores a strided sample (FULL_GRAD_SAMPLE elements of gA, gB)
+FULL_GRAD_MODULES = ("trunk.blocks.0.mlp.fc1", "trunk.blocks.7.mlp.fc2", "trunk.blocks.16.mlp.fc1", "trunk.blocks.31.mlp.fc2")
+FULL_GRAD_SAMPLE = 257
+
+
+def toy_tokenizer_32(texts, context_length=32):
+    return toy_tokenizer(texts, context_length=context_length)
+
+
+CONFIGS = {"tiny": (TINY, RES, LORA, LR), "wide": (WIDE, WIDE_RES, LORA_WIDE, LR_WIDE), "full": (FULL, FULL_RES, LORA_FULL, LR_WIDE)}
 
 
 def seeded_parameter(name: str, shape) -> torch.Tensor:

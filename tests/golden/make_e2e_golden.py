@@ -60,7 +60,7 @@ def build_reference_tiny(c=None):
     pe = lambda: PositionEmbeddingSine(num_pos_feats=d, normalize=True, scale=None, temperature=10000)
     neck = Sam3DualViTDetNeck(position_encoding=pe(), d_model=d, scale_factors=[4.0, 2.0, 1.0, 0.5], trunk=vit,
                               add_sam2_neck=False)
-    text = VETextEncoder(tokenizer=D.toy_tokenizer, d_model=d, **c["text"])
+    text = VETextEncoder(tokenizer=D.toy_tokenizer_32 if c["text"]["context_length"] == 32 else D.toy_tokenizer, d_model=d, **c["text"])
     backbone = SAM3VLBackbone(visual=neck, text=text, scalp=1)
     enc_layer = TransformerEncoderLayer(activation="relu", d_model=d, dim_feedforward=ffn, dropout=p,
                                         pos_enc_at_attn=True, pos_enc_at_cross_attn_keys=False,
@@ -103,13 +103,13 @@ def build_reference_tiny(c=None):
                      use_instance_query=False, multimask_output=True, inst_interactive_predictor=None, matcher=matcher)
 
 
-def reference_batch(res=None):
+def reference_batch(res=None, samples=None):
     from sam3.train.data.collator import collate_fn_api
     from sam3.train.data.sam3_image_dataset import Datapoint, FindQueryLoaded, Image, InferenceMetadata, Object
     res = res or D.RES
     imgs = D.make_images_res(res)
     dps = []
-    for i, ((text, boxes), img) in enumerate(zip(D.SAMPLES, imgs)):
+    for i, ((text, boxes), img) in enumerate(zip(samples or D.SAMPLES, imgs)):
         objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask_res(b, res))
                 for j, b in enumerate(boxes)]
         q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
@@ -197,7 +197,8 @@ def main():
     res["sd_keys"] = np.array(list(model.state_dict().keys()))
     res["param_names"] = np.array(sorted(param_names))
 
-    batch = reference_batch(RESOLUTION)
+    full = which == "full"
+    batch = reference_batch(RESOLUTION, D.FULL_SAMPLES if full else None)
     fi, ft = batch.find_inputs[0], batch.find_targets[0]
     res["batch/img_batch"] = np_(batch.img_batch)
     res["batch/texts"] = np.array(batch.find_text_batch)
@@ -208,16 +209,18 @@ def main():
               "is_valid_segment", "is_exhaustive", "object_ids", "object_ids_padded"):
         res[f"batch/find_target/{k}"] = np_(getattr(ft, k))
 
-    # eval-mode forward (no DAC, no aux bookkeeping)
-    model.eval()
-    with torch.no_grad():
-        out = model(batch)[0]
-    dump_outputs(res, "eval", out)
+    if not full:        # (the full-size fixture is one adapted training step: ~10 minutes of CPU as it is)
+        # eval-mode forward (no DAC, no aux bookkeeping)
+        model.eval()
+        with torch.no_grad():
+            out = model(batch)[0]
+        dump_outputs(res, "eval", out)
 
-    # training-mode forward of the un-adapted model (matching inside forward)
+        # training-mode forward of the un-adapted model (matching inside forward)
+        model.train()
+        out = model(batch)[0]
+        dump_outputs(res, "train", out)
     model.train()
-    out = model(batch)[0]
-    dump_outputs(res, "train", out)
 
     # LoRA + the native CLI's loss stack and loop
     with contextlib.redirect_stdout(io.StringIO()):
@@ -252,7 +255,7 @@ def main():
                         a["indices"] = matcher(a, tg)
         return outputs[0][0] if isinstance(outputs[0], list) else outputs[0], float(wrapper(outputs, targets)["core_loss"])
     yardstick_only = "--yardstick" in sys.argv      # tiny: measured in its own invocation (e2e_tiny.npz predates it and must
-    if which == "tiny" and not yardstick_only:      # not move: extra forwards shift CPU reduction order by an ulp)
+    if (which == "tiny" or full) and not yardstick_only:      # not move: extra forwards shift CPU reduction order by an ulp)
         raise_skip = True
     else:
         raise_skip = False
@@ -312,7 +315,9 @@ def main():
         print("autocast yardstick unavailable:", type(e).__name__, str(e)[:200])
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=LEARNING_RATE, weight_decay=D.WD)
     losses = []
-    for step in range(D.STEPS):
+    import time as _time
+    for step in range(1 if full else D.STEPS):
+        _t0 = _time.time()
         outputs = model(batch)
         targets = [model.back_convert(t) for t in batch.find_targets]
         with SAM3Output.iteration_mode(outputs, iter_mode=SAM3Output.IterMode.ALL_STEPS_PER_STAGE) as it:
@@ -330,8 +335,16 @@ def main():
             for k, v in loss_dict.items():
                 res[f"loss/{k}"] = np.float64(float(v))
             for n, m in model.named_modules():
-                if isinstance(m, ref_root.LoRALayer) and (which == "tiny" or any(w in n for w in D.WIDE_GRAD_MODULES)):
+                if isinstance(m, ref_root.LoRALayer) and full:
+                    if any(w in n for w in D.FULL_GRAD_MODULES):
+                        res[f"gA/{n}"], res[f"gB/{n}"] = np_(m.lora_A.grad), np_(m.lora_B.grad)
+                    else:       # a strided sample of every other adapter's gradients + their maxima (the test's error scale)
+                        ga, gb = m.lora_A.grad.flatten(), m.lora_B.grad.flatten()
+                        res[f"gAs/{n}"], res[f"gBs/{n}"] = np_(ga[::D.FULL_GRAD_SAMPLE]), np_(gb[::D.FULL_GRAD_SAMPLE])
+                        res[f"gAmax/{n}"], res[f"gBmax/{n}"] = np.float64(ga.abs().max()), np.float64(gb.abs().max())
+                elif isinstance(m, ref_root.LoRALayer) and (which == "tiny" or any(w in n for w in D.WIDE_GRAD_MODULES)):
                     res[f"gA/{n}"], res[f"gB/{n}"] = np_(m.lora_A.grad), np_(m.lora_B.grad)
+            print("step %d: %.1f s, core_loss %.6f" % (step, _time.time() - _t0, float(total)), flush=True)
         opt.step()
         if step == 0:
             for n, m in model.named_modules():
@@ -342,6 +355,13 @@ def main():
     if which != "tiny":         # the big per-query mask tensors are pinned by the tiny fixture; keep this one small
         for k in [k for k in res if k.endswith(("pred_masks", "pred_masks_o2m", "encoder_hidden_states"))]:
             res[k] = res[k][:, :4] if res[k].ndim == 4 else res[k][::8]
+    if full:                    # 1008^2 image and masks: the test rebuilds the image from its seed; masks at 4 queries, every 4th pixel
+        del res["batch/img_batch"]
+        for k in [k for k in res if k.endswith(("pred_masks", "pred_masks_o2m", "semantic_seg"))]:
+            res[k] = res[k][..., ::4, ::4]
+        for k in ("batch/find_target/segments", "batch/find_target/semantic_segments"):
+            if k in res:
+                res[k] = np.packbits(res[k].astype(bool), axis=-1)
     out_path = os.path.join(HERE, f"e2e_{which}.npz")
     np.savez_compressed(out_path, **res)
     print("adapted:", len(names), "modules; losses:", " ".join(f"{l:.6f}" for l in losses))

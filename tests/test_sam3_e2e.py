@@ -436,6 +436,101 @@ def test_wide_training_step_fp32_matches_reference(gold_wide):
     assert max(m["loss_curve_rel"]) <= 1e-3, (m["losses"], m["loss_curve_rel"])
 
 
+GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_full.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_full_size_training_step_fp32_matches_reference():
+    """The REAL model size (e2e_case_defs.FULL = sam3/model_builder.py:69-187,486-495: 1008^2 input, 72 x 72 tokens, depth-32
+    1024-wide trunk with 24 x 24 windows and 4 global blocks, tiled position table, interpolated RoPE, 6 + 6 DETR layers, 200
+    queries, 24-layer text tower) -- one image, one training step of the reference's own classes on the CPU in fp32
+    (tests/golden/make_e2e_golden.py full; weights and adapters by name-seeded draws, only buffers stored), against this library
+    on the GPU with the 64 ViT-MLP adapters (full_lora_config.yaml's targets at rank 16 / alpha 32) on the exact-fp32 HIP path:
+    north_star's 1e-3 on every output's logits / boxes / masks, every loss term, matcher indices of the final and the five
+    auxiliary outputs bit-exact, the A/B gradients of all 64 adapters (four stored in full, the others as strided samples)."""
+    from sam3_lora_amd.trainer import match_all_steps, move_to_device
+    gold = np.load(GOLD_FULL)
+    dev = torch.device("cuda")
+    model = build_sam3_image_model(device="cpu", eval_mode=False, config=D.FULL, tokenizer=D.toy_tokenizer_32,
+                                   act_checkpoint=False, match_in_forward=False)
+    assert sorted(model.state_dict().keys()) == sorted(str(k) for k in gold["sd_keys"])
+    assert sorted(n for n, _ in model.named_parameters()) == [str(n) for n in gold["param_names"]]
+    sd = {n: D.seeded_parameter(n, p.shape) for n, p in model.named_parameters()}
+    sd.update(state_dict_of(gold))
+    model.load_state_dict(sd, strict=True)
+    del sd
+    layers = _inject(model, gold, D.LORA_FULL)
+    assert len(layers) == 64
+    model.to(dev).train()
+    # the batch: the first sample at 1008^2 (the generator's first draw), 2 boxes + rectangular masks
+    res = D.FULL_RES
+    (text, boxes), img = D.FULL_SAMPLES[0], D.make_images_res(res)[0]
+    objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask_res(b, res))
+            for j, b in enumerate(boxes)]
+    q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
+                        query_processing_order=0,
+                        inference_metadata=InferenceMetadata(coco_image_id=0, original_image_id=0, original_category_id=0,
+                                                             original_size=(res, res), object_id=-1, frame_index=-1))
+    batch = collate_fn_api([Datapoint(find_queries=[q], images=[Image(data=img, objects=objs, size=(res, res))])],
+                           dict_key="input", with_seg_masks=True)["input"]
+    for k in gold.files:            # the collated targets are the reference collator's
+        if k.startswith("batch/find_target/") and "segments" not in k:
+            got = getattr(batch.find_targets[0], k.split("/")[2])
+            assert np.array_equal(got.numpy(), gold[k]), k
+    batch = move_to_device(batch, dev)
+    matcher, wrapper = _criterion()
+    model.set_prefetch_matcher(wrapper)
+    outputs = model(batch)
+    targets = [model.back_convert(t) for t in batch.find_targets]
+    match_all_steps(wrapper, outputs.output, targets)
+    loss_dict = wrapper(outputs, targets)
+    loss_dict["core_loss"].backward()
+    out = outputs.output[0][0]
+    rec = {"outputs": {}, "loss_terms": {}, "grads_full": {}, "grads_sampled_worst": 0.0}
+
+    def err(a, ref):
+        a = a.detach().float().cpu().numpy()
+        if a.ndim == 4:         # masks: the first queries, every 4th pixel
+            a = a[:, :ref.shape[1], ::4, ::4]
+        elif a.shape != ref.shape:
+            a = a[::8]          # encoder states: every 8th token
+        assert a.shape == ref.shape, (a.shape, ref.shape)
+        return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12))
+    n_idx = 0
+    for k in gold.files:
+        if not k.startswith("lora/"):
+            continue
+        parts = k.split("/")[1:]
+        node = out
+        if parts[0].startswith("aux"):
+            node, parts = out["aux_outputs"][int(parts[0][3:])], parts[1:]
+        if parts[0] == "indices":
+            got = torch.stack([node["indices"][0], node["indices"][1]]).cpu().numpy()
+            assert np.array_equal(got, gold[k]), (k, got, gold[k])
+            n_idx += 1
+            continue
+        rec["outputs"]["/".join(k.split("/")[1:])] = err(node[parts[0]], gold[k])
+    assert n_idx == 6
+    for k in gold.files:
+        if k.startswith("loss/") and "ce_f1" not in k and "acc" not in k:
+            ref = float(gold[k])
+            rec["loss_terms"][k[5:]] = abs(float(loss_dict[k[5:]]) - ref) / max(abs(ref), 1e-3)
+    for n_, mod in layers.items():
+        if f"gA/{n_}" in gold.files:
+            rec["grads_full"][n_] = max(_rel(mod.lora_A.grad, gold[f"gA/{n_}"]), _rel(mod.lora_B.grad, gold[f"gB/{n_}"]))
+        else:
+            for g_, key in ((mod.lora_A.grad, "gA"), (mod.lora_B.grad, "gB")):
+                got = g_.detach().float().flatten()[::D.FULL_GRAD_SAMPLE].cpu().numpy()
+                e = float(np.abs(got - gold[f"{key}s/{n_}"]).max() / max(float(gold[f"{key}max/{n_}"]), 1e-30))
+                rec["grads_sampled_worst"] = max(rec["grads_sampled_worst"], e)
+    _record("full_fp32", rec)
+    assert len(rec["grads_full"]) == 4 and len(rec["outputs"]) >= 40
+    assert max(rec["outputs"].values()) <= 1e-3, rec["outputs"]
+    assert max(rec["loss_terms"].values()) <= 1e-3, rec["loss_terms"]
+    assert max(rec["grads_full"].values()) <= 5e-3 and rec["grads_sampled_worst"] <= 5e-3, (rec["grads_full"], rec["grads_sampled_worst"])
+
+
 # bf16 layout (frozen tensors and activations bf16, A/B fp32; the DETR decoder + scoring head stay fp32 -- vit.DEFAULT_FP32_ISLANDS;
 # what bench.py runs) against the reference's fp32 CPU run.  The bar is the reference's OWN mixed-precision mode: its model under
 # torch.autocast(bf16) against its fp32 run (tests/golden/ref_autocast_bf16.json, written by make_e2e_golden.py --yardstick:
@@ -474,6 +569,9 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
     to_training_layout(model)
     assert tuple(model._sam3_fp32_islands) == tuple(DEFAULT_FP32_ISLANDS)
     assert model.transformer.decoder.norm.weight.dtype == torch.float32
+    # the memory-side work inside the decoder (image cross-attention of every layer + the two position-bias MLPs) stays bf16
+    assert len(model._sam3_fp32_holes) == len(model.transformer.decoder.layers) + 2
+    assert model.transformer.decoder.boxRPB_embed_x.layers[0].weight.dtype == torch.bfloat16
     assert model.transformer.encoder.layers[0].norm1.weight.dtype == torch.bfloat16
     m = run_training_steps(model, layers, g, move_to_device(batch, dev), D.STEPS, D.CONFIGS[which][3], D.WD)
     yard = _yardstick(which)

@@ -64,7 +64,8 @@ class ToySam3(nn.Module):
 
     def forward(self, batch: ToyBatch):
         x = batch.img_batch
-        feat = self.backbone.vision_backbone.trunk(x.to(self.transformer.decoder.query.dtype))[-1]
+        trunk = self.backbone.vision_backbone.trunk
+        feat = trunk(x.to(trunk.patch_embed.proj.weight.dtype))[-1]         # the trunk's dtype (the decoder may be an fp32 island)
         return [self.transformer.decoder(feat)]            # one find stage
 
     @staticmethod

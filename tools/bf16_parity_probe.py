@@ -58,7 +58,7 @@ ISLAND_SETS = {
 }
 
 
-def run(which, variant, islands=None, fused=None):
+def run(which, variant, islands=None, fused=None, holes=None):
     from sam3_lora_amd import _ffi
     from sam3_lora_amd.trainer import move_to_device
     from sam3_lora_amd.vit import to_training_layout
@@ -78,13 +78,13 @@ def run(which, variant, islands=None, fused=None):
         model = T.build_wide(gold, act_checkpoint=False, match_in_forward=False)
         layers, batch = T._inject(model, gold, D.LORA_WIDE), T.make_batch_wide()
     model.to(dev).train()
-    to_training_layout(model, fp32_islands=islands)
+    to_training_layout(model, fp32_islands=islands, fp32_holes=holes)
     from sam3_lora_amd import functional as F2
     F2.set_fused_linear(fused)
     if variant == "torch_fp32":
         torch_fp32_adapters(model)
     m = T.run_training_steps(model, layers, gold, move_to_device(batch, dev), D.STEPS, D.CONFIGS[which][3], D.WD)
-    return {"islands": list(getattr(model, "_sam3_fp32_islands", ())), "presence_logit": m["outputs"].get("presence_logit_dec"),
+    return {"islands": list(getattr(model, "_sam3_fp32_islands", ())), "holes": len(getattr(model, "_sam3_fp32_holes", ())), "presence_logit": m["outputs"].get("presence_logit_dec"),
             "pred_masks": m["outputs"].get("pred_masks"),
             "pred_logits": max(v for k, v in m["outputs"].items() if k.endswith("pred_logits")),
             "pred_boxes": max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes")),
@@ -101,12 +101,14 @@ if __name__ == "__main__":
         yard = _j.load(open(os.path.join(ROOT, "tests", "golden", "ref_autocast_bf16.json")))
         res["reference_autocast_bf16_vs_its_fp32"] = yard
         for which in ("tiny", "wide"):
-            for name, isl in ISLAND_SETS.items():
-                for fused in (True, False):
+            sets = [("none", (), None), ("dec_with_bf16_holes(default)", ISLAND_SETS["dec"], None), ("dec_all_fp32", ISLAND_SETS["dec"], ()),
+                    ("dec+enc+seg", ISLAND_SETS["dec+enc+seg"], None)]
+            for name, isl, holes in sets:
+                for rep in range(2):        # twice: the frozen GEMMs' stream-K reductions make runs differ by a few per cent
                     try:
-                        res[f"{which}/{name}/{'fused' if fused else 'two_pass'}"] = run(which, "hl", islands=isl, fused=fused)
+                        res[f"{which}/{name}/run{rep}"] = run(which, "hl", islands=isl, fused=True, holes=holes)
                     except Exception as e:
-                        res[f"{which}/{name}/{'fused' if fused else 'two_pass'}"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                        res[f"{which}/{name}/run{rep}"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         print(json.dumps(res, indent=1))
         sys.exit(0)
     for which in ("tiny", "wide"):
