@@ -68,6 +68,7 @@ def parse():
                     help="headline step with fp8 frozen-W base GEMMs (BASELINE configs[4] mode; default: measured as a sub-object)")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 frozen-W sub-measurement")
     ap.add_argument("--no-fused-ab", action="store_true", help="skip the fused-fc1 on/off sub-measurement")
+    ap.add_argument("--no-literal", action="store_true", help="skip the literal full_lora_config.yaml (r=32, dropout 0.1) sub-measurement")
     ap.add_argument("--model", choices=["sam3", "tiny"], default="sam3",
                     help="tiny: the parity fixture's widths at 112^2 (contract tests only; the line says so)")
     return ap.parse_args()
@@ -893,6 +894,26 @@ def main():
             enable_fp8_frozen(False)
         del full
         torch.cuda.empty_cache()
+        if (not args.no_literal and args.rank == 16 and args.dropout == 0.0 and not args.fp8_frozen and args.act_dtype == "bf16"
+                and args.model == "sam3"):
+            # the reference's SHIPPED default (configs/full_lora_config.yaml:12-14: rank 32, alpha 64, dropout 0.1) on the same workload
+            lit = FullStep(dev, args.batch, 32, world, rank, dropout=0.1, act_checkpoint=args.act_checkpoint,
+                           match_once=not args.match_twice, bf16=True, kind=args.model)
+            for _ in range(2):
+                lit.step()
+            l_steps = max(3, min(args.steps, 6))
+            dtl = timed(lit.step, l_steps)
+            if rank == 0:
+                v = world * args.batch * l_steps / dtl
+                out["literal_full_lora_config"] = {
+                    "value": round(v, 2), "unit": "images/s", "ms_per_step": round(dtl / l_steps * 1e3, 3), "steps": l_steps,
+                    "rank": 32, "alpha": 64, "dropout": 0.1, "vs_r16_line": round(v / out["value"], 4),
+                    "finite": bool(torch.isfinite(lit.last_loss).item()), "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                    "what": "the same whole training step at configs/full_lora_config.yaml's literal adapter settings (r = 32, alpha = 64, "
+                            "LoRA dropout 0.1 generated inside the kernels): single-rounded bf16 operand images (hi + lo is r <= 16), "
+                            "two-pass backward, fc1 + GELU through sam3_lora_linear_fwd"}
+            del lit
+            torch.cuda.empty_cache()
         if args.full_only:
             if rank == 0:
                 print(json.dumps(out))

@@ -83,3 +83,29 @@ def test_train_save_infer_validate_merge_chain(tmp_path, monkeypatch):
     metrics = I.validate(str(path), str(tmp_path / "out" / "best_lora_weights.pt"), "unused", prob_threshold=0.0,
                          dataset=SyntheticSegmentDataset(3, split="valid", resolution=112, source=128))
     assert metrics["images"] == 3 and metrics["num_ground_truth"] == 6 and 0.0 <= metrics["mAP"] <= 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The validation script's post-processing against the REFERENCE's own functions (tests/golden/consumer_cases.npz, written by
+# make_consumer_golden.py: validate_sam3_lora.py:232-352 executed unmodified + sam3/perflib/nms.py): the surviving set and its
+# order, scores, boxes and masks are bit-exact (integer / index work + the same sigmoid).
+def test_nms_and_overlap_merge_match_the_reference_functions():
+    import os
+    import numpy as np
+    import torch
+    import consumer_case_defs as C
+    from sam3_lora_amd import inference as I
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consumer_cases.npz"))
+    for name, n, side, clusters, seed, pt, it, k, mt in C.CASES:
+        logits, masks, boxes = C.make_case(n, side, clusters, seed)
+        fm, fs, fb = I.apply_sam3_nms(logits, masks, boxes, prob_threshold=pt, nms_iou_threshold=it, max_detections=k)
+        assert np.array_equal(fs.numpy(), gold[f"{name}/nms_scores"]), name
+        assert np.array_equal(fb.numpy(), gold[f"{name}/nms_boxes"]), name
+        assert np.array_equal(fm.numpy(), gold[f"{name}/nms_masks"]), name
+        if len(fm) > 0:
+            mm, ms, mb = I.merge_overlapping_masks(fm > 0.5, fs, fb, iou_threshold=mt)
+        else:
+            mm, ms, mb = fm > 0.5, fs, fb
+        assert len(mm) == int(gold[f"{name}/merged_count"]), name
+        assert np.array_equal(np.packbits(mm.numpy().astype(bool), axis=-1), gold[f"{name}/merged_masks"]), name
+        assert np.array_equal(ms.numpy(), gold[f"{name}/merged_scores"]) and np.array_equal(mb.numpy(), gold[f"{name}/merged_boxes"]), name
