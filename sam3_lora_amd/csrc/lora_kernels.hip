@@ -1271,7 +1271,7 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
                   {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
-                  {"SAM3_LORA_FUSED_ORDER", false, 0}};
+                  {"SAM3_LORA_FUSED_ORDER", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -2106,7 +2106,7 @@ static int fused_cu_count() {
 
 int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, int dtype) {
     return dtype == SAM3_LORA_BF16 && rank >= 1 && rank <= 32 && in_features > 0 && out_features > 0 &&
-           in_features % fl::BK == 0 && out_features % 8 == 0;
+           in_features % 64 == 0 && out_features % 8 == 0;
 }
 
 size_t sam3_lora_linear_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
@@ -2126,8 +2126,8 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
     layout &= ~SAM3_LORA_PREPACKED;
     if ((rc = check_common(M, in_features, out_features, rank, layout, dtype))) return rc;
     if (!sam3_lora_linear_fwd_supported(in_features, out_features, rank, dtype))
-        return fail(SAM3_LORA_ENOTSUP, "fused linear: bf16 activations, rank <= 32, in_features %% %d == 0 (got in %d, rank %d, dtype %d)",
-                    fl::BK, in_features, rank, dtype);
+        return fail(SAM3_LORA_ENOTSUP, "fused linear: bf16 activations, rank <= 32, in_features %% 64 == 0 (got in %d, rank %d, dtype %d)",
+                    in_features, rank, dtype);
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
     if ((rc = check_act(W, ldw, in_features, dtype, "W"))) return rc;
     if ((rc = check_act(y_out, ldy, out_features, dtype, "y_out"))) return rc;
@@ -2181,22 +2181,27 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
         fa.Y = (bf16_t*)y_out; fa.ldy = ldy;
         fa.A = (bf16_t*)act_out; fa.lda = ldact;
         fa.M = M; fa.Mp = Mp; fa.N = out_features; fa.K = in_features;
-        fa.tiles_m = (int)((M + fl::BM - 1) / fl::BM);
-        fa.tiles_n = (out_features + fl::BN - 1) / fl::BN;
+        // tile configuration: 1 = fl::CfgPair (256 x 128 x 32, two workgroups per CU), 0 = fl::CfgBig (256 x 256 x 64, one)
+        const int pair = (int)env_int("SAM3_LORA_FUSED_TILE", 0);
+        const int bm = pair ? fl::CfgPair::BM : fl::CfgBig::BM, bn = pair ? fl::CfgPair::BN : fl::CfgBig::BN;
+        fa.tiles_m = (int)((M + bm - 1) / bm);
+        fa.tiles_n = (out_features + bn - 1) / bn;
         fa.order = (int)env_int("SAM3_LORA_FUSED_ORDER", 0);
         const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
-        long long grid = env_int("SAM3_LORA_FUSED_WGS", fused_cu_count());
+        long long grid = env_int("SAM3_LORA_FUSED_WGS", (long long)fused_cu_count() * (pair ? fl::CfgPair::WGS_PER_CU : 1));
         if (grid > ntiles) grid = ntiles;
         if (grid < 1) grid = 1;
         const int trow = RP * 2;
         ProfScope ps(SAM3_LORA_STAGE_FUSED, out_features, st);
-#define SAM3_FL_LAUNCH(ACT_, TROW_) \
-        hipLaunchKernelGGL((fl::k_fused_linear<ACT_, TROW_>), dim3((unsigned)grid), dim3(fl::NTHREADS), 0, st, fa)
+#define SAM3_FL_LAUNCH(CFG_, ACT_, TROW_) \
+        hipLaunchKernelGGL((fl::k_fused_linear<fl::CFG_, ACT_, TROW_>), dim3((unsigned)grid), dim3(fl::TileGeo<fl::CFG_>::NTHREADS), 0, st, fa)
+#define SAM3_FL_CFG(ACT_, TROW_) do { if (pair) SAM3_FL_LAUNCH(CfgPair, ACT_, TROW_); else SAM3_FL_LAUNCH(CfgBig, ACT_, TROW_); } while (0)
         if (act) {
-            if (trow == 64) SAM3_FL_LAUNCH(1, 64); else SAM3_FL_LAUNCH(1, 32);
+            if (trow == 64) SAM3_FL_CFG(1, 64); else SAM3_FL_CFG(1, 32);
         } else {
-            if (trow == 64) SAM3_FL_LAUNCH(0, 64); else SAM3_FL_LAUNCH(0, 32);
+            if (trow == 64) SAM3_FL_CFG(0, 64); else SAM3_FL_CFG(0, 32);
         }
+#undef SAM3_FL_CFG
 #undef SAM3_FL_LAUNCH
     }
     return launch_ok("sam3_lora_linear_fwd");

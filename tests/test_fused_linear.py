@@ -37,7 +37,7 @@ def _reload():
 def _knobs_back():
     yield
     if torch.cuda.is_available():
-        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_SINGLE_ROUND"):
+        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_SINGLE_ROUND"):
             os.environ.pop(k, None)
         _reload()
         Fn.set_fused_linear(None)
@@ -68,7 +68,10 @@ SHAPES = [(1000, 128, 520, 16, 0), (1000, 128, 520, 16, 1), (37, 64, 8, 4, 0), (
 @pytest.mark.parametrize("M,fin,fout,rank,layout", SHAPES)
 @pytest.mark.parametrize("gelu", [False, True])
 @pytest.mark.parametrize("packed", [False, True])
-def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, layout, gelu, packed):
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, layout, gelu, packed, tile):
+    os.environ["SAM3_LORA_FUSED_TILE"] = tile       # 0: 256 x 256 x 64, one workgroup per CU; 1: 256 x 128 x 32, two per CU
+    _reload()
     x, W, b, A, B = _case(M, fin, fout, rank, layout, seed=M + rank)
     s = 1.7
     want = O.lora_linear_forward(x, W, b, A, B, s, layout, acc_dtype=np.float64)
@@ -85,7 +88,10 @@ def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, lay
     assert torch.equal(tT, tT2)
 
 
-def test_no_bias_and_rank_32_single_rounded_images():
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_no_bias_and_rank_32_single_rounded_images(tile):
+    os.environ["SAM3_LORA_FUSED_TILE"] = tile
+    _reload()
     M, fin, fout = 700, 128, 520
     for rank, tol in ((32, 1e-2), (24, 1e-2)):
         x, W, _, A, B = _case(M, fin, fout, rank, 0, seed=rank, bias=False)
@@ -113,14 +119,14 @@ def test_dropout_on_the_branch_input_only():
 
 
 def test_persistent_tile_walk_is_bit_identical_for_any_grid():
-    """12 tiles on 1 / 3 / 5 / 256 workgroups (tiles per workgroup: 12, 4, 2-3, 1), repeated: the same bits."""
+    """12 (24) tiles on 1 / 3 / 5 / 512 workgroups, both tile orders, both tile configurations, repeated: the same bits."""
     M, fin, fout, rank = 1000, 192, 776, 16
     x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=3)
     args = (_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), 2.0, 0)
     outs = []
-    for wgs in ("1", "3", "5", "256"):
-        for order in ("0", "1"):        # tile order: column tile fastest / column blocks (placement only)
-            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_ORDER"] = wgs, order
+    for wgs, order, tile in [(w, o, t) for w in ("1", "3", "5", "512") for o in ("0", "1") for t in ("0", "1")]:
+        if True:        # grid size, tile order (placement only) and tile configuration (same K order per output element)
+            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_ORDER"], os.environ["SAM3_LORA_FUSED_TILE"] = wgs, order, tile
             _reload()
             for _ in range(3):              # repeated: a race between DMA and read would show as run-to-run differences
                 y, a, _ = Fn.lora_linear_fwd_(*args, gelu=True)
@@ -131,7 +137,14 @@ def test_persistent_tile_walk_is_bit_identical_for_any_grid():
     _one_rounding(outs[0][0].float().cpu().numpy(), want)
 
 
-def test_fused_linear_at_configs1_fc1_shape():
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_fused_linear_at_configs1_fc1_shape(tile):
+    os.environ["SAM3_LORA_FUSED_TILE"] = tile
+    _reload()
+    _configs1_fc1_shape()
+
+
+def _configs1_fc1_shape():
     """BASELINE configs[1]: M = 8 x 5184, fc1 1024 -> 4736, r = 16: sampled rows against fp64 on the GPU (the oracle's
     expression in torch.float64), all columns; a = GELU(h); bit-reproducible run to run."""
     g = torch.Generator(device=DEV).manual_seed(0)

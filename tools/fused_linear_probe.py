@@ -60,17 +60,20 @@ def main():
     torch.cuda.synchronize()
     rounds = {}
     variants = [("two_pass", two_pass, {}), ("gemm_only", gemm_only, {}),
-                ("fused", fused, {}), ("fused_order0", fused, {"SAM3_LORA_FUSED_ORDER": "0"}), ("fused_noact", fused_noact, {})]
+                ("fused_big", fused, {"SAM3_LORA_FUSED_TILE": "0"}), ("fused_pair", fused, {"SAM3_LORA_FUSED_TILE": "1"}),
+                ("fused_noact_big", fused_noact, {"SAM3_LORA_FUSED_TILE": "0"})]
     for r in range(5):
         for name, f, env in variants:
-            for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER"):
+            for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_FUSED_TILE"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             lib.sam3_lora_debug_reload_knobs()
             f()
             rounds.setdefault(name, []).append(timed(f, 10))
-    for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER"):
+    for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_FUSED_TILE"):
         os.environ.pop(k, None)
+    if os.environ.get("PROBE_TILE"):
+        os.environ["SAM3_LORA_FUSED_TILE"] = os.environ["PROBE_TILE"]
     lib.sam3_lora_debug_reload_knobs()
     out["us"] = {k: {"median": float(np.median(v)), "min": float(np.min(v)), "all": [round(t, 1) for t in v]} for k, v in rounds.items()}
     # in-situ split of the fused call and of the two-pass adapter call
