@@ -57,6 +57,10 @@ def test_two_ranks_launched_like_the_driver_complete():
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
     assert r["adapter_path"]["no_recompute"]["value"] > 0 and r["config"]["finite"]
     assert r["exchange_overlap"]["world"] == 2 and r["exchange_overlap"]["step_ms_exposed"] > 0
+    # the per-bucket timeline (HIP events on the reducer's side stream against the end of backward): every bucket once, in index order
+    tl = r["exchange_overlap"]["buckets_rank0"]
+    assert [b["bucket"] for b in tl] == list(range(r["exchange_overlap"]["collectives_per_step"])) and len(tl) >= 1
+    assert all(b["end_ms_after_backward_end"] >= b["start_ms_after_backward_end"] and b["bytes"] > 0 for b in tl)
     assert r["distributed"]["rank_device_ids"] == [0, 0] and r["distributed"]["backend"] == "gloo"
     assert sum(1 for l in p.stdout.splitlines() if l.startswith("{")) == 1      # rank 0 only
 
