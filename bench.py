@@ -336,6 +336,57 @@ def torch_unfused_block(w, iters=5):
     return avg
 
 
+def fused_site_measurement(w, iters=5):
+    """SURVEY 8(f)-1 at the benchmark's fc1 site (M rows, 1024 -> 4736): `h = x W^T + b + s (x A) B`, `a = GELU(h)` as
+    hipBLASLt GEMM + sam3_lora_fwd_act (k_t1 + k_t2<GELU>) against sam3_lora_linear_fwd (k_t1 + k_wext + k_fused_linear), interleaved
+    in this process; the fused GEMM kernel alone from the library's in-situ timer, against the dense bf16 MFMA peak."""
+    import ctypes
+    from sam3_lora_amd import _ffi
+    from sam3_lora_amd.functional import lora_fwd_, lora_linear_fwd_, pack_operands
+    dev, M, s = w.dev, w.M, w.scaling
+    if w.x1[0].dtype != torch.bfloat16 or w.rank > 32:
+        return {"note": "bf16 activations and rank <= 32 only"}
+    g = torch.Generator(device=dev).manual_seed(7)
+    W = (torch.randn(D_HID, D_MODEL, device=dev, generator=g) / 32).bfloat16()
+    b = (torch.randn(D_HID, device=dev, generator=g) * 0.1).bfloat16()
+    x, A, B = w.x1[0], w.A1[0].detach(), w.B1[0].detach()
+    blob = pack_operands(A, B, 0)
+    h, a = torch.empty(M, D_HID, device=dev, dtype=torch.bfloat16), torch.empty(M, D_HID, device=dev, dtype=torch.bfloat16)
+
+    def two_pass():
+        torch.addmm(b, x, W.t(), out=h)
+        lora_fwd_(x, A, B, h, s, 0, packed=blob, gelu_out=a)
+
+    def fused():
+        lora_linear_fwd_(x, W, b, A, B, s, 0, packed=blob, gelu=True, y_out=h, gelu_out=a)
+    t2, tf = [], []
+    for _ in range(3):
+        t2.append(time_events(two_pass, iters, warm=1, reps=1)[0])
+        tf.append(time_events(fused, iters, warm=1, reps=1)[0])
+    lib = _ffi.load()
+    cap = 16
+    lib.sam3_lora_prof_start(_ffi.STAGE_FUSED, cap)
+    for _ in range(5):
+        fused()
+    us, st, dm = (ctypes.c_float * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    n = lib.sam3_lora_prof_stop(us, st, dm, cap)
+    k_us = sorted(us[i] for i in range(n))[n // 2] if n > 0 else None
+    flop = 2.0 * M * D_MODEL * D_HID
+    out = {"M": M, "in": D_MODEL, "out": D_HID, "two_pass_us": round(sorted(t2)[1], 1), "fused_us": round(sorted(tf)[1], 1),
+           "speedup": round(sorted(t2)[1] / sorted(tf)[1], 3),
+           "what": "the fc1 -> GELU site: hipBLASLt GEMM + sam3_lora_fwd_act against sam3_lora_linear_fwd (the adapter inside the "
+                   "frozen GEMM), interleaved rounds, HIP events on the current stream"}
+    if k_us:
+        out["roofline"] = {"bound": "mfma", "kernel": f"k_fused_linear [M={M},N={D_HID},K={D_MODEL}+64]", "avg_us": round(k_us, 1),
+                           "achieved": round(flop / k_us / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                           "frac": round(flop / k_us / 1e6 / 2500.0, 4),
+                           "hbm_bytes_written": 2 * M * D_HID * 2,
+                           "what": "frozen-GEMM FLOPs only (the rank-r K step and the GELU epilogue are overhead) over the in-situ kernel "
+                                   "time, against the 2.5 PFLOP/s dense bf16 peak; PMC WRITE_SIZE = exactly 2 M N e "
+                                   "(profiles/r04d_fc1_site_pmc_write.txt)"}
+    return out
+
+
 def trunk_step_bench(dev, batch, rank, steps, world, checkpoint=True):
     """The adapters in their real host: the SAM3 ViT-Det trunk (sam3_lora_amd/vit.py, 32 blocks, 1008^2 input,
     random init, frozen weights bf16) with root-API LoRA on fc1/fc2, one training step = forward with per-block
@@ -983,6 +1034,11 @@ def main():
                                                   "torch.autograd, same activation dtype, same GPU"}
         except Exception as e:      # an auxiliary comparison must never cost the bench line
             out["torch_unfused_block"] = {"error": str(e)[:200]}
+        try:
+            if args.blocks == N_BLOCKS or args.model == "sam3":
+                out["fused_linear_site"] = fused_site_measurement(w)
+        except Exception as e:
+            out["fused_linear_site"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         out["roofline"]["operands"] = ("hi + lo bf16 pairs for A, B, t, gt (fp32 arithmetic on the bf16 activations; "
                                        "include/sam3_lora_amd.h)" if w.rank <= 16 and e_ == 2 else "single-rounded bf16 / fp32")
     # the same kernels with single-rounded operands (round 2's arithmetic: SAM3_LORA_SINGLE_ROUND=1) -- what the hi + lo form costs

@@ -196,6 +196,25 @@ def test_mlp_node_with_the_fused_fc1_matches_the_two_pass_form():
         assert (u - v).abs().max() / v.abs().max() < tol, ((u - v).abs().max() / v.abs().max()).item()
 
 
+def test_row_pitches_larger_than_the_row_width():
+    """x, W, y and the GELU output as column slices of wider tensors (row pitch > width, 16-byte aligned): the descriptors address
+    by pitch; nothing outside the slices is touched."""
+    M, fin, fout, rank, s = 333, 128, 264, 16, 2.0
+    x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=21)
+    want = O.lora_linear_forward(x, W, b, A, B, s, 0, acc_dtype=np.float64)
+    xw = torch.full((M, fin + 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    xw[:, 32:32 + fin] = _t(x, torch.bfloat16)
+    Ww = torch.full((fout, fin + 16), 7.0, device=DEV, dtype=torch.bfloat16)
+    Ww[:, :fin] = _t(W, torch.bfloat16)
+    yw = torch.full((M, fout + 24), 5.0, device=DEV, dtype=torch.bfloat16)
+    aw = torch.full((M, fout + 8), 3.0, device=DEV, dtype=torch.bfloat16)
+    y, a, _ = Fn.lora_linear_fwd_(xw[:, 32:32 + fin], Ww[:, :fin], _t(b, torch.bfloat16), _t(A), _t(B), s, 0, gelu=True,
+                                  y_out=yw[:, 8:8 + fout], gelu_out=aw[:, :fout])
+    _one_rounding(yw[:, 8:8 + fout].float().cpu().numpy(), want)
+    _one_rounding(aw[:, :fout].float().cpu().numpy(), torch.nn.functional.gelu(yw[:, 8:8 + fout].double()).cpu().numpy(), slack=1e-6)
+    assert bool((yw[:, :8] == 5.0).all()) and bool((yw[:, 8 + fout:] == 5.0).all()) and bool((aw[:, fout:] == 3.0).all())
+
+
 def test_unsupported_shapes_say_so():
     lib = _ffi.load()
     assert lib.sam3_lora_linear_fwd_supported(1024, 4736, 16, 0) == 1
