@@ -38,7 +38,9 @@
  *                         rank-r intermediates t / gt are carried as hi + lo bf16 pairs (16 mantissa bits), so the branch
  *                         and its gradients are fp32 arithmetic on the caller's bf16 tensors -- the only bf16 roundings are
  *                         those of x / gy (the caller's) and of y / gx on the way out.  16 < r: A, B, t, gt rounded to
- *                         bf16 once each (also for r <= 16 with SAM3_LORA_SINGLE_ROUND=1 in the environment);
+ *                         bf16 once each (also for r <= 16 with SAM3_LORA_SINGLE_ROUND=1 in the environment).  With
+ *                         SAM3_LORA_EXACT_GROUPS=1 ranks above 16 run as consecutive groups of 16 on the hi + lo kernels instead
+ *                         (one more pass over the activations per group; blob / saved-t sizes follow -- ask the sizing functions);
  *         SAM3_LORA_F32   exact fp32: fp32 operands on v_mfma_f32_16x16x4_f32, fp32 intermediates -- the arithmetic
  *                         of the reference's un-autocast training (train_sam3_lora_native.py).
  *     gA/gB are accumulated and returned in fp32 either way.
@@ -247,7 +249,7 @@ unsigned sam3_lora_debug_set_stages(unsigned mask);
 
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
  * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_WGS,
- * SAM3_LORA_FUSED_ORDER, SAM3_LORA_FUSED_TILE) are read from the
+ * SAM3_LORA_FUSED_ORDER, SAM3_LORA_FUSED_TILE, SAM3_LORA_EXACT_GROUPS) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);

@@ -1271,7 +1271,8 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
                   {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
-                  {"SAM3_LORA_FUSED_ORDER", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0}};
+                  {"SAM3_LORA_FUSED_ORDER", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0},
+                  {"SAM3_LORA_EXACT_GROUPS", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1374,8 +1375,18 @@ void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
 // Ranks above 32 run as consecutive groups of <= 32 rank indices (the kernels hold one or two 16-wide rank tiles):
 // y += s (x A_g) B_g per group, and the four gradient products per group -- A_c / B_c slices are addressed through
 // the strides of the full tensors, so no copy is made.
-inline int n_groups(int rank) { return (rank + 31) / 32; }
-inline int group_rank(int rank, int g) { return rank - 32 * g < 32 ? rank - 32 * g : 32; }
+// SAM3_LORA_EXACT_GROUPS=1 (bf16 activations): groups of 16 instead of 32, so that EVERY rank runs on the hi + lo kernels -- one-rounding
+// outputs and 3e-5 gradients also for the reference's default rank 32 (configs/full_lora_config.yaml:12), at the price of one more pass
+// over the activations per 16 rank indices (r = 32: the adapter path twice; measured in DESIGN section 8).  Off by default: the
+// single-rounded rank-32 group is 1.7 % behind the r = 16 step and its error is invisible end to end (tools/bf16_parity_probe.py).
+inline int group_size(int rank, int dtype) {
+    return (dtype != SAM3_LORA_F32 && rank > 16 && env_flag("SAM3_LORA_EXACT_GROUPS")) ? 16 : 32;
+}
+inline int n_groups(int rank, int dtype) { const int gs = group_size(rank, dtype); return (rank + gs - 1) / gs; }
+inline int group_rank(int rank, int g, int dtype) {
+    const int gs = group_size(rank, dtype);
+    return rank - gs * g < gs ? rank - gs * g : gs;
+}
 
 // caller-held operand images (sam3_lora_pack) of ONE group: [ W1 = A_c^T | W2t = B_c^T | W1b = B_c | W2tb = A_c ],
 // bf16 for SAM3_LORA_BF16 activations, fp32 for SAM3_LORA_F32 (exact path); groups follow each other in the blob
@@ -1396,7 +1407,7 @@ PackedLayout packed_layout(int in_f, int out_f, int rank, int dtype) {
 }
 size_t packed_total(int in_f, int out_f, int rank, int dtype) {
     size_t n = 0;
-    for (int g = 0; g < n_groups(rank); ++g) n += packed_layout(in_f, out_f, group_rank(rank, g), dtype).total;
+    for (int g = 0; g < n_groups(rank, dtype); ++g) n += packed_layout(in_f, out_f, group_rank(rank, g, dtype), dtype).total;
     return n;
 }
 // bytes of the saved t of one group: bf16 fragment-major [r_pad, M_pad], or fp32 row-major [M_pad, r_pad]
@@ -1716,18 +1727,18 @@ const char* sam3_lora_last_error(void) { return g_err; }
 size_t sam3_lora_saved_t_bytes(int64_t M, int rank, int dtype) {
     if (M <= 0 || rank < 1 || rank > SAM3_LORA_MAX_RANK) return 0;
     size_t n = 0;
-    for (int g = 0; g < n_groups(rank); ++g) n += saved_t_group_bytes(M, group_rank(rank, g), dtype);
+    for (int g = 0; g < n_groups(rank, dtype); ++g) n += saved_t_group_bytes(M, group_rank(rank, g, dtype), dtype);
     return n;
 }
 
 size_t sam3_lora_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
     if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
-    return fwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
+    return fwd_ws(M, in_features, out_features, group_rank(rank, 0, dtype), dtype).total;
 }
 
 size_t sam3_lora_bwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
     if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
-    return bwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
+    return bwd_ws(M, in_features, out_features, group_rank(rank, 0, dtype), dtype).total;
 }
 
 size_t sam3_lora_packed_bytes(int in_features, int out_features, int rank, int dtype) {
@@ -1742,13 +1753,14 @@ static int pack_jobs_of(const void* A, const void* B, void* packed, int in_featu
     const int f32 = dtype == SAM3_LORA_F32;
     char* p = (char*)packed;
     int n = 0;
-    for (int g = 0; g < n_groups(rank); ++g) {
-        const int rg = group_rank(rank, g);
+    const int gs = group_size(rank, dtype);
+    for (int g = 0; g < n_groups(rank, dtype); ++g) {
+        const int rg = group_rank(rank, g, dtype);
         const Geo gq = geo_of(rg, dtype);
         const int RP = gq.RP, hr = gq.hl ? 1 : 0, hc = gq.hl ? 2 : 0;       // hi + lo along the image's rows / columns
         const PackedLayout pl = packed_layout(in_features, out_features, rg, dtype);
-        const float* Ag = (const float*)A + 32LL * g * s.a_sr;
-        const float* Bg = (const float*)B + 32LL * g * s.b_sr;
+        const float* Ag = (const float*)A + (long long)gs * g * s.a_sr;
+        const float* Bg = (const float*)B + (long long)gs * g * s.b_sr;
         jobs[n++] = PackJob{Ag, p + pl.w1, RP, in_features, rg, in_features, s.a_sr, s.a_si, 0, f32, hr};
         jobs[n++] = PackJob{Bg, p + pl.w2t, out_features, RP, out_features, rg, s.b_so, s.b_sr, 0, f32, hc};
         jobs[n++] = PackJob{Bg, p + pl.w1b, RP, out_features, rg, out_features, s.b_sr, s.b_so, 0, f32, hr};
@@ -1765,7 +1777,7 @@ int sam3_lora_pack(const void* A, const void* B, void* packed, int in_features, 
     if ((rc = check_common(1, in_features, out_features, rank, layout, dtype))) return rc;
     if (!A || !B || !packed) return fail(SAM3_LORA_EINVAL, "NULL pointer");
     if (((uintptr_t)packed & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
-    PackJob* jobs = new PackJob[4 * (size_t)n_groups(rank)];
+    PackJob* jobs = new PackJob[4 * (size_t)n_groups(rank, dtype)];
     const int n = pack_jobs_of(A, B, packed, in_features, out_features, rank, layout, dtype, jobs);
     launch_pack(jobs, n, (hipStream_t)stream);
     delete[] jobs;
@@ -1785,7 +1797,7 @@ int sam3_lora_pack_many(int count, const void* const* A, const void* const* B, v
         if ((rc = check_common(1, in_features[i], out_features[i], rank[i], layout, dtype))) return rc;
         if (!A[i] || !B[i] || !packed[i]) return fail(SAM3_LORA_EINVAL, "NULL pointer in entry %d", i);
         if (((uintptr_t)packed[i] & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned (entry %d)", i);
-        total += 4 * (size_t)n_groups(rank[i]);
+        total += 4 * (size_t)n_groups(rank[i], dtype);
     }
     PackJob* jobs = new PackJob[total];
     int n = 0;
@@ -1851,7 +1863,7 @@ static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, 
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
     if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
     float inv_keep; const DropKey dk = make_dropkey(drop_p, seed, offset, in_features, &inv_keep);
-    const size_t need = fwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
+    const size_t need = fwd_ws(M, in_features, out_features, group_rank(rank, 0, dtype), dtype).total;
     if (!workspace || workspace_bytes < need)
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
@@ -1861,13 +1873,13 @@ static int fwd_impl(const void* x, const void* A, const void* B, void* y_inout, 
     if (dtype != SAM3_LORA_BF16 && dtype != SAM3_LORA_F32) return fail(SAM3_LORA_EINVAL, "unknown dtype %d", dtype);
 
     const Strides s = strides_of(layout, in_features, out_features, rank);
-    const int ng = n_groups(rank);
+    const int ng = n_groups(rank, dtype), gs = group_size(rank, dtype);
     const char* blob = (const char*)A;
     char* tT = (char*)tT_out;
     for (int g = 0; g < ng; ++g) {
-        const int rg = group_rank(rank, g);
-        const void* Ag = pre ? (const void*)blob : (const void*)((const float*)A + 32LL * g * s.a_sr);
-        const void* Bg = pre ? nullptr : (const void*)((const float*)B + 32LL * g * s.b_sr);
+        const int rg = group_rank(rank, g, dtype);
+        const void* Ag = pre ? (const void*)blob : (const void*)((const float*)A + (long long)gs * g * s.a_sr);
+        const void* Bg = pre ? nullptr : (const void*)((const float*)B + (long long)gs * g * s.b_sr);
         // the activation rides on the LAST group's update: by then y holds the complete sum
         const int act_g = (g == ng - 1) ? act : 0;
         fwd_group(x, Ag, Bg, pre, y_inout, tT, M, in_features, out_features, rg, ldx, ldy, s, scaling * inv_keep, dk, dtype,
@@ -2020,21 +2032,21 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
     if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
     if (act && !gx_inout) return fail(SAM3_LORA_EINVAL, "an activation derivative needs gx_inout");
     if (act && (rc = check_act(pre_act, ldpre, in_features, dtype, "pre_act"))) return rc;
-    const size_t need = bwd_ws(M, in_features, out_features, group_rank(rank, 0), dtype).total;
+    const size_t need = bwd_ws(M, in_features, out_features, group_rank(rank, 0, dtype), dtype).total;
     if (!workspace || workspace_bytes < need)
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
 
     const Strides s = strides_of(layout, in_features, out_features, rank);
-    const int ng = n_groups(rank);
+    const int ng = n_groups(rank, dtype), gs = group_size(rank, dtype);
     const char* blob = (const char*)A;
     const char* tT = (const char*)tT_saved;
     for (int g = 0; g < ng; ++g) {
-        const int rg = group_rank(rank, g);
-        const void* Ag = pre ? (const void*)blob : (const void*)((const float*)A + 32LL * g * s.a_sr);
-        const void* Bg = pre ? nullptr : (const void*)((const float*)B + 32LL * g * s.b_sr);
-        float* gAg = gA_accum ? gA_accum + 32LL * g * s.a_sr : nullptr;
-        float* gBg = gB_accum ? gB_accum + 32LL * g * s.b_sr : nullptr;
+        const int rg = group_rank(rank, g, dtype);
+        const void* Ag = pre ? (const void*)blob : (const void*)((const float*)A + (long long)gs * g * s.a_sr);
+        const void* Bg = pre ? nullptr : (const void*)((const float*)B + (long long)gs * g * s.b_sr);
+        float* gAg = gA_accum ? gA_accum + (long long)gs * g * s.a_sr : nullptr;
+        float* gBg = gB_accum ? gB_accum + (long long)gs * g * s.b_sr : nullptr;
         const int a2 = (act && g == ng - 1) ? 2 : 0;
         bwd_group(gy, x, tT, Ag, Bg, pre, gx_inout, gAg, gBg, M, in_features, out_features, rg, ldgy, ldx, ldgx, s,
                   scaling * inv_keep, dk, dtype, accumulate, (char*)workspace, (hipStream_t)stream, a2,
@@ -2105,7 +2117,7 @@ static int fused_cu_count() {
 }
 
 int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, int dtype) {
-    return dtype == SAM3_LORA_BF16 && rank >= 1 && rank <= 32 && in_features > 0 && out_features > 0 &&
+    return dtype == SAM3_LORA_BF16 && rank >= 1 && rank <= 32 && n_groups(rank, dtype) == 1 && in_features > 0 && out_features > 0 &&
            in_features % 64 == 0 && out_features % 8 == 0;
 }
 

@@ -65,9 +65,14 @@ def _oracle_full_grads(gy, x, A, B, s, layout, mask=None, chunk=4096):
     return gA, gB
 
 
-def _one_rounding(got, ref, slack=3e-5):
+def _one_rounding(got, ref, slack=3e-5, intermediate=None):
+    """|got - ref| <= half an ulp of ref (one rounding to bf16) + slack; `intermediate`: the value that was ALSO rounded on the way
+    (the in-place result after the first of two rank groups) adds half an ulp of ITS magnitude."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    bad = np.abs(got - ref) > 2.0 ** -8 * np.abs(ref) + slack * np.abs(ref).max()
+    bound = 2.0 ** -8 * np.abs(ref) + slack * np.abs(ref).max()
+    if intermediate is not None:
+        bound = bound + 2.0 ** -8 * np.abs(np.asarray(intermediate, np.float64))
+    bad = np.abs(got - ref) > bound
     assert not bad.any(), (int(bad.sum()), float((np.abs(got - ref) / (np.abs(ref).max() + 1e-30)).max()))
 
 
@@ -80,14 +85,38 @@ CASES = [  # (tag, batch, fin, fout, rank, alpha, drop)
 ]
 
 
+@pytest.fixture(autouse=True)
+def _knobs_back():
+    yield
+    if torch.cuda.is_available():
+        import os
+        from sam3_lora_amd import _ffi
+        os.environ.pop("SAM3_LORA_EXACT_GROUPS", None)
+        _ffi.load().sam3_lora_debug_reload_knobs()
+
+
+@pytest.mark.parametrize("tag,batch,fin,fout,r,alpha,drop", [c for c in CASES if c[4] == 32], ids=[c[0] for c in CASES if c[4] == 32])
+def test_rank_32_in_exact_groups_of_16_meets_the_hi_lo_bars(tag, batch, fin, fout, r, alpha, drop):
+    """SAM3_LORA_EXACT_GROUPS=1: ranks above 16 run as groups of 16 on the hi + lo kernels -- the reference's default rank 32 (and
+    its literal dropout 0.1) then gets the fp32 weight gradients of r <= 16 (3e-5 of max against fp64) and bf16 outputs within TWO
+    roundings of fp64 values: the in-place tensor is rounded once after the first group (half an ulp of THAT value) and once at the
+    end (one rounding only would need the 32 rank indices in one pass, i.e. 64-wide hi + lo kernels -- not built).  Opt-in: +9.6 % on the literal step (profiles/r04p).  Default: one
+    single-rounded group of 32, 1e-2 -- the case below."""
+    import os
+    from sam3_lora_amd import _ffi
+    os.environ["SAM3_LORA_EXACT_GROUPS"] = "1"
+    _ffi.load().sam3_lora_debug_reload_knobs()
+    test_named_configs_at_full_size_against_oracle(tag, batch, fin, fout, r, alpha, drop, "bf16", exact_groups=True)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("tag,batch,fin,fout,r,alpha,drop", CASES, ids=[c[0] for c in CASES])
-def test_named_configs_at_full_size_against_oracle(tag, batch, fin, fout, r, alpha, drop, dtype):
+def test_named_configs_at_full_size_against_oracle(tag, batch, fin, fout, r, alpha, drop, dtype, exact_groups=False):
     if dtype == "f32" and tag.startswith(("c0", "c3-fc2", "c4")):
         pytest.skip("fp32 covered by the r=16 and literal-config cases at this size")
     M, s = batch * TOK, alpha / r
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
-    exact = dtype == "bf16" and r <= 16                 # hi + lo operands: fp32 arithmetic on bf16 data
+    exact = dtype == "bf16" and (r <= 16 or exact_groups)      # hi + lo operands: fp32 arithmetic on bf16 data
     tol = (3e-5 if exact else 1e-2) if dtype == "bf16" else 2e-5
     x, gy, base, gxb, A, B = _inputs(M, fin, fout, r, seed=len(tag) + r)
     seed, p = 1234567, drop
@@ -106,8 +135,13 @@ def test_named_configs_at_full_size_against_oracle(tag, batch, fin, fout, r, alp
     want_y = base[rows] + O.adapter_delta(x[rows], A, B, s, 0, drop_scale_mask=mrows, acc_dtype=np.float64)
     gx_l, _, _ = O.adapter_backward(gy[rows], x[rows], A, B, s, 0, drop_scale_mask=mrows, acc_dtype=np.float64)
     if exact:
-        _one_rounding(y[rows].float().cpu().numpy(), want_y)
-        _one_rounding(gx[rows].float().cpu().numpy(), gxb[rows] + gx_l)
+        mid_y = mid_gx = None
+        if exact_groups and r > 16:     # the in-place tensors after the FIRST group of 16 (rounded once there)
+            mid_y = base[rows] + O.adapter_delta(x[rows], A[:, :16], B[:16], s, 0, drop_scale_mask=mrows, acc_dtype=np.float64)
+            mid_gx = gxb[rows] + O.adapter_backward(gy[rows], x[rows], A[:, :16], B[:16], s, 0, drop_scale_mask=mrows,
+                                                    acc_dtype=np.float64)[0]
+        _one_rounding(y[rows].float().cpu().numpy(), want_y, intermediate=mid_y)
+        _one_rounding(gx[rows].float().cpu().numpy(), gxb[rows] + gx_l, intermediate=mid_gx)
     else:
         assert _relmax(y[rows].float().cpu().numpy(), want_y) < tol, "forward"
         assert _relmax(gx[rows].float().cpu().numpy(), gxb[rows] + gx_l) < tol, "input gradient"
