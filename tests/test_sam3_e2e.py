@@ -677,3 +677,38 @@ def test_fast_multihead_attention_equals_the_stock_module(batch_first, case, mas
     (y0, gi0, gw0, go0, gb0), (y1, gi1, gw1, go1, gb1) = outs
     close = lambda a, b: (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3)
     assert close(y0, y1) and all(close(a, b) for a, b in zip(gi0, gi1)) and close(gw0, gw1) and close(go0, go1) and close(gb0, gb1)
+
+
+def test_training_layout_islands_and_holes_on_cpu(gold):
+    """``vit.to_training_layout`` without a GPU: which tensors stay fp32 (the decoder's query stream + the scoring head), which
+    of those follow bf16 after all (each layer's image cross-attention, the two position-bias MLPs), that the boundary hooks make
+    the mixed model run (eval forward on the CPU in bf16), that scores / boxes leave in fp32, and that calling it again with
+    ``fp32_islands=()`` gives the all-bf16 layout and removes the hooks."""
+    from sam3_lora_amd.vit import DEFAULT_FP32_ISLANDS, to_training_layout
+    model = build(gold)
+    for p in model.parameters():            # what apply_lora_to_model does to the base (lora_layers.py:176-178); no adapters here
+        p.requires_grad_(False)
+    to_training_layout(model)
+    assert tuple(model._sam3_fp32_islands) == tuple(DEFAULT_FP32_ISLANDS)
+    dec = model.transformer.decoder
+    assert len(model._sam3_fp32_holes) == len(dec.layers) + 2
+    for n, p in model.named_parameters():
+        hole = any(n.startswith(h + ".") for h in model._sam3_fp32_holes)
+        island = n.startswith(("transformer.decoder.", "dot_prod_scoring."))
+        assert p.dtype == (torch.float32 if (island and not hole) else torch.bfloat16), (n, p.dtype)
+    assert dec.layers[0].self_attn.in_proj_weight.dtype == torch.float32
+    assert dec.layers[0].cross_attn.in_proj_weight.dtype == torch.bfloat16
+    batch = make_batch()
+    batch.img_batch = batch.img_batch.bfloat16()
+    model.eval()
+    with torch.no_grad():
+        out = model(batch)[0]
+    assert out["pred_logits"].dtype == out["pred_boxes"].dtype == torch.float32 and out["pred_masks"].dtype == torch.bfloat16
+    assert torch.isfinite(out["pred_logits"]).all() and torch.isfinite(out["pred_masks"].float()).all()
+    # close to the fp32 reference forward already on the CPU (bf16 trunk): logits within a few per cent of max
+    ref = gold["eval/pred_logits"]
+    assert np.abs(out["pred_logits"].numpy() - ref).max() <= 5e-2 * np.abs(ref).max()
+    n_hooks = len(model._sam3_layout_hooks)
+    assert n_hooks == 2 + len(model._sam3_fp32_holes) + 1          # two islands, the holes, the mask head that consumes the queries
+    to_training_layout(model, fp32_islands=())
+    assert model._sam3_layout_hooks == [] and all(p.dtype == torch.bfloat16 for p in model.parameters() if not p.requires_grad)
