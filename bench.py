@@ -242,7 +242,8 @@ def insitu_kernels(w, steps=2):
     M, r = w.M, w.rank
     e = w.x1[0].element_size()
     single = os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") not in ("", "0")
-    RP = 32 if (r > 16 or (e == 2 and not single)) else 16       # bf16, r <= 16: t / gt travel as hi | lo pairs (32 columns)
+    RG = 16 if r <= 16 else 32                                   # rank tile(s) of one group
+    RP = RG * (2 if (e == 2 and not single) else 1)              # bf16: t / gt travel as hi | lo pairs (2 RG columns)
     one_pass = r <= 16 and os.environ.get("SAM3_LORA_TWO_PASS_GY", "0") in ("", "0")
     names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2",
              _ffi.STAGE_T3_GB: "k_t3+gt" if one_pass else "k_t3", _ffi.STAGE_T3_GA: "k_t3",
@@ -961,8 +962,8 @@ def main():
                     "rank": 32, "alpha": 64, "dropout": 0.1, "vs_r16_line": round(v / out["value"], 4),
                     "finite": bool(torch.isfinite(lit.last_loss).item()), "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                     "what": "the same whole training step at configs/full_lora_config.yaml's literal adapter settings (r = 32, alpha = 64, "
-                            "LoRA dropout 0.1 generated inside the kernels): single-rounded bf16 operand images (hi + lo is r <= 16), "
-                            "two-pass backward, fc1 + GELU through sam3_lora_linear_fwd"}
+                            "LoRA dropout 0.1 generated inside the kernels): hi + lo operand images as at r = 16 (64-wide), two-pass "
+                            "backward, fc1 + GELU through sam3_lora_linear_fwd"}
             del lit
             torch.cuda.empty_cache()
         if args.full_only:

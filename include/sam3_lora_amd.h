@@ -34,13 +34,12 @@
  *     1 <= r <= SAM3_LORA_MAX_RANK; ranks above 32 run as consecutive groups of 32 rank indices (one more pass over
  *     the activations per group -- the reference has no rank limit, configs/full_lora_config.yaml:12).
  *   - activation dtype (x, y, gy, gx):
- *         SAM3_LORA_BF16  bf16 data on the bf16 MFMAs, fp32 accumulation.  r <= 16: the operand images of A / B and the
- *                         rank-r intermediates t / gt are carried as hi + lo bf16 pairs (16 mantissa bits), so the branch
- *                         and its gradients are fp32 arithmetic on the caller's bf16 tensors -- the only bf16 roundings are
- *                         those of x / gy (the caller's) and of y / gx on the way out.  16 < r: A, B, t, gt rounded to
- *                         bf16 once each (also for r <= 16 with SAM3_LORA_SINGLE_ROUND=1 in the environment).  With
- *                         SAM3_LORA_EXACT_GROUPS=1 ranks above 16 run as consecutive groups of 16 on the hi + lo kernels instead
- *                         (one more pass over the activations per group; blob / saved-t sizes follow -- ask the sizing functions);
+ *         SAM3_LORA_BF16  bf16 data on the bf16 MFMAs, fp32 accumulation.  The operand images of A / B and the rank-r intermediates
+ *                         t / gt of every rank group (<= 32 rank indices) are carried as hi + lo bf16 pairs (16 mantissa bits),
+ *                         so the branch and its gradients are fp32 arithmetic on the caller's bf16 tensors -- the only bf16
+ *                         roundings are those of x / gy (the caller's) and of y / gx on the way out (once per rank group).
+ *                         SAM3_LORA_SINGLE_ROUND=1 in the environment: A, B, t, gt rounded to bf16 once each instead;
+ *                         SAM3_LORA_HL_MAX_RANK=16: that only for groups of 17..32 rank indices (round 3's behaviour);
  *         SAM3_LORA_F32   exact fp32: fp32 operands on v_mfma_f32_16x16x4_f32, fp32 intermediates -- the arithmetic
  *                         of the reference's un-autocast training (train_sam3_lora_native.py).
  *     gA/gB are accumulated and returned in fp32 either way.
@@ -212,7 +211,7 @@ int sam3_lora_bwd_act_q8(const void* gy, const void* x, const void* tT_saved, co
  * W (row pitch ldw elements) and bias (or NULL) are the frozen layer's parameters in the activation dtype; A / B / layout /
  * tT_out / dropout arguments as sam3_lora_fwd (the rank-r intermediate t = drop(x) A_c still comes from one pass over x, and
  * rides into the GEMM as one more K step against the hi + lo image of scaling * B_c).  y_out need not be initialised.
- * Supported (sam3_lora_linear_fwd_supported != 0): SAM3_LORA_BF16, rank <= 32, in_features a multiple of 64, out_features a
+ * Supported (sam3_lora_linear_fwd_supported != 0): SAM3_LORA_BF16, rank <= 32 (one rank group), in_features a multiple of 64, out_features a
  * multiple of 8; SAM3_LORA_ENOTSUP otherwise -- the caller then runs its GEMM and sam3_lora_fwd / _fwd_act.
  */
 int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, int dtype);
@@ -249,7 +248,7 @@ unsigned sam3_lora_debug_set_stages(unsigned mask);
 
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
  * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_WGS,
- * SAM3_LORA_FUSED_ORDER, SAM3_LORA_FUSED_TILE, SAM3_LORA_EXACT_GROUPS) are read from the
+ * SAM3_LORA_FUSED_ORDER, SAM3_LORA_FUSED_TILE, SAM3_LORA_HL_MAX_RANK) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);

@@ -162,9 +162,9 @@ struct PackJob {
     long long si, sj;
     int ldd;              // row pitch of dst in elements (0 => J); > J when packing into a slice of a wider buffer
     int f32;
-    int hl;               // bf16 hi + lo image: 1 = rows 16..31 hold the lo parts of rows 0..15 (I == 32); 2 = columns (J == 32),
-                          // interleaved per 4 rank indices: [hi 4g..4g+3 | lo 4g..4g+3] at columns 8g..8g+7; Iv / Jv then
-                          // bound the rank index
+    int hl;               // bf16 hi + lo image: 1 = the second half of the I rows holds the lo parts of the first half (I == 32 / 64);
+                          // 2 = columns (J == 32 / 64), interleaved per 4 rank indices: [hi 4g..4g+3 | lo 4g..4g+3] at columns
+                          // 8g..8g+7; Iv / Jv then bound the rank index
 };
 
 constexpr int PACK_JOBS_MAX = 64;    // 64 x 56 B of kernel arguments per launch
@@ -179,8 +179,9 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
     const int i = (int)(idx / jb.J), j = (int)(idx % jb.J);
     // source index (both halves read the same master).  hl == 2 (k_t2's operand rows) interleaves the halves per group of 4
     // rank indices -- [hi 0..3 | lo 0..3 | hi 4..7 | lo 4..7 | ...] -- so that a lane's hi and lo fragments are ONE 16-byte load
-    const int is = jb.hl == 1 ? (i & 15) : i, js = jb.hl == 2 ? ((j >> 3) * 4 + (j & 3)) : j;
-    const bool lo = (jb.hl == 1 && i >= 16) || (jb.hl == 2 && ((j >> 2) & 1));
+    const int half = jb.I >> 1;
+    const int is = jb.hl == 1 ? (i >= half ? i - half : i) : i, js = jb.hl == 2 ? ((j >> 3) * 4 + (j & 3)) : j;
+    const bool lo = (jb.hl == 1 && i >= half) || (jb.hl == 2 && ((j >> 2) & 1));
     float v = (is < jb.Iv && js < jb.Jv) ? jb.src[is * jb.si + js * jb.sj] : 0.f;
     const long long o = (long long)i * (jb.ldd ? jb.ldd : jb.J) + j;
     if (jb.f32) {
@@ -261,16 +262,19 @@ __device__ __forceinline__ void store_t4(bf16_t* __restrict__ T, bf16_t* __restr
 // HL: the fp32 values v -> hi = bf16(v) as rank tile 0, lo = bf16(v - hi) as rank tile 1 of a rank-32 image
 // The row-major image (k_t2's operand) interleaves the halves per 4 rank indices: T[m][8 g .. 8 g + 3] = hi, [8 g + 4 .. + 7] =
 // lo (g = r0 / 4) -- one 16-byte store here, one 16-byte load per tile in k_t2.
-__device__ __forceinline__ void store_t4_hl(bf16_t* __restrict__ T, bf16_t* __restrict__ TTf, long long m, int r0, f32x4 v) {
+// RH rank tiles per half (RH = 1: r <= 16, RH = 2: r <= 32), `tt` = the rank tile of v: row image T[m][RH * 32] = tile after tile of
+// 32 entries; fragment-major image: 2 RH blocks per 32-row step, [hi tiles 0..RH-1 | lo tiles 0..RH-1].
+template <int RH>
+__device__ __forceinline__ void store_t4_hl(bf16_t* __restrict__ T, bf16_t* __restrict__ TTf, long long m, int tt, int r0, f32x4 v) {
     const unsigned h0 = pack2(v[0], v[1]), h1 = pack2(v[2], v[3]);
     const unsigned l0 = pack2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), l1 = pack2(v[2] - bf_lo(h1), v[3] - bf_hi(h1));
-    *reinterpret_cast<uint4*>(T + m * 32 + 2 * r0) = make_uint4(h0, h1, l0, l1);
+    *reinterpret_cast<uint4*>(T + m * (RH * 32) + tt * 32 + 2 * r0) = make_uint4(h0, h1, l0, l1);
     const long long blk = m >> 5;
     const int gq = (int)(m & 31) >> 3, jq = (int)(m & 7);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {        // fragment-major image: rank tile 0 = hi, 1 = lo (k_t3's two A-operands)
-        const unsigned p0 = rt ? l0 : h0, p1 = rt ? l1 : h1;
-        bf16_t* tb = TTf + (((blk * 2 + rt) * 4 + gq) * 16 + r0) * 8 + jq;
+    for (int hh = 0; hh < 2; ++hh) {        // fragment-major image: hi block, lo block of this rank tile (k_t3's A-operands)
+        const unsigned p0 = hh ? l0 : h0, p1 = hh ? l1 : h1;
+        bf16_t* tb = TTf + (((blk * (2 * RH) + hh * RH + tt) * 4 + gq) * 16 + r0) * 8 + jq;
         tb[0] = (bf16_t)(p0 & 0xffffu);
         tb[8] = (bf16_t)(p0 >> 16);
         tb[16] = (bf16_t)(p1 & 0xffffu);
@@ -289,8 +293,10 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
                                             bf16_t* __restrict__ TTf, long long M, long long Mp, int K,
                                             DropKey dk, float* __restrict__ P = nullptr, int kc_per = 0) {
     static_assert(!PART || RT == 1 || HL, "split-K partials are laid out for one rank tile");
-    static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
+    static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: rank tiles [hi .. | lo ..]");
+    static_assert(!(PART && HL) || RT == 2, "split-K partials are laid out for one rank tile");
     constexpr int RP = RT * 16, BM = 64, CPR = BK / 8;          // CPR 16-byte chunks per tile row
+    constexpr int RH = HL ? RT / 2 : RT;                        // rank tiles of the result
     constexpr int RPP = 256 / CPR;                               // tile rows covered per pass of 256 threads
     constexpr int XP = BM / RPP, WP = RP / RPP;                  // passes for the x tile / the W1 tile
     static_assert(RP % RPP == 0, "tile geometry");
@@ -325,12 +331,12 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
             const int row = lrow + RPP * i;
             uint4 v = xr[i];
             if (dk.thr) v = drop8(v, (unsigned long long)(m0 + row) * dk.width + k, dk);
-            xs[buf][row * CPR + (lc ^ (row & 15))] = v;
+            xs[buf][row * CPR + (lc ^ (row & (CPR - 1)))] = v;
         }
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
             const int r = lrow + RPP * j;
-            ws[buf][r * CPR + (lc ^ (r & 15))] = wr[j];
+            ws[buf][r * CPR + (lc ^ (r & (CPR - 1)))] = wr[j];
         }
     };
 
@@ -350,10 +356,10 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             const int c = kk * 4 + g;
-            const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[buf][row * CPR + (c ^ n)]);
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[buf][row * CPR + (c ^ (n & (CPR - 1)))]);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, ws[buf][(rt * 16 + n) * CPR + (c ^ n)]);
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, ws[buf][(rt * 16 + n) * CPR + (c ^ (n & (CPR - 1)))]);
                 // D[i = rank idx][n = activation row] += sum_k W1[i][k] * X[row][k]
                 acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[rt], 0, 0, 0);
             }
@@ -363,13 +369,17 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
     }
     // lane (n, g) holds t[row = m0 + wave*16 + n][rank idx = rt*16 + g*4 + j]
     const long long m = m0 + wave * 16 + n;
-    if (HL) acc[0] += acc[RT - 1];          // x.A_hi + x.A_lo
+    if (HL) {                               // x.A_hi + x.A_lo, rank tile by rank tile
+#pragma unroll
+        for (int tt = 0; tt < RH; ++tt) acc[tt] += acc[RH + tt];
+    }
     if (PART) {
         *reinterpret_cast<f32x4*>(P + ((long long)blockIdx.y * Mp + m) * 16 + g * 4) = acc[0];
         return;
     }
     if (HL) {
-        store_t4_hl(T, TTf, m, g * 4, acc[0]);
+#pragma unroll
+        for (int tt = 0; tt < RH; ++tt) store_t4_hl<RH>(T, TTf, m, tt, g * 4, acc[tt]);
         return;
     }
 #pragma unroll
@@ -602,13 +612,14 @@ struct GaEmit {
     float* part;            // [row blocks][16][N]
 };
 template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false>
-__global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
+__global__ __launch_bounds__(256, (HL && !DROP) ? (RT == 4 ? 2 : (ACT == 2 ? (GA ? 2 : 3) : 4)) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
                                             ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga) {
-    static_assert(!GA || (ACT == 2 && HL && !DROP && sizeof(YT) == 2), "the in-pass gA contraction: GELU' pass of the hi + lo kernels");
+    static_assert(!GA || (ACT == 2 && HL && RT == 2 && !DROP && sizeof(YT) == 2), "the in-pass gA contraction: GELU' pass of the hi + lo kernels, r <= 16");
     static_assert(!Q8 || ACT != 0, "the fp8 image is the one of the activation-fused passes");
-    static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
+    static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: RT / 2 rank tiles, each as [hi 4 | lo 4] per 4 rank indices");
+    constexpr int RH = HL ? RT / 2 : 1;         // hi + lo: rank tiles (r <= 16: 1, r <= 32: 2)
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
     __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
     __shared__ uint4 atile_all[GA ? 4 : 1][GA ? 16 * 16 : 1];       // GA: act(h) of the wave's tile, bf16
@@ -633,15 +644,17 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) 
 
     // W2^T fragments (MFMA A-operand: i = output column, k = rank index), kept for the whole kernel
     uint2 wlo[8], whi[8];
+    uint4 wq2[HL && RT == 4 ? 8 : 1];           // r <= 32: the second rank tile's (hi quad | lo quad)
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
         const int col = c0 + ct * 16 + n;
         const bool ok = col < N;
         wlo[ct] = whi[ct] = make_uint2(0u, 0u);
-        if (HL) {       // interleaved image: this lane's hi and lo quads are adjacent
+        if (HL) {       // interleaved image: this lane's hi and lo quads are adjacent; rank tile tt at entries tt * 32 ..
             const uint4 w4 = ok ? *reinterpret_cast<const uint4*>(W2t + (long long)col * RP + g * 8) : make_uint4(0u, 0u, 0u, 0u);
             wlo[ct] = make_uint2(w4.x, w4.y);
             whi[ct] = make_uint2(w4.z, w4.w);
+            if (RT == 4) wq2[ct] = ok ? *reinterpret_cast<const uint4*>(W2t + (long long)col * RP + 32 + g * 8) : make_uint4(0u, 0u, 0u, 0u);
         } else {
             wlo[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + g * 4) : make_uint2(0u, 0u);
             if (RT == 2)
@@ -655,11 +668,13 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) 
     const int col = c0 + (lane & 15) * 8;
 
     // T fragment of a tile (MFMA B-operand: k = rank index, n = activation row); T has Mp >= 16*ntiles rows
+    uint4 tq2n = make_uint4(0u, 0u, 0u, 0u), tq2 = tq2n;        // r <= 32: the second rank tile's (t_hi | t_lo) quad: next / current tile
     auto load_t = [&](long long t, uint2& lo, uint2& hi) {
-        if (HL) {       // (t_hi, t_lo) of this lane's 4 rank indices: one 16-byte load (store_t4_hl's layout)
+        if (HL) {       // (t_hi, t_lo) of this lane's 4 rank indices: one 16-byte load per rank tile (store_t4_hl's layout)
             const uint4 t4 = *reinterpret_cast<const uint4*>(T + (t * 16 + n) * RP + g * 8);
             lo = make_uint2(t4.x, t4.y);
             hi = make_uint2(t4.z, t4.w);
+            if (RT == 4) tq2n = *reinterpret_cast<const uint4*>(T + (t * 16 + n) * RP + 32 + g * 8);
             return;
         }
         lo = *reinterpret_cast<const uint2*>(T + (t * 16 + n) * RP + g * 4);
@@ -685,6 +700,12 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) 
                 const uint4 tc = make_uint4(thi.x, thi.y, 0u, 0u);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, tb), d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, tc), d, 0, 0, 0);
+                if (RT == 4) {      // rank indices 16..31: the same two products on the second tile's quads
+                    const uint4 tb2 = make_uint4(tq2.x, tq2.y, tq2.x, tq2.y);
+                    const uint4 tc2 = make_uint4(tq2.z, tq2.w, 0u, 0u);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq2[ct]), __builtin_bit_cast(bf16x8, tb2), d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq2[ct]), __builtin_bit_cast(bf16x8, tc2), d, 0, 0, 0);
+                }
             } else {
                 const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
                 const uint4 tb = make_uint4(tlo.x, tlo.y, thi.x, thi.y);
@@ -743,6 +764,7 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) 
             if (ACT == 2) hcur = hnxt;
             tlo = nlo;
             thi = nhi;
+            tq2 = tq2n;
             gfc = gfn;
             const long long tn = t + 4 < t_fast_end ? t + 4 : t;   // last iteration re-reads its own tile (L2 hit)
             load_t(tn, nlo, nhi);
@@ -760,6 +782,7 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) 
         YTile<YT> cur, hcur;
         uint2 tlo, thi;
         load_t(t, tlo, thi);
+        tq2 = tq2n;
         cur.template load<false>(Y, ldy, t * 16, col, lane, M, N);
         if (ACT == 2) hcur.template load<false, true>(AUX, ldaux, t * 16, col, lane, M, N);
         delta_to_slab(tlo, thi);
@@ -806,8 +829,8 @@ template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false>
 __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
                                             long long M, long long Mp, int N, int rows_per_wg, DropKey dk, int xcd_order) {
-    static_assert(!HL || RT == 2, "hi + lo operands are laid out as a rank-32 image");
-    constexpr int RTA = HL ? 1 : RT;            // rank tiles of the result
+    static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: fragment blocks [hi tiles | lo tiles] per step");
+    constexpr int RTA = HL ? RT / 2 : RT;       // rank tiles of the result
     constexpr int RP = RTA * 16, CW = 128, CPR = 16;
     __shared__ uint4 xs[4][32 * CPR];      // 32 rows x 256 B per wave; reused as the reduction buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -893,8 +916,8 @@ __global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long 
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
                 // D[i = rank idx][n = column] += sum_m T[m][i] * X[m][col]
-                acc[HL ? 0 : rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[rt]), xf,
-                                                                              acc[HL ? 0 : rt][ct], 0, 0, 0);
+                acc[rt % RTA][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[rt]), xf,
+                                                                           acc[rt % RTA][ct], 0, 0, 0);    // HL: hi and lo block of a tile -> one accumulator
         }
         wave_sync();
     };
@@ -1104,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP
     f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < nchunks; ++c)
         s4 += __builtin_bit_cast(f32x4, ldg16(GTP + ((long long)c * Mp + m) * 16 + r0));
-    if (HL) store_t4_hl(T, TTf, m, r0, s4);
+    if (HL) store_t4_hl<1>(T, TTf, m, 0, r0, s4);
     else store_t4<1>(T, TTf, m, 0, r0, pack2(s4[0], s4[1]), pack2(s4[2], s4[3]));
 }
 
@@ -1168,9 +1191,10 @@ struct Geo {
 };
 inline Geo geo_of(int rank, int dtype) {
     Geo g;
-    g.hl = dtype != SAM3_LORA_F32 && rank <= 16 && !env_flag("SAM3_LORA_SINGLE_ROUND");
+    // hi + lo for every rank group (<= 32 rank indices); SAM3_LORA_HL_MAX_RANK=16 restores round 3's single-rounded 17..32
+    g.hl = dtype != SAM3_LORA_F32 && rank <= (int)env_int("SAM3_LORA_HL_MAX_RANK", 32) && !env_flag("SAM3_LORA_SINGLE_ROUND");
     g.RG = rpad(rank);
-    g.RP = g.hl ? 32 : g.RG;
+    g.RP = g.hl ? 2 * g.RG : g.RG;
     g.RT = g.RP / 16;
     return g;
 }
@@ -1234,7 +1258,7 @@ int check_q8(const Q8Out* q8, int width, int rank, int dtype, int act) {
     if (q8->fmt != SAM3_FP8_E4M3 && q8->fmt != SAM3_FP8_E5M2) return fail(SAM3_LORA_EINVAL, "fp8 output: unknown format %d", q8->fmt);
     if (q8->ld < width || (q8->ld & 7) || ((uintptr_t)q8->q & 7)) return fail(SAM3_LORA_EINVAL, "fp8 output: row pitch / base must be 8-byte aligned");
     if (act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "fp8 output rides on the activation-fused passes only");
-    if (!geo_of(rank, dtype).hl || rank > 32)
+    if (!geo_of(rank, dtype).hl || rank > 16)
         return fail(SAM3_LORA_ENOTSUP, "fp8 output needs bf16 activations and rank <= 16 (hi + lo kernels)");
     return 0;
 }
@@ -1272,7 +1296,8 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
                   {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
                   {"SAM3_LORA_FUSED_ORDER", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0},
-                  {"SAM3_LORA_EXACT_GROUPS", false, 0}};
+                  {"SAM3_LORA_HL_MAX_RANK", false, 0},
+                  {"SAM3_LORA_T1_BK", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1375,13 +1400,7 @@ void launch_pack(const PackJob& a, const PackJob& b, hipStream_t st) {
 // Ranks above 32 run as consecutive groups of <= 32 rank indices (the kernels hold one or two 16-wide rank tiles):
 // y += s (x A_g) B_g per group, and the four gradient products per group -- A_c / B_c slices are addressed through
 // the strides of the full tensors, so no copy is made.
-// SAM3_LORA_EXACT_GROUPS=1 (bf16 activations): groups of 16 instead of 32, so that EVERY rank runs on the hi + lo kernels -- one-rounding
-// outputs and 3e-5 gradients also for the reference's default rank 32 (configs/full_lora_config.yaml:12), at the price of one more pass
-// over the activations per 16 rank indices (r = 32: the adapter path twice; measured in DESIGN section 8).  Off by default: the
-// single-rounded rank-32 group is 1.7 % behind the r = 16 step and its error is invisible end to end (tools/bf16_parity_probe.py).
-inline int group_size(int rank, int dtype) {
-    return (dtype != SAM3_LORA_F32 && rank > 16 && env_flag("SAM3_LORA_EXACT_GROUPS")) ? 16 : 32;
-}
+inline int group_size(int /*rank*/, int /*dtype*/) { return 32; }
 inline int n_groups(int rank, int dtype) { const int gs = group_size(rank, dtype); return (rank + gs - 1) / gs; }
 inline int group_rank(int rank, int g, int dtype) {
     const int gs = group_size(rank, dtype);
@@ -1421,7 +1440,7 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
     dim3 grid((unsigned)(Mp / 64));
     const int nk = (K + 127) / 128;
     // small M: split K over workgroups so that ~640 of them exist (fp32 partials in `part`, fixed-order sum after)
-    if ((RT == 1 || hl) && part && K >= 2048 && grid.x < 512 && !env_flag("SAM3_LORA_T1_NO_SPLIT")) {
+    if ((RT == 1 || (hl && RT == 2)) && part && K >= 2048 && grid.x < 512 && !env_flag("SAM3_LORA_T1_NO_SPLIT")) {
         int ks = (int)((640 + grid.x - 1) / grid.x);
         ks = ks > 8 ? 8 : ks;
         const int kc_per = (nk + ks - 1) / ks;
@@ -1447,7 +1466,7 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
     // Workgroups hold 40-48 KB of LDS, so up to 4 (r <= 16) fit a CU.  When the grid needs more than one residency
     // round, a nearly empty last round costs a whole round: cap the residency (dynamic-LDS padding) at the value whose
     // last round is fullest.  Measured at M = 82,944 (1296 workgroups): 163 us uncapped, 138-141 us capped.
-    const int lds_static = 32768 + 2 * RT * 8192 / 2;
+    const int lds_static = 32768 + 2 * RT * 8192 / 2;       // xs 32 KB + ws 2 x RT x 4 KB
     const int omax = 163840 / lds_static > 4 ? 4 : 163840 / lds_static;
     unsigned pad = 0;
     if ((long long)grid.x > 256LL * omax && K >= 2048) {      // short sweeps (K = 1024) measured better uncapped
@@ -1464,6 +1483,16 @@ void launch_t1(const void* X, long long ldx, const bf16_t* W1, bf16_t* T, bf16_t
     pad = (unsigned)env_int("SAM3_LORA_T1_LDS_PAD", pad);
     if (RT == 1)
         hipLaunchKernelGGL((k_t1<XT, 1, 128>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+    else if (hl && RT == 4) {   // r <= 32 as hi + lo: four rank tiles [hi 0, hi 1 | lo 0, lo 1]
+        // 128-column chunks need 64 KB of LDS here (the W1 tile is as large as the x tile): two workgroups per CU, too few bytes in
+        // flight.  64-column chunks (32 KB, five workgroups): 94.9 / 27.7 us at K = 4736 / 1024 against 119.4 / 32.8 us
+        // (M = 41,472, same box, profiles/r04t_adapter_rank32_bk*.json; single-rounded rank 32: 83.3 / 23.7).  SAM3_LORA_T1_BK=128
+        // selects the wide chunks.
+        if (env_int("SAM3_LORA_T1_BK", 64) == 64)
+            hipLaunchKernelGGL((k_t1<XT, 4, 64, false, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+        else
+            hipLaunchKernelGGL((k_t1<XT, 4, 128, false, true>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
+    }
     else if (hl)
         hipLaunchKernelGGL((k_t1<XT, 2, 128, false, true>), grid, dim3(256), pad, st, (const XT*)X, ldx, W1, T, TT, M, Mp, K, dk);
     else
@@ -1531,7 +1560,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
         else if (act == 2) { if (dk.thr) T2_LAUNCH(RTV, true, 2, HV); else T2_LAUNCH(RTV, false, 2, HV); } \
         else { if (dk.thr) T2_LAUNCH(RTV, true, 0, HV); else T2_LAUNCH(RTV, false, 0, HV); }    \
     } while (0)
-    if (RT == 1) T2_RT(1, false); else if (hl) T2_RT(2, true); else T2_RT(2, false);
+    if (RT == 1) T2_RT(1, false); else if (hl && RT == 4) T2_RT(4, true); else if (hl) T2_RT(2, true); else T2_RT(2, false);
 #undef T2_RT
 #undef T2_LAUNCH
 }
@@ -1548,6 +1577,8 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
          else hipLaunchKernelGGL((k_t3<XT, RTV, GV, false, HV>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk, xcd); } while (0)
     if (RT == 1) {
         if (gather) T3_LAUNCH(1, true, false); else T3_LAUNCH(1, false, false);
+    } else if (hl && RT == 4) {
+        if (gather) T3_LAUNCH(4, true, true); else T3_LAUNCH(4, false, true);
     } else if (hl) {
         if (gather) T3_LAUNCH(2, true, true); else T3_LAUNCH(2, false, true);
     } else {
@@ -1969,7 +2000,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
             if (gB_g && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, hl, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         }
         // GELU'-fused backward of the hi + lo kernels: gA from act(h) INSIDE the pass over gx (k_t2<GA>), no second read of x
-        ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && !dk.thr && (x == nullptr || ga_in_t2_enabled());
+        ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && RG == 16 && !dk.thr && (x == nullptr || ga_in_t2_enabled());
         // (x == NULL with the in-pass form switched off by a partial debug stage mask: nothing can read the input -- skip, the
         // header says a partial mask leaves the outputs meaningless)
         if (gA_g && s3a && !ga_in_pass && x)
@@ -2124,7 +2155,7 @@ int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, 
 size_t sam3_lora_linear_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {
     if (check_common(M, in_features, out_features, rank, 0, dtype)) return 0;
     if (!sam3_lora_linear_fwd_supported(in_features, out_features, rank, dtype)) return 0;
-    return fwd_ws(M, in_features, out_features, rank, dtype).total + al256((size_t)out_features * 64 * 2);
+    return fwd_ws(M, in_features, out_features, rank, dtype).total + al256((size_t)out_features * 128 * 2);
 }
 
 int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
@@ -2152,7 +2183,7 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
     if (256LL * ldx * 2 >= (1LL << 31) || 256LL * ldw * 2 >= (1LL << 31) || 256LL * ldy * 2 >= (1LL << 31) || (act && 256LL * ldact * 2 >= (1LL << 31)))
         return fail(SAM3_LORA_ENOTSUP, "fused linear: row pitches beyond 4 M elements are not addressable by the tile descriptors");
     const FwdWs w = fwd_ws(M, in_features, out_features, rank, dtype);
-    const size_t need = w.total + al256((size_t)out_features * 64 * 2);
+    const size_t need = w.total + al256((size_t)out_features * 128 * 2);
     if (!workspace || workspace_bytes < need)
         return fail(SAM3_LORA_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     if (((uintptr_t)workspace & 255)) return fail(SAM3_LORA_EINVAL, "workspace must be 256-byte aligned");
@@ -2180,7 +2211,7 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
                           gq.RG == 16 ? (float*)(ws + w.t1p) : nullptr);
     if (stage_on(SAM3_LORA_STAGE_PACK)) {
         ProfScope ps(SAM3_LORA_STAGE_PACK, out_features, st);
-        const int groups = gq.hl ? 4 : 8;
+        const int groups = gq.hl ? RP / 8 : 8;
         hipLaunchKernelGGL(fl::k_wext, dim3((unsigned)((out_features * groups + 255) / 256)), dim3(256), 0, st, (const bf16_t*)W2t, Wext,
                            out_features, RP, gq.hl ? 1 : 0, scaling * inv_keep);
     }
@@ -2209,9 +2240,9 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
         hipLaunchKernelGGL((fl::k_fused_linear<fl::CFG_, ACT_, TROW_>), dim3((unsigned)grid), dim3(fl::TileGeo<fl::CFG_>::NTHREADS), 0, st, fa)
 #define SAM3_FL_CFG(ACT_, TROW_) do { if (pair) SAM3_FL_LAUNCH(CfgPair, ACT_, TROW_); else SAM3_FL_LAUNCH(CfgBig, ACT_, TROW_); } while (0)
         if (act) {
-            if (trow == 64) SAM3_FL_CFG(1, 64); else SAM3_FL_CFG(1, 32);
+            if (trow == 128) SAM3_FL_CFG(1, 128); else if (trow == 64) SAM3_FL_CFG(1, 64); else SAM3_FL_CFG(1, 32);
         } else {
-            if (trow == 64) SAM3_FL_CFG(0, 64); else SAM3_FL_CFG(0, 32);
+            if (trow == 128) SAM3_FL_CFG(0, 128); else if (trow == 64) SAM3_FL_CFG(0, 64); else SAM3_FL_CFG(0, 32);
         }
 #undef SAM3_FL_CFG
 #undef SAM3_FL_LAUNCH

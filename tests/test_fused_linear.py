@@ -37,7 +37,7 @@ def _reload():
 def _knobs_back():
     yield
     if torch.cuda.is_available():
-        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_SINGLE_ROUND"):
+        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_HL_MAX_RANK"):
             os.environ.pop(k, None)
         _reload()
         Fn.set_fused_linear(None)
@@ -89,16 +89,26 @@ def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, lay
 
 
 @pytest.mark.parametrize("tile", ["0", "1"])
-def test_no_bias_and_rank_32_single_rounded_images(tile):
+def test_no_bias_rank_32_and_single_rounded_images(tile):
+    """Ranks 17..32: the rank-r term is 128 K slots (two more K steps) of hi + lo images -- one rounding, as r <= 16; with
+    SAM3_LORA_HL_MAX_RANK=16 / SAM3_LORA_SINGLE_ROUND=1 the plain [M][32] / [M][16] row images (1e-2)."""
     os.environ["SAM3_LORA_FUSED_TILE"] = tile
     _reload()
     M, fin, fout = 700, 128, 520
-    for rank, tol in ((32, 1e-2), (24, 1e-2)):
+    for rank in (32, 24, 17):
         x, W, _, A, B = _case(M, fin, fout, rank, 0, seed=rank, bias=False)
         want = O.lora_linear_forward(x, W, None, A, B, 2.0, 0, acc_dtype=np.float64)
-        y, _, _ = Fn.lora_linear_fwd_(_t(x, torch.bfloat16), _t(W, torch.bfloat16), None, _t(A), _t(B), 2.0, 0)
-        err = np.abs(y.float().cpu().numpy() - want).max() / np.abs(want).max()
-        assert err < tol, err
+        y, _, tT = Fn.lora_linear_fwd_(_t(x, torch.bfloat16), _t(W, torch.bfloat16), None, _t(A), _t(B), 2.0, 0, save_t=True)
+        _one_rounding(y.float().cpu().numpy(), want)
+        y2 = torch.zeros_like(y)
+        assert torch.equal(tT, Fn.lora_fwd_(_t(x, torch.bfloat16), _t(A), _t(B), y2, 2.0, 0, save_t=True))
+    os.environ["SAM3_LORA_HL_MAX_RANK"] = "16"
+    _reload()
+    x, W, _, A, B = _case(M, fin, fout, 32, 0, seed=32, bias=False)
+    want = O.lora_linear_forward(x, W, None, A, B, 2.0, 0, acc_dtype=np.float64)
+    y, _, _ = Fn.lora_linear_fwd_(_t(x, torch.bfloat16), _t(W, torch.bfloat16), None, _t(A), _t(B), 2.0, 0)
+    assert np.abs(y.float().cpu().numpy() - want).max() / np.abs(want).max() < 1e-2
+    os.environ.pop("SAM3_LORA_HL_MAX_RANK")
     # r <= 16 with the single-rounded images (SAM3_LORA_SINGLE_ROUND=1): the [M][16] row image of t
     os.environ["SAM3_LORA_SINGLE_ROUND"] = "1"
     _reload()
