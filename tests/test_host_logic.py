@@ -200,19 +200,20 @@ def test_linear_with_lora_exposes_linear_attrs():
 # ------------------------------------------------------------------ C-ABI ----------------
 def lib_has_packed_sizes():
     """sam3_lora_packed_bytes: four operand images per rank group of <= 32 (bf16, or fp32 for the exact path), each
-    256-byte aligned; 0 (with an error text) on bad shapes.  bf16 with r <= 16: hi + lo images, laid out as rank 32."""
+    256-byte aligned; 0 (with an error text) on bad shapes.  bf16: hi + lo images -- a group of <= 16 rank indices is laid out 32 wide,
+    one of 17..32 is laid out 64 wide."""
     lib = _ffi.load()
     n16 = lib.sam3_lora_packed_bytes(1024, 4736, 16, _ffi.DT_F32)          # fp32 images of a 16-wide rank tile
     assert n16 == 2 * 16 * (1024 + 4736) * 4 and n16 % 256 == 0
     n = lib.sam3_lora_packed_bytes(1024, 4736, 16, _ffi.DT_BF16)            # hi | lo: 32 bf16 columns
     assert n == 2 * 32 * (1024 + 4736) * 2 == n16 and lib.sam3_lora_packed_bytes(1024, 4736, 3, _ffi.DT_BF16) == n
     n32 = lib.sam3_lora_packed_bytes(1024, 4736, 32, _ffi.DT_BF16)
-    assert n32 == n and lib.sam3_lora_packed_bytes(1024, 4736, 32, _ffi.DT_F32) == 2 * n16
+    assert n32 == 2 * n and lib.sam3_lora_packed_bytes(1024, 4736, 17, _ffi.DT_BF16) == n32 and lib.sam3_lora_packed_bytes(1024, 4736, 32, _ffi.DT_F32) == 2 * n16
     # rank 33..64: two groups (32 + the rest); rank 80 = 32 + 32 + 16
     assert lib.sam3_lora_packed_bytes(1024, 4736, 64, _ffi.DT_BF16) == 2 * n32
     assert lib.sam3_lora_packed_bytes(1024, 4736, 40, _ffi.DT_BF16) == n32 + n
     assert lib.sam3_lora_packed_bytes(1024, 4736, 80, _ffi.DT_BF16) == 2 * n32 + n
-    assert lib.sam3_lora_saved_t_bytes(5184, 16, _ffi.DT_BF16) == 32 * 5184 * 2 == lib.sam3_lora_saved_t_bytes(5184, 32, _ffi.DT_BF16)
+    assert lib.sam3_lora_saved_t_bytes(5184, 16, _ffi.DT_BF16) == 32 * 5184 * 2 == lib.sam3_lora_saved_t_bytes(5184, 32, _ffi.DT_BF16) // 2
     assert lib.sam3_lora_packed_bytes(1024, 4736, _ffi.MAX_RANK + 1, _ffi.DT_BF16) == 0 and "rank" in _ffi.last_error()
     assert lib.sam3_lora_packed_bytes(1024, 4736, 0, _ffi.DT_BF16) == 0
     return True
@@ -259,8 +260,8 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     assert "multiples of 8" in _ffi.last_error()
     assert lib2.sam3_lora_saved_t_bytes(41472, 16, _ffi.DT_BF16) == 32 * 41472 * 2       # hi | lo
     assert lib2.sam3_lora_saved_t_bytes(41472, 16, _ffi.DT_F32) == 16 * 41472 * 4
-    assert lib2.sam3_lora_saved_t_bytes(100, 17, _ffi.DT_BF16) == 32 * 128 * 2
-    assert lib2.sam3_lora_saved_t_bytes(100, 64, _ffi.DT_BF16) == 2 * 32 * 128 * 2
+    assert lib2.sam3_lora_saved_t_bytes(100, 17, _ffi.DT_BF16) == 64 * 128 * 2
+    assert lib2.sam3_lora_saved_t_bytes(100, 64, _ffi.DT_BF16) == 2 * 64 * 128 * 2
     # workspaces are sized for one rank group: rank 64 needs what rank 32 needs
     assert (lib2.sam3_lora_bwd_workspace_bytes(41472, 1024, 4736, 64, 0)
             == lib2.sam3_lora_bwd_workspace_bytes(41472, 1024, 4736, 32, 0) > 0)
