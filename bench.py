@@ -929,20 +929,25 @@ def main():
             # BASELINE configs[4]'s mode on the same workload: frozen base GEMMs on the fp8 MFMA kernels
             loss_bf16 = full.last_loss.item()
             enable_fp8_frozen(True)
-            for _ in range(2):
-                full.step()
-            f_steps = max(3, min(args.steps, 6))
-            dtf = timed(full.step, f_steps)
-            if rank == 0:
-                out["fp8_frozen_w"] = {
-                    "value": round(world * args.batch * f_steps / dtf, 2), "unit": "images/s",
-                    "ms_per_step": round(dtf / f_steps * 1e3, 3), "steps": f_steps,
-                    "loss": round(full.last_loss.item(), 4), "loss_bf16_build": round(loss_bf16, 4),
-                    "finite": bool(torch.isfinite(full.last_loss).item()),
-                    "what": "the same whole training step with the frozen Linears' GEMMs in fp8 (weights e4m3 per-tensor scale, "
-                            "activations e4m3 / gradients e5m2 with delayed scaling -- written by the producing kernels (LayerNorm, the "
-                            "GELU / GELU' adapter passes) where there is one, by the HIP quantiser otherwise; hipBLASLt fp8 MFMA "
-                            "through torch._scaled_mm); LoRA branch bf16 / fp32 as before"}
+            try:
+                for _ in range(2):
+                    full.step()
+                f_steps = max(3, min(args.steps, 6))
+                dtf = timed(full.step, f_steps)
+                if rank == 0:
+                    out["fp8_frozen_w"] = {
+                        "value": round(world * args.batch * f_steps / dtf, 2), "unit": "images/s",
+                        "ms_per_step": round(dtf / f_steps * 1e3, 3), "steps": f_steps,
+                        "loss": round(full.last_loss.item(), 4), "loss_bf16_build": round(loss_bf16, 4),
+                        "finite": bool(torch.isfinite(full.last_loss).item()),
+                        "what": "the same whole training step with the frozen Linears' GEMMs in fp8 (weights e4m3 per-tensor scale, "
+                                "activations e4m3 / gradients e5m2 with delayed scaling -- written by the producing kernels (LayerNorm, the "
+                                "GELU / GELU' adapter passes) where there is one, by the HIP quantiser otherwise; hipBLASLt fp8 MFMA "
+                                "through torch._scaled_mm); LoRA branch bf16 / fp32 as before"}
+            except (ValueError, FloatingPointError) as e:      # e.g. the Hungarian solver refusing a non-finite cost matrix
+                if world > 1:
+                    raise
+                out["fp8_frozen_w"] = {"error": str(e)[:200], "finite": False, "loss_bf16_build": round(loss_bf16, 4)}
             enable_fp8_frozen(False)
         del full
         torch.cuda.empty_cache()

@@ -612,7 +612,7 @@ struct GaEmit {
     float* part;            // [row blocks][16][N]
 };
 template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false>
-__global__ __launch_bounds__(256, (HL && !DROP) ? (RT == 4 ? 2 : (ACT == 2 ? (GA ? 2 : 3) : 4)) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
+__global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
                                             ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga) {
@@ -623,6 +623,10 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (RT == 4 ? 2 : (ACT == 2 ? (GA
     constexpr int RP = RT * 16, CW = 128, LDW = CW + 4;
     __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
     __shared__ uint4 atile_all[GA ? 4 : 1][GA ? 16 * 16 : 1];       // GA: act(h) of the wave's tile, bf16
+    // r <= 32 (two rank tiles): the W fragments -- the same for the four waves -- live in LDS (16 KB), not in 64 registers per lane:
+    // three workgroups per CU instead of two
+    constexpr bool WSH = HL && RT == 4;
+    __shared__ uint4 wsh[WSH ? 2 : 1][WSH ? 8 : 1][WSH ? 64 : 1];
     if (blockIdx.y < (unsigned)ride.rows) {     // riding reduction blocks (scheduled first; see reduce_block)
         const long long e = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         if (e < 2LL * ride.nblk)
@@ -644,17 +648,25 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (RT == 4 ? 2 : (ACT == 2 ? (GA
 
     // W2^T fragments (MFMA A-operand: i = output column, k = rank index), kept for the whole kernel
     uint2 wlo[8], whi[8];
-    uint4 wq2[HL && RT == 4 ? 8 : 1];           // r <= 32: the second rank tile's (hi quad | lo quad)
+    if (WSH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * 256 + tid, tt = e >> 9, ct = (e >> 6) & 7, l = e & 63;
+            const int col = c0 + ct * 16 + (l & 15);
+            wsh[tt][ct][l] = col < N ? *reinterpret_cast<const uint4*>(W2t + (long long)col * RP + tt * 32 + (l >> 4) * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
         const int col = c0 + ct * 16 + n;
         const bool ok = col < N;
         wlo[ct] = whi[ct] = make_uint2(0u, 0u);
-        if (HL) {       // interleaved image: this lane's hi and lo quads are adjacent; rank tile tt at entries tt * 32 ..
+        if (WSH) {
+        } else if (HL) {       // interleaved image: this lane's hi and lo quads are adjacent; rank tile tt at entries tt * 32 ..
             const uint4 w4 = ok ? *reinterpret_cast<const uint4*>(W2t + (long long)col * RP + g * 8) : make_uint4(0u, 0u, 0u, 0u);
             wlo[ct] = make_uint2(w4.x, w4.y);
             whi[ct] = make_uint2(w4.z, w4.w);
-            if (RT == 4) wq2[ct] = ok ? *reinterpret_cast<const uint4*>(W2t + (long long)col * RP + 32 + g * 8) : make_uint4(0u, 0u, 0u, 0u);
         } else {
             wlo[ct] = ok ? *reinterpret_cast<const uint2*>(W2t + (long long)col * RP + g * 4) : make_uint2(0u, 0u);
             if (RT == 2)
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (RT == 4 ? 2 : (ACT == 2 ? (GA
                 // the v_mfma_f32_16x16x32_bf16 whose result it accumulates onto, without wait states, and MI355X then returns wrong,
                 // run-to-run varying sums (reproduced stand-alone: tools/probes/mfma_chain_probe.hip, profiles/r03b_mfma_k16_after_k32.txt;
                 // 16 s_nop states by hand, or an unrelated MFMA in between, make it exact).  One MFMA shape per accumulator chain.
-                const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
+                const uint4 wa = WSH ? wsh[0][ct][lane] : make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
                 const uint4 tb = make_uint4(tlo.x, tlo.y, tlo.x, tlo.y);
                 const uint4 tc = make_uint4(thi.x, thi.y, 0u, 0u);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, tb), d, 0, 0, 0);
@@ -703,8 +715,9 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (RT == 4 ? 2 : (ACT == 2 ? (GA
                 if (RT == 4) {      // rank indices 16..31: the same two products on the second tile's quads
                     const uint4 tb2 = make_uint4(tq2.x, tq2.y, tq2.x, tq2.y);
                     const uint4 tc2 = make_uint4(tq2.z, tq2.w, 0u, 0u);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq2[ct]), __builtin_bit_cast(bf16x8, tb2), d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq2[ct]), __builtin_bit_cast(bf16x8, tc2), d, 0, 0, 0);
+                    const uint4 w2 = wsh[WSH ? 1 : 0][ct][lane];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2), __builtin_bit_cast(bf16x8, tb2), d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2), __builtin_bit_cast(bf16x8, tc2), d, 0, 0, 0);
                 }
             } else {
                 const uint4 wa = make_uint4(wlo[ct].x, wlo[ct].y, whi[ct].x, whi[ct].y);
@@ -826,7 +839,7 @@ __global__ __launch_bounds__(256, (HL && !DROP) ? (RT == 4 ? 2 : (ACT == 2 ? (GA
 // HL (RT == 2): the two fragment blocks of a step are the hi and lo parts of the same 16 rank indices and accumulate
 // into ONE rank tile (RTA = 1): G = t_hi^T X + t_lo^T X.
 template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false>
-__global__ __launch_bounds__(256) void k_t3(const XT* __restrict__ X, long long ldx,
+__global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
                                             long long M, long long Mp, int N, int rows_per_wg, DropKey dk, int xcd_order) {
     static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: fragment blocks [hi tiles | lo tiles] per step");

@@ -517,7 +517,7 @@ def test_one_pass_backward_matches_two_pass(shape, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
-@pytest.mark.parametrize("rank,drop", [(16, 0.0), (16, 0.2), (24, 0.0)])
+@pytest.mark.parametrize("rank,drop", [(16, 0.0), (16, 0.2), (24, 0.0), (24, 0.2), (32, 0.1)])
 def test_activation_fused_entry_points(dtype, rank, drop):
     """sam3_lora_fwd_act / sam3_lora_bwd_act: the update itself is bit-identical to the plain entry points; the extra
     output is GELU of the (rounded) updated tensor, the backward's gx is the plain gx times GELU'(pre-activation) --
