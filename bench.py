@@ -1046,7 +1046,7 @@ def main():
         except Exception as e:
             out["fused_linear_site"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         out["roofline"]["operands"] = ("hi + lo bf16 pairs for A, B, t, gt (fp32 arithmetic on the bf16 activations; "
-                                       "include/sam3_lora_amd.h)" if w.rank <= 16 and e_ == 2 else "single-rounded bf16 / fp32")
+                                       "include/sam3_lora_amd.h)" if e_ == 2 and os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") in ("", "0") and w.rank <= int(os.environ.get("SAM3_LORA_HL_MAX_RANK", "32") or 32) else "single-rounded bf16 / fp32")
     # the same kernels with single-rounded operands (round 2's arithmetic: SAM3_LORA_SINGLE_ROUND=1) -- what the hi + lo form costs
     if not args.no_roofline and args.rank <= 16 and act_dtype == torch.bfloat16 and os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") in ("", "0"):
         from sam3_lora_amd import _ffi

@@ -3,10 +3,10 @@ GPU parity of SURVEY 8(f)-1, the adapter INSIDE the frozen GEMM (``sam3_lora_lin
 
     y = x W^T + b + s (drop(x) A_c) B_c           a = GELU(y)                lora_layers.py:87-91 + vitdet.py:585-590
 
-against the fp64 numpy oracle (oracle/lora_oracle.py: ``lora_linear_forward``) on the same bf16 inputs.  Bar (bf16, r <= 16,
+against the fp64 numpy oracle (oracle/lora_oracle.py: ``lora_linear_forward``) on the same bf16 inputs.  Bar (bf16, r <= 32,
 hi + lo images): every output element within ONE bf16 rounding of the fp64 value (``_one_rounding``) -- tighter than the
-GEMM-then-adapter pair, which rounds the frozen GEMM's output before the branch is added; 16 < r <= 32 (single-rounded
-images): 1e-2 of max.  The saved t^T is bit-identical to ``sam3_lora_fwd``'s, so the backward is unchanged.
+GEMM-then-adapter pair, which rounds the frozen GEMM's output before the branch is added; single-rounded images
+(SAM3_LORA_SINGLE_ROUND=1 / SAM3_LORA_HL_MAX_RANK=16 for 16 < r): 1e-2 of max.  The saved t^T is bit-identical to ``sam3_lora_fwd``'s, so the backward is unchanged.
 """
 import os
 

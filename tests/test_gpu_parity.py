@@ -6,12 +6,14 @@ GPU parity (run with ``-m gpu`` on an MI355X): the HIP path, called through the 
     GPU plus size-independent properties (linearity, bitwise run-to-run determinism).
 
 Tolerances (floating point; stated per check):
-  bf16 activations, r <= 16 (the benchmark's layout): A, B and the rank-r intermediates t / gt travel as hi + lo bf16 pairs,
+  bf16 activations, rank groups of <= 32 (round 4; r <= 16 is the benchmark's layout): A, B and the rank-r intermediates t / gt travel
+  as hi + lo bf16 pairs,
   so the branch is fp32 arithmetic on the caller's bf16 data.  Against the fp64 oracle ON THE SAME bf16 INPUTS the fp32
   weight gradients agree to 3e-5 of max |.| and every bf16 output element to ONE rounding of the output (2^-8 relative,
   ``_one_rounding``) -- tests ``test_hi_lo_*``; the older, looser checks below (1e-2 against the reference's fp32 outputs
   from fp32 inputs, 6e-3 against the single-rounding model) bound the effect of rounding x / gy themselves.
-  bf16 activations, 16 < r <= 32 per group: A, B, t, gt rounded to bf16 once each: 6e-3 of max |.| against a model of exactly
+  bf16 activations, single-rounded operands (SAM3_LORA_SINGLE_ROUND=1, or SAM3_LORA_HL_MAX_RANK=16 for 16 < r <= 32): A, B, t, gt
+  rounded to bf16 once each: 6e-3 of max |.| against a model of exactly
   those roundings (``adapter_delta_bf16_model``), 1e-2 against the fp32 reference.
   fp32 activations: exact fp32 products and accumulation (v_mfma_f32_16x16x4_f32), fp32 intermediates: 1e-5 of the
   tensor's max magnitude against the reference's own fp32 outputs and against the fp64 oracle.
