@@ -1,6 +1,7 @@
 """Build the in-tree HIP shared library (gfx950 only).  hipcc cross-compiles without a GPU."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -26,9 +27,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SRCS + [os.path.join(INCLUDE, "sam3_lora_amd.h"), os.path.join(INCLUDE, "sam3_vit_amd.h"),
-                   os.path.join(INCLUDE, "sam3_loss_amd.h"), os.path.join(INCLUDE, "sam3_fp8_amd.h"), os.path.join(INCLUDE, "sam3_seg_amd.h"),
-                   os.path.join(PKG_DIR, "csrc", "lora_f32_kernels.inc")]
+    # every source the library is compiled from: the .hip units, the .inc files they include, the public headers
+    deps = SRCS + sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.inc"))) + sorted(glob.glob(os.path.join(INCLUDE, "*.h")))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

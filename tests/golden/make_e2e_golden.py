@@ -294,7 +294,7 @@ def main():
                 total.backward()
                 return {n: (m.lora_A.grad.float().clone(), m.lora_B.grad.float().clone()) for n, m in model.named_modules()
                         if isinstance(m, ref_root.LoRALayer) and m.lora_A.grad is not None
-                        and (which == "tiny" or any(w in n for w in D.WIDE_GRAD_MODULES))}
+                        and (which == "tiny" or full or any(w in n for w in D.WIDE_GRAD_MODULES))}
             g32 = grads(contextlib.nullcontext())
             g16 = grads(torch.autocast("cpu", dtype=torch.bfloat16))
             per = {n: max(relmax(g16[n][0], g32[n][0]), relmax(g16[n][1], g32[n][1])) for n in g32 if n in g16}
