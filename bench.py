@@ -247,7 +247,7 @@ def insitu_kernels(w, steps=2):
     one_pass = r <= 16 and os.environ.get("SAM3_LORA_TWO_PASS_GY", "0") in ("", "0")
     names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2",
              _ffi.STAGE_T3_GB: "k_t3+gt" if one_pass else "k_t3", _ffi.STAGE_T3_GA: "k_t3",
-             _ffi.STAGE_REDUCE: "k_reduce", 64: "k_gt_reduce"}
+             _ffi.STAGE_REDUCE: "k_reduce", 64: "k_gt_reduce", _ffi.STAGE_T3W: "k_t3w", _ffi.STAGE_XGX: "k_xgx"}
 
     def alg_bytes(kernel, dim):
         if kernel == "k_t2":      # read + write Y[M,N]; read T[M,RP], W2t[N,RP]
@@ -258,6 +258,10 @@ def insitu_kernels(w, steps=2):
             return e * M * dim + e * RP * M
         if kernel == "k_t3+gt":   # one pass over gy: gB partials and gt (T, TT written by k_gt_reduce)
             return e * M * dim + e * RP * M
+        if kernel == "k_t3w":     # backward version 2 over gy: gB partials and gt (partials, or its images) from one read
+            return e * M * dim + e * RP * M
+        if kernel == "k_xgx":     # backward version 2 over x and gx: read x, read + write gx; A_c image (gt arrives as partials: overhead)
+            return 3 * e * M * dim + e * dim * RP
         if kernel == "k_gt_reduce":   # pure overhead of the one-pass form: fp32 gt partials back in, T and TT out
             return -(-dim // 128) * M * 64 + 2 * e * M * RP
         if kernel == "k_reduce":  # read-modify-write fp32 gA, gB

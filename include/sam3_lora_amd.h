@@ -243,6 +243,8 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
 #define SAM3_LORA_STAGE_REDUCE 32u  /* fixed-order sum of the partials into gA/gB: rides on the backward's k_t2 launch (bf16, gx wanted), k_reduce otherwise */
 #define SAM3_LORA_STAGE_GT_REDUCE 64u /* k_gt_reduce : chunk sum of the gt partials k_t3 emitted (r <= 16)  */
 #define SAM3_LORA_STAGE_FUSED 128u  /* k_fused_linear : frozen GEMM + rank-r K step + bias + activation (sam3_lora_linear_fwd) */
+#define SAM3_LORA_STAGE_T3W 256u    /* k_t3w    : backward version 2 over gy -- gB partials + gt (partials, or its images when out <= 1024) */
+#define SAM3_LORA_STAGE_XGX 512u    /* k_xgx    : backward version 2 over x and gx -- gx += s.gt.A_c^T and the gA partials in one pass */
 #define SAM3_LORA_STAGE_ALL 0xffffffffu
 unsigned sam3_lora_debug_set_stages(unsigned mask);
 

@@ -45,7 +45,7 @@ FP8_AMAX_SLOTS = 64            # SAM3_FP8_AMAX_SLOTS
 FP8_AMAX_STRIDE = 32           # SAM3_FP8_AMAX_STRIDE: floats between two slots (one 128-byte line per slot)
 FP8_AMAX_FLOATS = FP8_AMAX_SLOTS * FP8_AMAX_STRIDE
 STAGE_PACK, STAGE_T1, STAGE_T2, STAGE_T3_GB, STAGE_T3_GA, STAGE_REDUCE, STAGE_ALL = 1, 2, 4, 8, 16, 32, 0xFFFFFFFF
-STAGE_GT_REDUCE, STAGE_FUSED = 64, 128
+STAGE_GT_REDUCE, STAGE_FUSED, STAGE_T3W, STAGE_XGX = 64, 128, 256, 512
 
 _lib = None
 _lock = threading.Lock()

@@ -40,6 +40,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "sam3_lora_amd.h"
 #include "fp8_common.inc"
@@ -867,16 +868,20 @@ __global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(co
         uint4 t[RT];        // t^T fragment of the step (issued BEFORE the x loads: it must land first)
         Raw8<XT> x[8];
     };
+    // row indices and the row pitch as 32-bit values (check_common / check_act bound M and ld* below 2^31): one v_min_u32 + one
+    // v_mad_u64_u32 per load instead of a 64-bit compare / select / multiply chain (120 VALU instructions per step before)
+    const unsigned m_last = (unsigned)(M - 1), ldx32 = (unsigned)ldx, wb32 = (unsigned)w_begin;
+    const XT* const Xc = X + colc;
+    const bf16_t* const TTl = TTf + lane * 8;
     auto gload = [&](int s0, Regs& r_) {
-        const int s = s0 < nst ? s0 : nst - 1;
-        const long long mb = w_begin + (long long)s * 32;
+        const unsigned mb = wb32 + (unsigned)(s0 < nst ? s0 : nst - 1) * 32u;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
-            r_.t[rt] = *reinterpret_cast<const uint4*>(TTf + (((mb >> 5) * RT + rt) * 64 + lane) * 8);
+            r_.t[rt] = *reinterpret_cast<const uint4*>(TTl + (unsigned long long)((mb >> 5) * RT + rt) * 512u);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const long long m = mb + lr + 4 * q;
-            r_.x[q].load(X + (m < M ? m : M - 1) * ldx + colc);
+            const unsigned m = min(mb + (unsigned)(lr + 4 * q), m_last);
+            r_.x[q].load(Xc + (unsigned long long)m * ldx32);
         }
     };
     f32x4 acc[RTA][8];
@@ -940,8 +945,10 @@ __global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(co
         gload(0, rA);
         for (int s = 0; s < nst2; s += 2) {
             gload(s + 1, rB);
-            stage(s, rA);
+            __builtin_amdgcn_sched_barrier(0);     // the next step's loads go out BEFORE this step is consumed (hipcc otherwise hoists
+            stage(s, rA);                          // the first consumer above them and waits for most of the queue first)
             gload(s + 2, rA);
+            __builtin_amdgcn_sched_barrier(0);
             stage(s + 1, rB);      // zeros if it is the padding step
         }
     }
@@ -1145,6 +1152,327 @@ __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward, version 2 (hi + lo operands, r <= 16): TWO kernels for the whole call instead of four.
+//
+// T3W  k_t3w  the pass over gy.  Like k_t3e it yields the gB partials AND gt = gy . B_c^T from one read of gy, but the
+//             workgroup's 8 waves split its COLUMNS (one 128-column chunk each: 1024 columns per workgroup) and walk the same
+//             32-row steps; the eight chunk contributions to gt meet in LDS once per step (one raw barrier, double-buffered
+//             exchange area; the prefetch of the next step is in flight across it).  gt therefore leaves as ceil(N / 1024)
+//             partials (5 at N = 4736) instead of ceil(N / 256) (19): 13 MB out and back instead of 50, and with
+//             N <= 1024 (FINAL) the sum is complete in the kernel and the two bf16 images of gt are written directly --
+//             no k_gt_reduce launch.  A wave owns its columns for the whole row group, so the gB partial goes from its
+//             accumulators to memory without the cross-wave pass of k_t3 / k_t3e.  The spill balance:
+//             gt partials 64 M ceil(N / 1024) bytes + gB partials 64 N x row groups, 28 MB at M = 41,472, N = 4736 with one
+//             workgroup per CU, against 58 MB for k_t3e's 256-column pairs.
+// XGX  k_xgx  the pass over x and gx: gx += s (gt A_c^T) (.) mask as k_t2, and IN THE SAME PASS gA = drop(x)^T gt from the x
+//             tile (k_t2<GA>'s contraction with the tile taken from memory instead of recomputed), with gt summed from T3W's
+//             partials per 16-row tile (NP 16-byte loads per lane) and split hi + lo in registers: the gt images never exist,
+//             k_gt_reduce and k_t3 over x are gone, and x / gx share one launch's ramp and tail.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier() {     // workgroup barrier that orders LDS traffic only: global loads in flight stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename XT, bool FINAL>
+__global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf,
+                                                float* __restrict__ Gpart, long long M, long long Mp, int N, int steps_per_wg,
+                                                const bf16_t* __restrict__ W1b, float* __restrict__ GTP,
+                                                bf16_t* __restrict__ T_out, bf16_t* __restrict__ TTf_out, int xcd_order) {
+    constexpr int CPR = 16;
+    __shared__ uint4 xs[8][32 * CPR];                                           // 8 KB per wave: its 32 x 128 tile
+    __shared__ __attribute__((aligned(16))) float gtx[2][8][32 * 16];           // [step parity][wave][row][rank]: gt contributions
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    unsigned ptile = blockIdx.y * gridDim.x + blockIdx.x;       // (column group, row group): the groups of a row range on one XCD
+    if (xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * gridDim.y);
+    const int cg = (int)(ptile % gridDim.x), rg = (int)(ptile / gridDim.x);
+    const int nchunks = (N + 127) / 128;
+    const int chunk = cg * 8 + wave;
+    const bool active = chunk < nchunks;                        // wave-uniform
+    const int c0 = chunk * 128;
+    const int s_begin = rg * steps_per_wg;
+    const int s_total = (int)(Mp >> 5);
+    const int nst = (s_begin + steps_per_wg < s_total ? s_begin + steps_per_wg : s_total) - s_begin;
+    const int lr = lane >> 4, lc = lane & 15;
+    const int col = c0 + lc * 8;
+    const int colc = (active && col < N) ? col : (N - 8);
+    const unsigned cmask = (active && col < N) ? 0xffffffffu : 0u;
+
+    // B operand of the gt contraction: B_c[r = n][c0 + ks*32 + g*8 .. +8], hi and lo rows of the image
+    uint4 bw[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cb = c0 + ks * 32 + g * 8;
+            const bool okc = active && cb < N;
+            bw[h][ks] = and4(*reinterpret_cast<const uint4*>(W1b + (long long)(h * 16 + n) * N + (okc ? cb : N - 8)), okc ? 0xffffffffu : 0u);
+        }
+    struct Regs {
+        uint4 t[2];
+        Raw8<XT> x[8];
+    };
+    // row indices and the row pitch as 32-bit values (the launcher checks M and ldx < 2^31): one v_min_u32 + one v_mad_u64_u32 per
+    // load instead of a 64-bit compare / select / multiply chain
+    const unsigned m_last = (unsigned)(M - 1), ldx32 = (unsigned)ldx;
+    const XT* const Xc = X + colc;
+    const bf16_t* const TTl = TTf + lane * 8;
+    auto gload = [&](int s0, Regs& r_) {
+        const unsigned s = (unsigned)(s_begin + (s0 < nst ? s0 : nst - 1));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) r_.t[h] = *reinterpret_cast<const uint4*>(TTl + (unsigned long long)(s * 2u + h) * 512u);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned m = min(s * 32u + (unsigned)(lr + 4 * q), m_last);
+            r_.x[q].load(Xc + (unsigned long long)m * ldx32);
+        }
+    };
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4* slab = xs[wave];
+    auto stage = [&](int s0, const Regs& r_) {
+        const long long mb = (long long)(s_begin + s0) * 32;
+        const unsigned smask = s0 < nst ? cmask : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = lr + 4 * q;
+            slab[row * CPR + (lc ^ (t3_h(row) << 1))] = and4(r_.x[q].packed(), mb + row < M ? smask : 0u);
+        }
+        wave_sync();
+        float* gout = &gtx[s0 & 1][wave][0];
+#pragma unroll
+        for (int rtile = 0; rtile < 2; ++rtile) {
+            f32x4 ga = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = rtile * 16 + n;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 xa = slab[row * CPR + ((ks * 4 + g) ^ (t3_h(row) << 1))];
+                // D[i = rank idx][n = row] += sum_col B_c[rank idx][col] * gy[row][col]   (k_t3e's transposed product)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    ga = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[h][ks]), __builtin_bit_cast(bf16x8, xa), ga, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x4*>(gout + (rtile * 16 + n) * 16 + g * 4) = ga;      // lane (n, g): gt[row n][ranks 4g .. 4g+3]
+        }
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            const int rowA = g * 8 + (n >> 2), rowB = rowA + 4;
+            const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
+            const char* base = reinterpret_cast<const char*>(slab);
+            const char* pa = base + ((rowA * CPR + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
+            const char* pb = base + ((rowB * CPR + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[h]), __builtin_bit_cast(bf16x8, both), acc[ct], 0, 0, 0);
+        }
+        wave_sync();
+    };
+    // after the step's barrier: two waves (rotating with the step) add the eight contributions in the fixed order 0 .. 7 and emit
+    // 4 consecutive rank entries per lane
+    auto emit = [&](int s0) {
+        const int rw = (s0 & 3) * 2;
+        if (wave != rw && wave != rw + 1) return;
+        const int l2 = (wave - rw) * 64 + lane;         // 128 lanes x 4 entries = the step's 32 rows x 16 ranks
+        const int row = l2 >> 2, r0 = (l2 & 3) * 4;
+        const float* gin = &gtx[s0 & 1][0][row * 16 + r0];
+        f32x4 s4 = *reinterpret_cast<const f32x4*>(gin);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s4 += *reinterpret_cast<const f32x4*>(gin + w * 512);
+        const long long m = (long long)(s_begin + s0) * 32 + row;
+        if (FINAL) store_t4_hl<1>(T_out, TTf_out, m, 0, r0, s4);
+        else *reinterpret_cast<f32x4*>(GTP + ((long long)cg * Mp + m) * 16 + r0) = s4;
+    };
+    // One code path for every wave (an idle wave of the last column group streams masked duplicates of the group's last 16
+    // bytes per row -- one line per row, L2 hits): no divergent control flow around the loads, so that the waits stay counted.
+    // The next step's loads are issued BEFORE the current step is consumed (sched_barrier pins that order: hipcc otherwise hoists
+    // the first consumer above them and waits for the whole queue first).
+    Regs rA, rB;
+    gload(0, rA);
+    for (int s = 0; s < nst; s += 2) {
+        gload(s + 1, rB);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(s, rA);
+        lds_barrier();
+        emit(s);
+        gload(s + 2, rA);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(s + 1, rB);           // the padding step of an odd count stages zeros
+        lds_barrier();
+        if (s + 1 < nst) emit(s + 1);
+    }
+    if (!active) return;
+    // the wave's accumulators ARE the row group's partial for its columns: lane (n, g) holds G[rank 4g + jj][col ct*16 + n]
+    float* out = Gpart + (long long)rg * 16 * N;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const int ocol = c0 + ct * 16 + n;
+        if (ocol < N) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = acc[ct][jj];
+        }
+    }
+}
+
+// NP: number of gt partials summed per tile (>= nparts; the surplus loads re-read the last partial and are masked out)
+template <bool DROP, int NP>
+__global__ __launch_bounds__(256, 2) void k_xgx(const bf16_t* __restrict__ X, long long ldx, bf16_t* __restrict__ Y, long long ldy,
+                                                const float* __restrict__ GTP, int nparts, long long Mp,
+                                                const bf16_t* __restrict__ W2t, long long M, int N, float scale, int tiles_per_wg,
+                                                DropKey dk, float* __restrict__ GApart, ReduceRide ride, int xcd_order) {
+    constexpr int RP = 32, CW = 128, LDW = CW + 4;
+    __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
+    __shared__ uint4 atile_all[4][16 * 16];         // the wave's x tile, bf16 [16 rows][16 chunks of 8], t3_h swizzle
+    __shared__ uint4 gtt_all[4][64];                // gt^T of the tile as the K = 32 A-operand image: [rank 16][hi rows 0..15 | lo rows 0..15]
+    if (blockIdx.y < (unsigned)ride.rows) {         // riding reduction blocks (the gB partials of k_t3w), scheduled first
+        const long long e = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        if (e < (long long)ride.nblk) reduce_block(ride.j0, e, ride.scale, ride.accumulate, &slab_all[0][0]);
+        return;
+    }
+    unsigned pbody = (blockIdx.y - (unsigned)ride.rows) * gridDim.x + blockIdx.x;
+    if (xcd_order) pbody = xcd_tile_index(pbody, gridDim.x * (gridDim.y - (unsigned)ride.rows));
+    const unsigned bx = pbody % gridDim.x, by = pbody / gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    float* slab = slab_all[wave];
+    uint4* atile = atile_all[wave];
+    uint4* gtt = gtt_all[wave];
+    const int c0 = bx * CW;
+    // A_c fragments (MFMA A-operand: i = output column, k = rank index; interleaved hi | lo image), kept for the whole kernel
+    uint4 wq[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const int colw = c0 + ct * 16 + n;
+        wq[ct] = colw < N ? *reinterpret_cast<const uint4*>(W2t + (long long)colw * RP + g * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const long long ntiles = (M + 15) / 16, nfull = M / 16;
+    const long long t_begin = (long long)by * tiles_per_wg + wave;
+    const long long t_end = min((long long)(by + 1) * tiles_per_wg, ntiles);
+    const int col = c0 + (lane & 15) * 8;
+    f32x4 gacc[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) gacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    struct GtP {
+        f32x4 p[NP];
+    };
+    auto load_gt = [&](long long t, GtP& q) {
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            const int cc = c < nparts ? c : nparts - 1;
+            q.p[c] = *reinterpret_cast<const f32x4*>(GTP + ((long long)cc * Mp + t * 16 + n) * 16 + g * 4);
+        }
+    };
+    // the tile's work once its operands are in registers
+    auto tile_body = [&](auto fast_tag, long long t, YTile<bf16_t>& cur, const YTile<bf16_t>& xt, const GtP& q) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        f32x4 s4 = q.p[0];
+#pragma unroll
+        for (int c = 1; c < NP; ++c) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            s4 += c < nparts ? q.p[c] : z;
+        }
+        const unsigned h0 = pack2(s4[0], s4[1]), h1 = pack2(s4[2], s4[3]);
+        const unsigned l0 = pack2(s4[0] - bf_lo(h0), s4[1] - bf_hi(h0)), l1 = pack2(s4[2] - bf_lo(h1), s4[3] - bf_hi(h1));
+        // delta^T: (w_hi, w_lo) . (t_hi, t_hi) + (w_hi, w_lo) . (t_lo, 0), as k_t2's hi + lo form
+        const uint4 tb = make_uint4(h0, h1, h0, h1), tc = make_uint4(l0, l1, 0u, 0u);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[ct]), __builtin_bit_cast(bf16x8, tb), d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[ct]), __builtin_bit_cast(bf16x8, tc), d, 0, 0, 0);
+            *reinterpret_cast<f32x4*>(slab + n * LDW + ct * 16 + g * 4) = d;
+        }
+        wave_sync();
+        cur.template add_store<FAST, DROP, 0>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, nullptr, 0, cur);
+        // the x tile (masked as the forward masked it) and gt^T in the K = 32 operand image: slot n = hi of row n, slot 16 + n = lo
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int rl = p * 4 + (lane >> 4);
+            uint4 v = xt.v[p];
+            if (DROP) v = drop8(v, (unsigned long long)(t * 16 + rl) * dk.width + col, dk);
+            atile[rl * 16 + ((lane & 15) ^ (t3_h(rl) << 1))] = v;
+        }
+        {
+            bf16_t* gb = reinterpret_cast<bf16_t*>(gtt) + (g * 4) * 32 + n;
+            gb[0] = (bf16_t)(h0 & 0xffffu);  gb[32] = (bf16_t)(h0 >> 16);  gb[64] = (bf16_t)(h1 & 0xffffu);  gb[96] = (bf16_t)(h1 >> 16);
+            gb[16] = (bf16_t)(l0 & 0xffffu); gb[48] = (bf16_t)(l0 >> 16);  gb[80] = (bf16_t)(l1 & 0xffffu);  gb[112] = (bf16_t)(l1 >> 16);
+        }
+        wave_sync();
+        const uint4 gf = gtt[n * 4 + g];
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const char* base = reinterpret_cast<const char*>(atile);
+        const int rowA = (g & 1) * 8 + (n >> 2), rowB = rowA + 4;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
+            const char* pa = base + ((rowA * 16 + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
+            const char* pb = base + ((rowB * 16 + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            // D[i = rank idx][n = column] += sum_row (gt_hi + gt_lo)[row][i] * drop(x)[row][col]
+            gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf), __builtin_bit_cast(bf16x8, both), gacc[ct], 0, 0, 0);
+        }
+        wave_sync();
+    };
+    const bool colfull = c0 + CW <= N;
+    const long long t_fast_end = colfull ? min(t_end, nfull) : t_begin;
+    long long t = t_begin;
+    if (t < t_fast_end) {       // branch-free stream, one tile ahead (k_t2's discipline): gt partials first, they are needed first
+        YTile<bf16_t> cur, nxt, xc, xn;
+        GtP qc, qn;
+        load_gt(t, qn);
+        nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
+        xn.template load<true, true>(X, ldx, t * 16, col, lane, M, N);
+        for (; t < t_fast_end; t += 4) {
+            cur = nxt;
+            xc = xn;
+            qc = qn;
+            const long long tn = t + 4 < t_fast_end ? t + 4 : t;
+            load_gt(tn, qn);
+            nxt.template load<true>(Y, ldy, tn * 16, col, lane, M, N);
+            xn.template load<true, true>(X, ldx, tn * 16, col, lane, M, N);
+            tile_body(std::true_type{}, t, cur, xc, qc);
+        }
+    }
+    for (; t < t_end; t += 4) {     // ragged tiles: predicated path (loads beyond M / N come back as zeros)
+        YTile<bf16_t> cur, xc;
+        GtP qc;
+        load_gt(t, qc);
+        cur.template load<false>(Y, ldy, t * 16, col, lane, M, N);
+        xc.template load<false, true>(X, ldx, t * 16, col, lane, M, N);
+        tile_body(std::false_type{}, t, cur, xc, qc);
+    }
+    // fixed-order cross-wave sum ((w0 + w1) + w2) + w3 through LDS (as k_t2<GA>); wave w writes column tiles 2w, 2w + 1
+    float* red = &slab_all[0][0];
+    float* out = GApart + (long long)by * 16 * N;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) *reinterpret_cast<f32x4*>(red + ((wave * 8 + ct) * 64 + lane) * 4) = gacc[ct];
+    __syncthreads();
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc) {
+        const int ct = wave * 2 + jc;
+        f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ((0 * 8 + ct) * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 8 + ct) * 64 + lane) * 4);
+        const int ocol = c0 + ct * 16 + n;
+        if (ocol < N) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = s4[jj];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // merge: Wm[o][i] = W[o][i] + scaling * sum_r A_c[i][r] * B_c[r][o]     (fp32, one-off)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ W, const float* __restrict__ A,
@@ -1244,8 +1572,26 @@ T3Plan plan_t3e(long long Mp, int N) {
     return p;
 }
 
+T3Plan plan_t3w(long long Mp, int N) {
+    // k_t3w: workgroup = 8 waves x one 128-column chunk each (`nchunks` counts column GROUPS of 1024) x a range of 32-row steps.
+    // One workgroup per CU (96 KB of LDS): ~256 of them, so that the gB partials (one per row group) stay small.
+    T3Plan p;
+    p.br = 32;
+    p.nchunks = ((N + 127) / 128 + 7) / 8;
+    const long long steps = Mp / 32;
+    long long nrg = env_int("SAM3_LORA_T3W_WGS", 256) / p.nchunks;
+    if (nrg > steps) nrg = steps;
+    if (nrg < 1) nrg = 1;
+    const long long spw = (steps + nrg - 1) / nrg;
+    p.rows_per_wg = (int)(spw * 32);
+    p.NR = (int)((steps + spw - 1) / spw);
+    return p;
+}
+// version 2 of the bf16 backward (k_t3w, k_xgx): hi + lo kernels, one rank group of <= 16; SAM3_LORA_BWD_V2=0 restores k_t3e
+bool bwd_v2_enabled() { return env_int("SAM3_LORA_BWD_V2", 1) != 0; }
+
 int check_common(long long M, int in_f, int out_f, int rank, int layout, int dtype) {
-    if (M <= 0) return fail(SAM3_LORA_EINVAL, "M must be positive (got %lld)", M);
+    if (M <= 0 || M >= (1LL << 31)) return fail(SAM3_LORA_EINVAL, "M must be in [1, 2^31) (got %lld)", M);
     if (in_f <= 0 || out_f <= 0 || (in_f % 8) || (out_f % 8))
         return fail(SAM3_LORA_EINVAL, "in_features/out_features must be positive multiples of 8 (got %d, %d)", in_f, out_f);
     if (rank < 1 || rank > SAM3_LORA_MAX_RANK)
@@ -1258,7 +1604,7 @@ int check_common(long long M, int in_f, int out_f, int rank, int layout, int dty
 
 int check_act(const void* p, long long ld, int width, int dtype, const char* what) {
     if (!p) return fail(SAM3_LORA_EINVAL, "%s is NULL", what);
-    if (ld < width) return fail(SAM3_LORA_EINVAL, "ld of %s (%lld) < row width (%d)", what, ld, width);
+    if (ld < width || ld >= (1LL << 31)) return fail(SAM3_LORA_EINVAL, "ld of %s (%lld) < row width (%d), or beyond 2^31 elements", what, ld, width);
     if (((uintptr_t)p & 15) || ((ld * (long long)esize(dtype)) & 15))
         return fail(SAM3_LORA_EINVAL, "%s: base pointer and row pitch must be 16-byte aligned", what);
     return 0;
@@ -1310,7 +1656,8 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
                   {"SAM3_LORA_FUSED_ORDER", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0},
                   {"SAM3_LORA_HL_MAX_RANK", false, 0},
-                  {"SAM3_LORA_T1_BK", false, 0}};
+                  {"SAM3_LORA_T1_BK", false, 0},
+                  {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_BWD_XGX", false, 0},   {"SAM3_LORA_T3W_WGS", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1617,6 +1964,42 @@ void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part,
     else hipLaunchKernelGGL(k_gt_reduce<false>, rg, dim3(256), 0, st, (const float*)GTP, p.nchunks, GT, GTT, Mp);
 }
 
+// version 2: the pass over gy (k_t3w).  `final_images`: N <= 1024 and the caller wants the bf16 images of gt (GT, GTT) -- the sum is
+// complete inside the kernel; otherwise p.nchunks fp32 partials go to GTP.
+template <typename XT>
+void launch_t3w(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N, const T3Plan& p,
+                const bf16_t* W1b, float* GTP, bf16_t* GT, bf16_t* GTT, bool final_images, hipStream_t st) {
+    dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
+    const int xcd = p.nchunks > 1 ? 1 : 0;      // the column groups of a row range share its t^T fragments and write neighbouring gt partial rows
+    ProfScope ps(SAM3_LORA_STAGE_T3W, N, st);
+    if (final_images)
+        hipLaunchKernelGGL((k_t3w<XT, true>), grid, dim3(512), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg / 32, W1b, GTP, GT, GTT, xcd);
+    else
+        hipLaunchKernelGGL((k_t3w<XT, false>), grid, dim3(512), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg / 32, W1b, GTP, GT, GTT, xcd);
+}
+constexpr int XGX_MAX_PARTS = 5;      // (8 partials in flight spill k_xgx's 256 registers)
+// version 2: the pass over x and gx (k_xgx); `ride`: the reduction of k_t3w's gB partials (j0 only)
+void launch_xgx(const void* X, long long ldx, void* GX, long long ldgx, const float* GTP, int nparts, long long Mp, const bf16_t* W2t,
+                long long M, int N, float scale, DropKey dk, float* GApart, const ReduceRide* ride_in, hipStream_t st) {
+    const long long ntiles = (M + 15) / 16;
+    const int nchunks = (N + 127) / 128;
+    const int tiles_per_wg = GA_TILES_PER_WG;
+    ReduceRide ride{};
+    if (ride_in) {
+        ride = *ride_in;
+        ride.rows = (int)(((long long)ride.nblk + nchunks - 1) / nchunks);
+    }
+    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows);
+    const int xcd = xcd_order_for(N);
+    ProfScope ps(SAM3_LORA_STAGE_XGX, N, st);
+#define XGX_LAUNCH(DV, NPV) hipLaunchKernelGGL((k_xgx<DV, NPV>), grid, dim3(256), 0, st, (const bf16_t*)X, ldx, (bf16_t*)GX, ldgx, GTP, nparts, \
+                                               Mp, W2t, M, N, scale, tiles_per_wg, dk, GApart, ride, xcd)
+#define XGX_NP(NPV) do { if (dk.thr) XGX_LAUNCH(true, NPV); else XGX_LAUNCH(false, NPV); } while (0)
+    if (nparts <= 1 && !dk.thr) XGX_NP(1); else if (nparts <= 2) XGX_NP(2); else XGX_NP(5);
+#undef XGX_NP
+#undef XGX_LAUNCH
+}
+
 // ---- exact-fp32 launchers (lora_f32_kernels.inc) ----------------------------------------------------
 void launch32_t1(const void* X, long long ldx, const float* W1, float* T, long long M, long long Mp, int K, int RT,
                  hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}) {
@@ -1684,7 +2067,7 @@ FwdWs fwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
 
 struct BwdWs {
     size_t w1b, w2tb, w1a, gt, gtt, t, tt, pb, pa, gtp, total;
-    T3Plan pB, pA, pE;      // pE: the one-pass (k_t3e) plan over gy, bf16 path with r <= 16
+    T3Plan pB, pA, pE, pW;  // pE: the one-pass (k_t3e) plan over gy, bf16 path with r <= 16; pW: version 2's (k_t3w)
 };
 BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     const Geo gq = geo_of(rank, dtype);
@@ -1695,6 +2078,7 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     w.pB = plan_t3(Mp, out_f, RG / 16);
     w.pA = plan_t3(Mp, in_f, RG / 16);
     w.pE = plan_t3e(Mp, out_f);
+    w.pW = plan_t3w(Mp, out_f);
     size_t off = 0;
     w.w1b = off; off += al256((size_t)RP * round_up(out_f, 128) * e);
     w.w2tb = off; off += al256((size_t)in_f * RP * e);
@@ -1703,7 +2087,11 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     w.gtt = off; off += al256((size_t)RP * Mp * e);
     w.t = off; off += al256((size_t)Mp * RP * e);
     w.tt = off; off += al256((size_t)RP * Mp * e);
-    w.pb = off; off += al256((size_t)(w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR) * RG * out_f * 4);
+    {
+        int nrb = w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR;
+        if (dtype != SAM3_LORA_F32 && RG == 16 && w.pW.NR > nrb) nrb = w.pW.NR;
+        w.pb = off; off += al256((size_t)nrb * RG * out_f * 4);
+    }
     {
         const int nra = ga_row_blocks(M);       // k_t2<GA> writes one gA partial per row block of ITS grid
         w.pa = off; off += al256((size_t)(w.pA.NR > nra ? w.pA.NR : nra) * RG * in_f * 4);
@@ -1978,7 +2366,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     }
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
     const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
-    bool one_pass = false, ga_in_pass = false;
+    bool one_pass = false, ga_in_pass = false, v2 = false;
     if (f32) {
         const float* T32 = (const float*)tT_saved;
         if (!T32) {     // no saved t: recompute t = drop(x) . A_c
@@ -2005,7 +2393,36 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         // r <= 16 with weight gradients wanted: gy is read ONCE -- k_t3e emits the gt partials beside the gB partials
         one_pass = RG == 16 && gB_g && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
         float* GTP = (float*)(ws + w.gtp);
-        if (one_pass) {
+        // version 2 (hi + lo): k_t3w over gy; when the plain backward wants gx, gA and gB, k_xgx finishes the call
+        v2 = one_pass && hl && bwd_v2_enabled() && M < (1LL << 31) && ldgy < (1LL << 31);
+        const bool xgx = v2 && gA_g && s3a && s2 && gx_inout && a2 == 0 && x && !q8 && w.pW.nchunks <= XGX_MAX_PARTS &&
+                         stage_on(SAM3_LORA_STAGE_REDUCE) && env_int("SAM3_LORA_BWD_XGX", 0) != 0;
+        if (v2) {
+            const bool final_images = !xgx && w.pW.nchunks == 1;
+            launch_t3w<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pW, (const bf16_t*)W1b, GTP, GT, GTT, final_images, st);
+            if (xgx) {
+                ReduceRide rd{};
+                rd.j0 = ReduceJob{PB, gB_g, w.pW.NR, RG, out_features, rank, s.b_sr, s.b_so};
+                rd.scale = scale;
+                rd.accumulate = accumulate;
+                rd.nblk = (int)(((long long)rank * out_features + 63) / 64);
+                const bool ride_ok = !env_flag("SAM3_LORA_NO_RIDE");
+                launch_xgx(x, ldx, gx_inout, ldgx, GTP, w.pW.nchunks, Mp, (const bf16_t*)W2tb, M, in_features, scale, dk, PA,
+                           ride_ok ? &rd : nullptr, st);
+                // gA's partials come out of that kernel: their fixed-order sum (3.5 MB at M = 41,472) follows as its own small launch
+                const ReduceJob ja{PA, gA_g, ga_row_blocks(M), RG, in_features, rank, s.a_sr, s.a_si};
+                const ReduceJob none{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
+                const int nblk_a = (int)(((long long)rank * in_features + 63) / 64);
+                ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + (ride_ok ? 0 : out_features), st);
+                if (ride_ok) hipLaunchKernelGGL(k_reduce, dim3((unsigned)nblk_a, 1), dim3(256), 0, st, ja, none, scale, accumulate);
+                else hipLaunchKernelGGL(k_reduce, dim3((unsigned)(nblk_a > rd.nblk ? nblk_a : rd.nblk), 2), dim3(256), 0, st, ja, rd.j0, scale, accumulate);
+                return;
+            }
+            if (!final_images) {
+                ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, out_features, st);
+                hipLaunchKernelGGL(k_gt_reduce<true>, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, w.pW.nchunks, GT, GTT, Mp);
+            }
+        } else if (one_pass) {
             launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, hl, (const bf16_t*)W1b, GTP, GT, GTT, st);
         } else {
             if (s1) launch_t1<bf16_t>(gy, ldgy, (const bf16_t*)W1b, GT, GTT, M, Mp, out_features, RT, hl, st, DropKey{0u, 0u, 0},
@@ -2023,7 +2440,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     const bool want_reduce = (gA_g || gB_g) && stage_on(SAM3_LORA_STAGE_REDUCE);
     ReduceRide ride{};
     if (want_reduce) {
-        ride.j0 = ReduceJob{PB, gB_g, one_pass ? w.pE.NR : w.pB.NR, RG, out_features, rank, s.b_sr, s.b_so};
+        ride.j0 = ReduceJob{PB, gB_g, v2 ? w.pW.NR : one_pass ? w.pE.NR : w.pB.NR, RG, out_features, rank, s.b_sr, s.b_so};
         ride.j1 = ReduceJob{PA, gA_g, ga_in_pass ? ga_row_blocks(M) : w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
         ride.scale = scale;
         ride.accumulate = accumulate;

@@ -272,6 +272,12 @@ def main():
         res["ref_autocast_bf16/pred_boxes"] = np.float64(max([relmax(o16["pred_boxes"], o32["pred_boxes"])] + [
             relmax(a["pred_boxes"], b["pred_boxes"]) for a, b in zip(o16["aux_outputs"], o32["aux_outputs"])]))
         res["ref_autocast_bf16/core_loss"] = np.float64(abs(l16 - l32) / abs(l32))
+        # does the reference's own mixed-precision forward keep the assignment of its fp32 forward?  (final + auxiliary outputs;
+        # the number of outputs whose matched (query, target) pairs differ)
+        pairs = [(o16, o32)] + list(zip(o16["aux_outputs"], o32["aux_outputs"]))
+        flips = sum(0 if all(torch.equal(x, y) for x, y in zip(a["indices"][:2], b["indices"][:2])) else 1 for a, b in pairs)
+        res["ref_autocast_bf16/outputs_with_different_matching"] = np.float64(flips)
+        res["ref_autocast_bf16/outputs_matched"] = np.float64(len(pairs))
         for k in ("presence_logit_dec", "pred_masks"):
             if k in o16 and k in o32:
                 res[f"ref_autocast_bf16/{k}"] = np.float64(relmax(o16[k], o32[k]))

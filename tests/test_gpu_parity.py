@@ -550,7 +550,12 @@ def test_activation_fused_entry_points(dtype, rank, drop):
         Fn.lora_bwd_(gy, x, None, A, B, gx, gA, gB, 2.0, cases.LAYOUT_ROOT, drop_p=drop, seed=9,
                      gelu_pre=h if mode == "act" else None)
         res[mode] = (gx, gA, gB)
-    assert torch.equal(res["plain"][1], res["act"][1]) and torch.equal(res["plain"][2], res["act"][2])
+    # gB comes from the same pass over gy in both modes: bit-identical.  gA: the plain bf16 backward of the hi + lo kernels forms it
+    # inside the pass over x / gx (k_xgx, row blocks of 48 tiles), the activation-fused one with k_t3 over x (row groups): the same
+    # products, another fp32 summation order.
+    assert torch.equal(res["plain"][2], res["act"][2])
+    ga_p, ga_a = res["plain"][1], res["act"][1]
+    assert torch.equal(ga_p, ga_a) or (ga_p - ga_a).abs().max() <= 2e-6 * ga_p.abs().max()
     hf = h.float().requires_grad_(True)
     torch.nn.functional.gelu(hf).sum().backward()
     want = res["plain"][0].float() * hf.grad
@@ -700,6 +705,48 @@ def test_hi_lo_with_dropout_and_fused_gelu():
     Fn.lora_bwd_(_t(gy, torch.bfloat16), _t(x, torch.bfloat16), tT, dA, dB, gx, gA, gB, s, 0, drop_p=p, seed=seed)
     _one_rounding(gx.float().cpu().numpy(), gx_l)
     assert _relmax(gA.cpu().numpy(), gA_w) < 3e-5 and _relmax(gB.cpu().numpy(), gB_w) < 3e-5
+
+
+@pytest.mark.parametrize("M,fin,fout,p", [(2000, 264, 520, 0.0), (777, 1024, 4736, 0.0), (777, 4736, 1024, 0.0), (3001, 264, 1160, 0.2),
+                                            (50, 136, 64, 0.0), (1, 64, 2056, 0.0)])
+def test_backward_versions_agree_with_each_other_and_the_oracle(monkeypatch, M, fin, fout, p):
+    """The bf16 backward of one rank group of <= 16 has three builds: version 1 (k_t3e + k_gt_reduce + k_t3 + k_t2:
+    SAM3_LORA_BWD_V2=0), version 2 (k_t3w -- eight waves split 1024 columns, gt summed across them in LDS: 1, 2 or 5 partials here,
+    written as the bf16 images directly when out_features <= 1024 -- the default) and version 2 with the pass over x and gx fused
+    (k_xgx: SAM3_LORA_BWD_XGX=1).  Same products, other fp32 summation orders: gx within ONE bf16 rounding of the fp64 oracle in
+    each, gA / gB 3e-5 of max; accumulate mode adds onto the caller's gradients in each."""
+    rng = np.random.default_rng(M + fout)
+    rank, s, seed = 16, 2.0, 77
+    x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    gy = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    gxb = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    A = (rng.uniform(-1, 1, (fin, rank)) / 4).astype(np.float32)
+    B = (rng.standard_normal((rank, fout)) * 0.05).astype(np.float32)
+    mask = O.dropout_scale_mask(M, fin, p, seed) if p else None
+    gx_l, gA_w, gB_w = O.adapter_backward(gy, x, A, B, s, 0, drop_scale_mask=mask, acc_dtype=np.float64)
+    dA, dB = _t(A), _t(B)
+    outs = {}
+    for name, env in (("v2", {}), ("v1", {"SAM3_LORA_BWD_V2": "0"}), ("v2+xgx", {"SAM3_LORA_BWD_XGX": "1"})):
+        for k in ("SAM3_LORA_BWD_V2", "SAM3_LORA_BWD_XGX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _reload_knobs()
+        y = torch.zeros(M, fout, device=DEV, dtype=torch.bfloat16)
+        tT = Fn.lora_fwd_(_t(x, torch.bfloat16), dA, dB, y, s, 0, save_t=True, drop_p=p, seed=seed)
+        gx = _t(gxb, torch.bfloat16)
+        gA, gB = torch.full_like(dA, 0.5), torch.full_like(dB, 0.25)
+        Fn.lora_bwd_(_t(gy, torch.bfloat16), _t(x, torch.bfloat16), tT, dA, dB, gx, gA, gB, s, 0, accumulate=True, drop_p=p, seed=seed)
+        outs[name] = (gx.float().cpu().numpy(), gA.cpu().numpy() - 0.5, gB.cpu().numpy() - 0.25)
+        _one_rounding(outs[name][0], gxb + gx_l)
+        ea, eb = _relmax(outs[name][1], gA_w), _relmax(outs[name][2], gB_w)
+        assert ea < 3e-5 and eb < 3e-5, (name, ea, eb)
+    for k in ("SAM3_LORA_BWD_V2", "SAM3_LORA_BWD_XGX"):
+        monkeypatch.delenv(k, raising=False)
+    _reload_knobs()
+    # gx does not depend on how gt's partials were laid out (the same fixed-order sum, the same hi + lo split): bit-identical
+    assert np.array_equal(outs["v2"][0], outs["v2+xgx"][0])
+    assert np.array_equal(outs["v2"][2], outs["v2+xgx"][2])          # gB: the same k_t3w partials through the same sum
 
 
 def test_riding_reduction_is_bit_identical_to_the_separate_launch(monkeypatch):

@@ -22,7 +22,8 @@ VARIANTS = {
     "no_ride": {"SAM3_LORA_NO_RIDE": "1"},
     "round-2 equivalent (single_round + no_ride)": {"SAM3_LORA_SINGLE_ROUND": "1", "SAM3_LORA_NO_RIDE": "1"},
 }
-KNOBS = ("SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE", "SAM3_LORA_T3E_WGS", "SAM3_LORA_T3_WGS", "SAM3_LORA_T2_TPW", "SAM3_LORA_XCD_ORDER")
+KNOBS = ("SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE", "SAM3_LORA_T3E_WGS", "SAM3_LORA_T3_WGS", "SAM3_LORA_T2_TPW", "SAM3_LORA_XCD_ORDER",
+         "SAM3_LORA_BWD_V2", "SAM3_LORA_BWD_XGX", "SAM3_LORA_T3W_WGS")
 
 
 def main():
@@ -65,7 +66,7 @@ def main():
             r = out.setdefault(name, {"env": env, "rounds": []})
             r["rounds"].append({"fwd+bwd_per_block_us_no_recompute": round(per_block_us, 1),
                                 "ops": {o["op"]: [o["avg_us"], o["frac_of_peak"]] for o in ops},
-                                "kernels": {f"{k['kernel']}@{k['dim']}": [k["avg_us"], round(k["GBps"] / 8000, 3)] for k in rows}})
+                                "kernels": {f"{k['kernel']}@{k['dim']}": [k["avg_us"], round(k["GBps"] / 8000, 3) if k["GBps"] else None] for k in rows}})
             del w
             torch.cuda.empty_cache()
     print(json.dumps(out, indent=1))
