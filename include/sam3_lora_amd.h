@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SAM3_LORA_ABI_VERSION 5
+#define SAM3_LORA_ABI_VERSION 6
 #define SAM3_LORA_MAX_RANK 1024
 
 #define SAM3_LORA_LAYOUT_ROOT 0
@@ -220,6 +220,22 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
                          int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldw, int64_t ldy,
                          int layout, float scaling, float drop_p, uint64_t seed, uint64_t offset, int dtype,
                          void* workspace, size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact);
+/*
+ * The same kernel in the fp8 frozen-W mode (BASELINE.json configs[4]; include/sam3_fp8_amd.h): the frozen GEMM runs on the e4m3
+ * images of its operands -- x_q8[M, in] (row pitch ldxq BYTES; e.g. what the LayerNorm before the MLP wrote beside its bf16 output)
+ * and w_q8[out, in] (row pitch ldwq bytes; made once, the weight is frozen) with one dequantisation scale each (DEVICE scalars:
+ * x ~ *scale_x * x_q8, delayed scaling) -- on v_mfma_scale_f32_16x16x128_f8f6f4, half the operand bytes and half the matrix-pipe time
+ * of the bf16 form; the LoRA branch stays bf16 / hi + lo (it reads the bf16 `x`), joins the same fp32 accumulator, and y_out / act_out
+ * are rounded once.  With act = SAM3_LORA_ACT_GELU and q8_out != NULL, GELU(y_out) ALSO leaves as the fp8 image the next frozen GEMM
+ * (fc2) consumes, by the protocol of sam3_lora_fwd_act_q8 (bit-identical to quantising act_out afterwards).  in_features % 128 == 0;
+ * otherwise as sam3_lora_linear_fwd (same workspace size).  Replaces, in that mode, hipBLASLt's fp8 GEMM + sam3_lora_fwd_act_q8.
+ */
+int sam3_lora_linear_fwd_q8(const void* x, const void* x_q8, int64_t ldxq, const float* scale_x, const void* w_q8, int64_t ldwq,
+                            const float* scale_w, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
+                            int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling,
+                            float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes,
+                            void* stream, int act, void* act_out, int64_t ldact,
+                            void* q8_out, int64_t ldq, int fmt, const float* amax_in, float* amax_out, float* scale_out);
 
 /*
  * Merge for adapter-free inference: Wm[out, in] = W[out, in] + scaling * (A_c @ B_c)^T, fp32.
@@ -250,7 +266,7 @@ unsigned sam3_lora_debug_set_stages(unsigned mask);
 
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
  * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_WGS,
- * SAM3_LORA_FUSED_ORDER, SAM3_LORA_FUSED_TILE, SAM3_LORA_HL_MAX_RANK) are read from the
+ * SAM3_LORA_FUSED_HALF, SAM3_LORA_FUSED_TILE, SAM3_LORA_HL_MAX_RANK) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);

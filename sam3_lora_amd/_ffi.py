@@ -18,7 +18,7 @@ LAYOUT_ROOT = 0
 LAYOUT_PACKAGE = 1
 DT_BF16 = 0
 DT_F32 = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_RANK = 1024
 
 EXPORTS = (
@@ -28,7 +28,7 @@ EXPORTS = (
     "sam3_lora_prof_start", "sam3_lora_prof_stop",
     "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
     "sam3_lora_fwd_act_q8", "sam3_lora_bwd_act_q8", "sam3_lora_bwd_act_recomputes_input",
-    "sam3_lora_linear_fwd", "sam3_lora_linear_fwd_supported", "sam3_lora_linear_fwd_workspace_bytes",
+    "sam3_lora_linear_fwd", "sam3_lora_linear_fwd_supported", "sam3_lora_linear_fwd_workspace_bytes", "sam3_lora_linear_fwd_q8",
 )
 ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
@@ -110,6 +110,16 @@ def _declare(lib):
         c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
         c_int, c_void_p, c_int64,                              # act, act_out, ldact
     ]
+    lib.sam3_lora_linear_fwd_q8.restype = c_int
+    lib.sam3_lora_linear_fwd_q8.argtypes = [
+        c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,     # x, x_q8, ldxq, scale_x, w_q8, ldwq, scale_w
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,       # bias, A, B, y_out, tT_out
+        c_int64, c_int, c_int, c_int,                          # M, in, out, rank
+        c_int64, c_int64, c_int, c_float,                      # ldx, ldy, layout, scaling
+        c_float, c_uint64, c_uint64, c_int,                    # drop_p, seed, offset, dtype
+        c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
+        c_int, c_void_p, c_int64,                              # act, act_out, ldact
+    ] + q8_tail
     lib.sam3_lora_bwd_act_recomputes_input.restype = c_int
     lib.sam3_lora_bwd_act_recomputes_input.argtypes = [c_int, c_int, ctypes.c_float]
     lib.sam3_lora_debug_reload_knobs.restype = None

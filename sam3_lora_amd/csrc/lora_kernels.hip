@@ -1654,7 +1654,7 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
                   {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
-                  {"SAM3_LORA_FUSED_ORDER", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0},
+                  {"SAM3_LORA_FUSED_HALF", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0},  {"SAM3_LORA_FUSED_PROBE", false, 0},
                   {"SAM3_LORA_HL_MAX_RANK", false, 0},
                   {"SAM3_LORA_T1_BK", false, 0},
                   {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_BWD_XGX", false, 0},   {"SAM3_LORA_T3W_WGS", false, 0}};
@@ -2588,10 +2588,17 @@ size_t sam3_lora_linear_fwd_workspace_bytes(int64_t M, int in_features, int out_
     return fwd_ws(M, in_features, out_features, rank, dtype).total + al256((size_t)out_features * 128 * 2);
 }
 
-int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
-                         int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldw, int64_t ldy,
-                         int layout, float scaling, float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace,
-                         size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact) {
+struct LinearF8 {        // the fp8 frozen-W form of sam3_lora_linear_fwd (sam3_lora_linear_fwd_q8)
+    const void* x_q8; long long ldxq;
+    const void* w_q8; long long ldwq;
+    const float* scale_x; const float* scale_w;
+    Q8Out q8;               // fp8 image of the activation output (q == nullptr: none)
+};
+
+static int linear_fwd_impl(const void* x, const void* W, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
+                           int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldw, int64_t ldy,
+                           int layout, float scaling, float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace,
+                           size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact, const LinearF8* f8) {
     g_err[0] = 0;
     if (drop_p < 0.f || drop_p > 1.f) return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p);
     int rc;
@@ -2602,7 +2609,21 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
         return fail(SAM3_LORA_ENOTSUP, "fused linear: bf16 activations, rank <= 32, in_features %% 64 == 0 (got in %d, rank %d, dtype %d)",
                     in_features, rank, dtype);
     if ((rc = check_act(x, ldx, in_features, dtype, "x"))) return rc;
-    if ((rc = check_act(W, ldw, in_features, dtype, "W"))) return rc;
+    if (!f8 && (rc = check_act(W, ldw, in_features, dtype, "W"))) return rc;
+    if (f8) {
+        if (in_features % 128) return fail(SAM3_LORA_ENOTSUP, "fused fp8 linear: in_features %% 128 == 0 (got %d)", in_features);
+        if (!f8->x_q8 || !f8->w_q8 || !f8->scale_x || !f8->scale_w) return fail(SAM3_LORA_EINVAL, "fused fp8 linear: NULL image or scale");
+        if (f8->ldxq < in_features || f8->ldwq < in_features || (f8->ldxq & 15) || (f8->ldwq & 15) || ((uintptr_t)f8->x_q8 & 15) || ((uintptr_t)f8->w_q8 & 15))
+            return fail(SAM3_LORA_EINVAL, "fused fp8 linear: image base pointers and row pitches must be 16-byte aligned");
+        if (256LL * f8->ldxq >= (1LL << 31) || 256LL * f8->ldwq >= (1LL << 31))
+            return fail(SAM3_LORA_ENOTSUP, "fused fp8 linear: row pitches beyond 8 M bytes are not addressable by the tile descriptors");
+        if (f8->q8.q) {
+            if (act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "fp8 output rides on the activation output only");
+            if (!f8->q8.amax_in || !f8->q8.amax_out || !f8->q8.scale_out) return fail(SAM3_LORA_EINVAL, "fp8 output: NULL pointer");
+            if (f8->q8.fmt != SAM3_FP8_E4M3 && f8->q8.fmt != SAM3_FP8_E5M2) return fail(SAM3_LORA_EINVAL, "fp8 output: unknown format %d", f8->q8.fmt);
+            if (f8->q8.ld < out_features || (f8->q8.ld & 7) || ((uintptr_t)f8->q8.q & 7)) return fail(SAM3_LORA_EINVAL, "fp8 output: row pitch / base must be 8-byte aligned");
+        }
+    }
     if ((rc = check_act(y_out, ldy, out_features, dtype, "y_out"))) return rc;
     if (bias && ((uintptr_t)bias & 7)) return fail(SAM3_LORA_EINVAL, "bias must be 8-byte aligned");
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
@@ -2610,7 +2631,7 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
     if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
     if (act && (rc = check_act(act_out, ldact, out_features, dtype, "act_out"))) return rc;
     if (tT_out && ((uintptr_t)tT_out & 15)) return fail(SAM3_LORA_EINVAL, "tT_out must be 16-byte aligned");
-    if (256LL * ldx * 2 >= (1LL << 31) || 256LL * ldw * 2 >= (1LL << 31) || 256LL * ldy * 2 >= (1LL << 31) || (act && 256LL * ldact * 2 >= (1LL << 31)))
+    if (256LL * ldx * 2 >= (1LL << 31) || (!f8 && 256LL * ldw * 2 >= (1LL << 31)) || 256LL * ldy * 2 >= (1LL << 31) || (act && 256LL * ldact * 2 >= (1LL << 31)))
         return fail(SAM3_LORA_ENOTSUP, "fused linear: row pitches beyond 4 M elements are not addressable by the tile descriptors");
     const FwdWs w = fwd_ws(M, in_features, out_features, rank, dtype);
     const size_t need = w.total + al256((size_t)out_features * 128 * 2);
@@ -2643,7 +2664,7 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
         ProfScope ps(SAM3_LORA_STAGE_PACK, out_features, st);
         const int groups = gq.hl ? RP / 8 : 8;
         hipLaunchKernelGGL(fl::k_wext, dim3((unsigned)((out_features * groups + 255) / 256)), dim3(256), 0, st, (const bf16_t*)W2t, Wext,
-                           out_features, RP, gq.hl ? 1 : 0, scaling * inv_keep);
+                           out_features, RP, gq.hl ? 1 : 0, scaling * inv_keep, f8 ? f8->scale_x : nullptr, f8 ? f8->scale_w : nullptr);
     }
     if (stage_on(SAM3_LORA_STAGE_FUSED)) {
         fl::Args fa;
@@ -2654,13 +2675,26 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
         fa.Y = (bf16_t*)y_out; fa.ldy = ldy;
         fa.A = (bf16_t*)act_out; fa.lda = ldact;
         fa.M = M; fa.Mp = Mp; fa.N = out_features; fa.K = in_features;
+        fa.X8 = nullptr; fa.W8 = nullptr; fa.ldx8 = fa.ldw8 = 0; fa.sx = fa.sw = nullptr;
+        fa.q8 = Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
+        if (f8) {
+            fa.X8 = (const unsigned char*)f8->x_q8; fa.ldx8 = f8->ldxq;
+            fa.W8 = (const unsigned char*)f8->w_q8; fa.ldw8 = f8->ldwq;
+            fa.sx = f8->scale_x; fa.sw = f8->scale_w;
+            fa.q8 = f8->q8;
+        }
         // tile configuration: 1 = fl::CfgPair (256 x 128 x 32, two workgroups per CU), 0 = fl::CfgBig (256 x 256 x 64, one)
-        const int pair = (int)env_int("SAM3_LORA_FUSED_TILE", 0);
+        // tile configuration: 0 = fl::CfgBig, 1 = fl::CfgPair, 2 = fl::CfgRing (256 x 256 x 32, four-stage ring)
+        const int tile_cfg = f8 ? 0 : (int)env_int("SAM3_LORA_FUSED_TILE", 0);
+        const int pair = tile_cfg == 1, ring = tile_cfg == 2;
         const int bm = pair ? fl::CfgPair::BM : fl::CfgBig::BM, bn = pair ? fl::CfgPair::BN : fl::CfgBig::BN;
         fa.tiles_m = (int)((M + bm - 1) / bm);
-        fa.tiles_n = (out_features + bn - 1) / bn;
-        fa.order = (int)env_int("SAM3_LORA_FUSED_ORDER", 0);
-        const long long ntiles = (long long)fa.tiles_m * fa.tiles_n;
+        {   // a last column of tiles at most half a tile wide runs as "half tiles" (fl::TileSeq); SAM3_LORA_FUSED_HALF=0: as full ones
+            const int rem = out_features % bn;
+            fa.half_col = (rem > 0 && rem <= bn / 2 && env_int("SAM3_LORA_FUSED_HALF", 1) != 0) ? 1 : 0;
+            fa.ncf = fa.half_col ? out_features / bn : (out_features + bn - 1) / bn;
+        }
+        const long long ntiles = (long long)fa.tiles_m * (fa.ncf + fa.half_col);
         long long grid = env_int("SAM3_LORA_FUSED_WGS", (long long)fused_cu_count() * (pair ? fl::CfgPair::WGS_PER_CU : 1));
         if (grid > ntiles) grid = ntiles;
         if (grid < 1) grid = 1;
@@ -2668,8 +2702,19 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
         ProfScope ps(SAM3_LORA_STAGE_FUSED, out_features, st);
 #define SAM3_FL_LAUNCH(CFG_, ACT_, TROW_) \
         hipLaunchKernelGGL((fl::k_fused_linear<fl::CFG_, ACT_, TROW_>), dim3((unsigned)grid), dim3(fl::TileGeo<fl::CFG_>::NTHREADS), 0, st, fa)
-#define SAM3_FL_CFG(ACT_, TROW_) do { if (pair) SAM3_FL_LAUNCH(CfgPair, ACT_, TROW_); else SAM3_FL_LAUNCH(CfgBig, ACT_, TROW_); } while (0)
-        if (act) {
+#define SAM3_FL_CFG(ACT_, TROW_) do { if (pair) SAM3_FL_LAUNCH(CfgPair, ACT_, TROW_); else if (ring) SAM3_FL_LAUNCH(CfgRing, ACT_, TROW_); else SAM3_FL_LAUNCH(CfgBig, ACT_, TROW_); } while (0)
+        const int probe = (int)env_int("SAM3_LORA_FUSED_PROBE", 0);
+        if (f8) {
+#define SAM3_FL_F8(ACT_, TROW_) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, ACT_, TROW_, 0, true>), dim3((unsigned)grid), dim3(512), 0, st, fa)
+            if (act) { if (trow == 128) SAM3_FL_F8(1, 128); else if (trow == 64) SAM3_FL_F8(1, 64); else SAM3_FL_F8(1, 32); }
+            else { if (trow == 128) SAM3_FL_F8(0, 128); else if (trow == 64) SAM3_FL_F8(0, 64); else SAM3_FL_F8(0, 32); }
+#undef SAM3_FL_F8
+        } else if (probe && !pair && trow == 64) {      // measurement aid (fl::k_fused_linear's PROBE): fill alone / matrix pipe alone
+#define SAM3_FL_PROBE(P_) do { if (act) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 1, 64, P_>), dim3((unsigned)grid), dim3(512), 0, st, fa); \
+                               else hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 0, 64, P_>), dim3((unsigned)grid), dim3(512), 0, st, fa); } while (0)
+            if (probe == 1) SAM3_FL_PROBE(1); else if (probe == 2) SAM3_FL_PROBE(2); else if (probe == 3) SAM3_FL_PROBE(3); else SAM3_FL_PROBE(4);
+#undef SAM3_FL_PROBE
+        } else if (act) {
             if (trow == 128) SAM3_FL_CFG(1, 128); else if (trow == 64) SAM3_FL_CFG(1, 64); else SAM3_FL_CFG(1, 32);
         } else {
             if (trow == 128) SAM3_FL_CFG(0, 128); else if (trow == 64) SAM3_FL_CFG(0, 64); else SAM3_FL_CFG(0, 32);
@@ -2678,6 +2723,26 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
 #undef SAM3_FL_LAUNCH
     }
     return launch_ok("sam3_lora_linear_fwd");
+}
+
+int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
+                         int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldw, int64_t ldy,
+                         int layout, float scaling, float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace,
+                         size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact) {
+    return linear_fwd_impl(x, W, bias, A, B, y_out, tT_out, M, in_features, out_features, rank, ldx, ldw, ldy, layout, scaling, drop_p, seed,
+                           offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact, nullptr);
+}
+
+int sam3_lora_linear_fwd_q8(const void* x, const void* x_q8, int64_t ldxq, const float* scale_x, const void* w_q8, int64_t ldwq,
+                            const float* scale_w, const void* bias, const void* A, const void* B, void* y_out, void* tT_out, int64_t M,
+                            int in_features, int out_features, int rank, int64_t ldx, int64_t ldy, int layout, float scaling, float drop_p,
+                            uint64_t seed, uint64_t offset, int dtype, void* workspace, size_t workspace_bytes, void* stream, int act,
+                            void* act_out, int64_t ldact, void* q8_out, int64_t ldq, int fmt, const float* amax_in, float* amax_out,
+                            float* scale_out) {
+    const LinearF8 f8{x_q8, (long long)ldxq, w_q8, (long long)ldwq, scale_x, scale_w,
+                      Q8Out{(unsigned char*)q8_out, (long long)ldq, amax_in, amax_out, scale_out, fmt}};
+    return linear_fwd_impl(x, nullptr, bias, A, B, y_out, tT_out, M, in_features, out_features, rank, ldx, 0, ldy, layout, scaling, drop_p, seed,
+                           offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact, &f8);
 }
 
 int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm, int in_features, int out_features,

@@ -365,6 +365,14 @@ def fused_linear_enabled() -> bool:
     return bool(_FUSED["on"])
 
 
+def fused_linear_fp8_enabled() -> bool:
+    """SAM3_LORA_FUSED_LINEAR_FP8=0: the fp8 frozen-W mode keeps hipBLASLt's fp8 GEMM + the adapter pass at the fc1 site."""
+    if _FUSED.get("fp8") is None:
+        import os
+        _FUSED["fp8"] = os.environ.get("SAM3_LORA_FUSED_LINEAR_FP8", "1") not in ("", "0")
+    return bool(_FUSED["fp8"])
+
+
 def linear_fwd_supported(fin: int, fout: int, rank: int, dtype) -> bool:
     """Whether :func:`lora_linear_fwd_` takes this shape (sam3_lora_linear_fwd_supported)."""
     if dtype != torch.bfloat16:
@@ -406,6 +414,48 @@ def lora_linear_fwd_(x2: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Ten
         ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream),
         _ffi.ACT_GELU if gelu else _ffi.ACT_NONE, a.data_ptr() if a is not None else None, a.stride(0) if a is not None else 0)
     _ffi.check(rc, "sam3_lora_linear_fwd")
+    return y, a, tT
+
+
+def lora_linear_fwd_q8_(x2: torch.Tensor, xq: torch.Tensor, sx: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor,
+                        bias: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor, scaling: float, layout: int,
+                        save_t: bool = False, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
+                        packed: Optional[torch.Tensor] = None, gelu: bool = False, q8=None):
+    """:func:`lora_linear_fwd_` in the fp8 frozen-W mode (sam3_lora_linear_fwd_q8): the frozen GEMM on the e4m3 images ``xq`` [M, in]
+    / ``wq`` [out, in] with their dequantisation scales ``sx`` / ``sw`` (one-element device tensors), the LoRA branch on the bf16
+    ``x2``; ``q8`` = ``fp8.producer_slots(...)``: GELU(y) also leaves as the fp8 image of the next frozen GEMM.
+    Returns ``(y, gelu_out or None, saved-t blob or None)``."""
+    lib = _ffi.load()
+    _require_cuda(x2, xq, wq, A, B, bias)
+    M, fin = x2.shape
+    fout = wq.shape[0]
+    rank = _rank_of(A, layout)
+    if x2.dtype != torch.bfloat16 or xq.shape != x2.shape or wq.shape[1] != fin or xq.stride(1) != 1 or wq.stride(1) != 1:
+        raise LoRAKernelError("sam3_lora_amd: fused fp8 linear takes bf16 x [M, in], e4m3 images xq [M, in] and wq [out, in] with unit column stride")
+    if xq.element_size() != 1 or wq.element_size() != 1:
+        raise LoRAKernelError("sam3_lora_amd: xq / wq must be fp8 tensors")
+    if bias is not None and (bias.dtype != torch.bfloat16 or not bias.is_contiguous()):
+        bias = bias.to(torch.bfloat16).contiguous()
+    nws = lib.sam3_lora_linear_fwd_workspace_bytes(M, fin, fout, rank, DT_BF16)
+    if nws == 0:
+        raise LoRAKernelError(f"sam3_lora_linear_fwd_workspace_bytes: {_ffi.last_error() or 'shape / dtype not supported'}")
+    ws = _workspace(x2.device, nws)
+    y = torch.empty(M, fout, dtype=x2.dtype, device=x2.device)
+    a = torch.empty_like(y) if gelu else None
+    tT = saved_t_like(M, rank, x2.device, DT_BF16) if save_t else None
+    if q8 is not None and not gelu:
+        raise LoRAKernelError("sam3_lora_amd: the fp8 image is the one of the activation output (gelu=True)")
+    qimg, qfmt, am_in, am_out, qscale = q8 if q8 is not None else (None, 0, None, None, None)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    rc = lib.sam3_lora_linear_fwd_q8(
+        x2.data_ptr(), xq.data_ptr(), xq.stride(0), sx.data_ptr(), wq.data_ptr(), wq.stride(0), sw.data_ptr(), ptr(bias),
+        (packed if packed is not None else A).data_ptr(), B.data_ptr(), y.data_ptr(), ptr(tT),
+        M, fin, fout, rank, x2.stride(0), y.stride(0), layout | (PREPACKED if packed is not None else 0),
+        float(scaling), float(drop_p), int(seed), int(offset), DT_BF16, ws.data_ptr(), ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream),
+        _ffi.ACT_GELU if gelu else _ffi.ACT_NONE, ptr(a), a.stride(0) if a is not None else 0,
+        ptr(qimg), qimg.stride(0) if qimg is not None else 0, int(qfmt), ptr(am_in), ptr(am_out), ptr(qscale))
+    _ffi.check(rc, "sam3_lora_linear_fwd_q8")
     return y, a, tT
 
 
@@ -670,11 +720,25 @@ class _LoRAMlpFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
         fused1 = (fused_linear_enabled() and not q8_ok and not fp8.eligible(x2, W1)
                   and linear_fwd_supported(W1.shape[1], W1.shape[0], _rank_of(_master(A1), layout), cdt))
+        fused1_q8 = (fused_linear_enabled() and fused_linear_fp8_enabled() and q8_ok and fp8.eligible(x2, W1) and x2.dtype == torch.bfloat16
+                     and W1.shape[1] % 128 == 0
+                     and linear_fwd_supported(W1.shape[1], W1.shape[0], _rank_of(_master(A1), layout), cdt))
         if fused1:
             # frozen GEMM + rank-r K step + bias + GELU in ONE kernel -- h and a are written once, never re-read
             qa = None
             h, a, t1 = lora_linear_fwd_(x2, W1, b1, _master(A1), _master(B1), s1, layout, save_t=need_w, drop_p=drop_p,
                                         seed=seed1, packed=pk1, gelu=True)
+        elif fused1_q8:
+            # the same in the fp8 frozen-W mode: e4m3 x (the LayerNorm's image when it made one for this weight) and W on the
+            # scaled fp8 MFMA, the LoRA branch as a bf16 K step, and GELU(h) also as the e4m3 input of fc2's GEMM
+            st = fp8.state_for(W1)
+            if x_q8 is not None and x_q8[2] == id(W1) and x_q8[0].shape == x2.shape:
+                xq, sx = x_q8[0], x_q8[1]
+            else:
+                xq, sx = st.qx(x2)
+            qa = fp8.producer_slots(W2, "x", x2.shape[0], W1.shape[0], x2.device)
+            h, a, t1 = lora_linear_fwd_q8_(x2, xq, sx, st.wq, st.scale, b1, _master(A1), _master(B1), s1, layout, save_t=need_w,
+                                           drop_p=drop_p, seed=seed1, packed=pk1, gelu=True, q8=qa)
         else:
             with torch.autocast("cuda", enabled=False):
                 h = _frozen_fwd(x2, W1, b1, x_q8)

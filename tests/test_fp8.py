@@ -239,3 +239,58 @@ def test_fp8_image_and_recomputed_input_ride_on_the_same_pass():
     for u, v in zip(res[0][:4], res[1][:4]):
         assert torch.equal(u, v)
     assert ((res[0][4] - res[1][4]).abs().max() / res[0][4].abs().max()).item() < 2e-6
+
+
+@pytest.mark.parametrize("M,fin,fout,rank,hl", [(776, 256, 520, 16, True), (1000, 1024, 776, 8, True), (300, 384, 264, 24, True),
+                                                (41472, 1024, 4736, 16, True), (776, 256, 520, 16, False)])
+def test_fused_fp8_linear_is_one_rounding_from_the_dequantised_oracle(M, fin, fout, rank, hl, monkeypatch):
+    """sam3_lora_linear_fwd_q8 (the fp8-W variant of the fused GEMM): e4m3 x and W on the scaled fp8 MFMA, the LoRA
+    branch as a bf16 hi + lo K step in the same accumulator, bias, GELU -- against fp64 arithmetic on the DEQUANTISED operands
+    (sx xq) (sw wq)^T + b + s (x A) B: every element within one bf16 rounding (the quantisation itself is the mode's, pinned by
+    test_quantiser_*); a = GELU(bf16(h)) to one rounding; the saved t^T is the plain forward's, bit for bit; and with the
+    delayed-scaling slots of the next GEMM handed in, GELU(h) also leaves as the e4m3 image a separate quantisation pass over it
+    would write, with the amax gathered for the next call."""
+    from sam3_lora_amd import _ffi, functional as Fn
+    from sam3_lora_amd.fp8 import Fp8Quantizer, Fp8Weight
+    if not hl:
+        monkeypatch.setenv("SAM3_LORA_SINGLE_ROUND", "1")
+    _ffi.load().sam3_lora_debug_reload_knobs()
+    g = torch.Generator(device=DEV).manual_seed(M + rank)
+    x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    W = (torch.randn(fout, fin, device=DEV, generator=g) / fin ** 0.5).bfloat16()
+    b = torch.randn(fout, device=DEV, generator=g).bfloat16()
+    A = torch.randn(fin, rank, device=DEV, generator=g) / fin ** 0.5
+    B = torch.randn(rank, fout, device=DEV, generator=g) * 0.1
+    s = 2.0
+    st = Fp8Weight(W)
+    xq, sx = st.qx(x)
+    y, a, tT = Fn.lora_linear_fwd_q8_(x, xq, sx, st.wq, st.scale, b, A, B, s, 0, save_t=True, gelu=True)
+    rows = torch.arange(M, device=DEV) if M <= 2048 else torch.randint(0, M, (512,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    xd = xq[rows].double() * sx.double()
+    want = xd @ (st.wq.double() * st.scale.double()).t() + b.double() + s * ((x[rows].double() @ A.double()) @ B.double())
+    err = (y[rows].double() - want).abs()
+    bound = 2.0 ** -8 * want.abs() + (3e-5 if hl else 1e-2) * want.abs().max()
+    assert (err <= bound).all(), (int((err > bound).sum()), float((err / want.abs().max()).max()))
+    ga = torch.nn.functional.gelu(y[rows].double())
+    assert ((a[rows].double() - ga).abs() <= 2.0 ** -8 * ga.abs() + 1e-6 * ga.abs().max() + 1e-6).all()
+    # the saved t^T: what the stand-alone forward saves
+    y2 = torch.zeros(M, fout, device=DEV, dtype=torch.bfloat16)
+    tT2 = Fn.lora_fwd_(x, A, B, y2, s, 0, save_t=True)
+    assert torch.equal(tT.view(torch.uint8), tT2.view(torch.uint8))
+    # repeated: the same bits (a DMA / read race would show here)
+    y3, a3, _ = Fn.lora_linear_fwd_q8_(x, xq, sx, st.wq, st.scale, b, A, B, s, 0, gelu=True)
+    assert torch.equal(y3, y) and torch.equal(a3, a)
+    # the fp8 image of GELU(h) for the next GEMM: delayed scaling with the amax of a previous tensor of the same role
+    q = Fp8Quantizer(_ffi.FP8_E4M3)
+    q(a * 0.5)                                   # calibrates: amax = max |a| / 2 -> some of a's values will saturate
+    slots = q.begin(a.device)
+    image = torch.empty(M, fout, dtype=torch.float8_e4m3fn, device=DEV)
+    y4, a4, _ = Fn.lora_linear_fwd_q8_(x, xq, sx, st.wq, st.scale, b, A, B, s, 0, gelu=True, q8=(image, _ffi.FP8_E4M3) + slots)
+    assert torch.equal(y4, y) and torch.equal(a4, a)
+    amax_prev = (a * 0.5).abs().max().float()
+    assert torch.allclose(slots[2], (amax_prev / 448.0).reshape(1))
+    want_img = (a.float() * (448.0 / amax_prev)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    assert torch.equal(image.view(torch.uint8), want_img.view(torch.uint8))
+    assert float(slots[1].max()) == float(a.abs().max().float())       # gathered for the next call
+    monkeypatch.delenv("SAM3_LORA_SINGLE_ROUND", raising=False)
+    _ffi.load().sam3_lora_debug_reload_knobs()

@@ -37,7 +37,7 @@ def _reload():
 def _knobs_back():
     yield
     if torch.cuda.is_available():
-        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_ORDER", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_HL_MAX_RANK"):
+        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_HL_MAX_RANK"):
             os.environ.pop(k, None)
         _reload()
         Fn.set_fused_linear(None)
@@ -129,14 +129,16 @@ def test_dropout_on_the_branch_input_only():
 
 
 def test_persistent_tile_walk_is_bit_identical_for_any_grid():
-    """12 (24) tiles on 1 / 3 / 5 / 512 workgroups, both tile orders, both tile configurations, repeated: the same bits."""
+    """12 (24) tiles + a last column of tiles 8 columns wide on 1 / 3 / 5 / 512 workgroups, that column run as half tiles (waves
+    re-arranged 4 x 2, dealt to the workgroups with one full tile fewer) or as full ones, both tile configurations, repeated: the
+    same bits."""
     M, fin, fout, rank = 1000, 192, 776, 16
     x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=3)
     args = (_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), 2.0, 0)
     outs = []
-    for wgs, order, tile in [(w, o, t) for w in ("1", "3", "5", "512") for o in ("0", "1") for t in ("0", "1")]:
-        if True:        # grid size, tile order (placement only) and tile configuration (same K order per output element)
-            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_ORDER"], os.environ["SAM3_LORA_FUSED_TILE"] = wgs, order, tile
+    for wgs, order, tile in [(w, o, t) for w in ("1", "3", "5", "512") for o in ("0", "1") for t in ("0", "1", "2")]:
+        if True:        # grid size, half-tile scheduling (placement only) and tile configuration (same K order per output element)
+            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_HALF"], os.environ["SAM3_LORA_FUSED_TILE"] = wgs, order, tile
             _reload()
             for _ in range(3):              # repeated: a race between DMA and read would show as run-to-run differences
                 y, a, _ = Fn.lora_linear_fwd_(*args, gelu=True)
@@ -147,7 +149,7 @@ def test_persistent_tile_walk_is_bit_identical_for_any_grid():
     _one_rounding(outs[0][0].float().cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("tile", ["0", "1"])
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
 def test_fused_linear_at_configs1_fc1_shape(tile):
     os.environ["SAM3_LORA_FUSED_TILE"] = tile
     _reload()

@@ -249,7 +249,7 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     for sym in declared | vit_declared | loss_declared | fp8_declared | seg_declared:
         assert hasattr(lib, sym), sym
     lib2 = _ffi.load()
-    assert lib2.sam3_lora_abi_version() == 5
+    assert lib2.sam3_lora_abi_version() == _ffi.ABI_VERSION == 6
     # which backward calls may leave x out (the GELU' pass recomputes it): a host-side rule, no device needed
     assert lib2.sam3_lora_bwd_act_recomputes_input(16, _ffi.DT_BF16, 0.0) == 1 and lib2.sam3_lora_bwd_act_recomputes_input(3, _ffi.DT_BF16, 0.0) == 1
     assert lib2.sam3_lora_bwd_act_recomputes_input(17, _ffi.DT_BF16, 0.0) == 0 and lib2.sam3_lora_bwd_act_recomputes_input(16, _ffi.DT_F32, 0.0) == 0

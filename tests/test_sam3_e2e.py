@@ -446,7 +446,7 @@ def test_wide_training_step_fp32_matches_reference(gold_wide):
 GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_full.npz")
 
 
-def _full_size_step(layout):
+def _full_size_step(layout, islands=None, holes=None, post_layout=None):
     """One training step at the REAL model size through this library on the GPU, `layout` = "fp32" (exact-fp32 adapters) or "bf16"
     (vit.to_training_layout: exactly what bench.py runs -- bf16 frozen tensors and activations, fp32 A/B, the default fp32
     islands, fused fc1, hi + lo operands); returns the error record against e2e_full.npz.  The REAL model size (e2e_case_defs.FULL = sam3/model_builder.py:69-187,486-495: 1008^2 input, 72 x 72 tokens, depth-32
@@ -472,10 +472,13 @@ def _full_size_step(layout):
     model.to(dev).train()
     if layout == "bf16":
         from sam3_lora_amd.vit import DEFAULT_FP32_ISLANDS, to_training_layout
-        to_training_layout(model)
-        assert tuple(model._sam3_fp32_islands) == tuple(DEFAULT_FP32_ISLANDS)
-        assert model.backbone.vision_backbone.trunk.blocks[0].mlp.fc1.original_layer.weight.dtype == torch.bfloat16
+        to_training_layout(model, fp32_islands=islands, fp32_holes=holes)
+        if islands is None:
+            assert tuple(model._sam3_fp32_islands) == tuple(DEFAULT_FP32_ISLANDS)
+            assert model.backbone.vision_backbone.trunk.blocks[0].mlp.fc1.original_layer.weight.dtype == torch.bfloat16
         assert layers[next(iter(layers))].lora_A.dtype == torch.float32
+        if post_layout is not None:
+            post_layout(model)
     # the batch: the first sample at 1008^2 (the generator's first draw), 2 boxes + rectangular masks
     res = D.FULL_RES
     (text, boxes), img = D.FULL_SAMPLES[0], D.make_images_res(res)[0]
@@ -520,7 +523,9 @@ def _full_size_step(layout):
             node, parts = out["aux_outputs"][int(parts[0][3:])], parts[1:]
         if parts[0] == "indices":
             got = torch.stack([node["indices"][0], node["indices"][1]]).cpu().numpy()
-            rec["indices_equal"] = rec.get("indices_equal", True) and bool(np.array_equal(got, gold[k]))
+            same = bool(np.array_equal(got, gold[k]))
+            rec["indices_equal"] = rec.get("indices_equal", True) and same
+            rec.setdefault("outputs_with_different_matching", []).extend([] if same else ["/".join(k.split("/")[1:-1]) or "final"])
             n_idx += 1
             continue
         rec["outputs"]["/".join(k.split("/")[1:])] = err(node[parts[0]], gold[k])
@@ -562,8 +567,9 @@ def test_full_size_training_step_bf16_layout_against_reference():
     against the reference's fp32 CPU step at that size (e2e_full.npz).  The bar is the reference's OWN mixed-precision mode at
     the same size -- its model under torch.autocast(bf16), ``sam3_lora/train/native_trainer.py:992``, against its fp32 run:
     ref_autocast_bf16.json["full"], written by ``make_e2e_golden.py full --yardstick`` (logits 3.5e-2, boxes 5.3e-2, presence
-    1.6e-2, masks 2.8e-2, loss 1.5e-2, A/B gradients worst 0.26 / median 0.13 over the 64 adapters).  Matcher indices of all
-    six outputs bit-exact; every output class, the loss and the worst A/B gradient within 1.0x of that yardstick."""
+    1.6e-2, masks 2.8e-2, loss 1.5e-2, A/B gradients worst 0.26 / median 0.13 over the 64 adapters; and its matching
+    differs from its own fp32 forward's in 1 of the 6 outputs).  Every output class, the loss, the worst A/B gradient and the number
+    of re-matched outputs within 1.0x of that yardstick; the exact-fp32 layout (the test above) is the one that is bit-exact."""
     rec = _full_size_step("bf16")
     yard = _yardstick("full")
     rec["reference_autocast_bf16_vs_its_fp32"] = yard
@@ -572,7 +578,9 @@ def test_full_size_training_step_bf16_layout_against_reference():
                       "pred_masks": cls("pred_masks"), "core_loss": rec["loss_terms"]["core_loss"],
                       "worst_AB_grad_full4": max(rec["grads_full"].values()), "worst_AB_grad_sampled60": rec["grads_sampled_worst"]}
     _record("full_bf16", rec)
-    assert rec["indices_equal"], "matcher indices differ from the reference's at full size"
+    # the assignment: the reference's own autocast forward re-matches `outputs_with_different_matching` of its 6 outputs at this size
+    # (1: near-tied costs under a 3e-2 move of the logits); this build may not flip more than that
+    assert len(rec["outputs_with_different_matching"]) <= int(yard["outputs_with_different_matching"]), rec["outputs_with_different_matching"]
     sm = rec["summary"]
     assert sm["pred_logits"] <= yard["pred_logits"], (sm, yard)
     assert sm["pred_boxes"] <= yard["pred_boxes"], (sm, yard)
