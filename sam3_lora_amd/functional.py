@@ -365,6 +365,12 @@ def fused_linear_enabled() -> bool:
     return bool(_FUSED["on"])
 
 
+def set_fused_linear_fp8(on: Optional[bool]) -> None:
+    """fp8 frozen-W mode: route the fc1 -> GELU site through ``sam3_lora_linear_fwd_q8`` (on, the default) or through hipBLASLt's
+    fp8 GEMM + ``sam3_lora_fwd_act_q8`` (off); ``None`` restores the environment default (SAM3_LORA_FUSED_LINEAR_FP8)."""
+    _FUSED["fp8"] = on
+
+
 def fused_linear_fp8_enabled() -> bool:
     """SAM3_LORA_FUSED_LINEAR_FP8=0: the fp8 frozen-W mode keeps hipBLASLt's fp8 GEMM + the adapter pass at the fc1 site."""
     if _FUSED.get("fp8") is None:

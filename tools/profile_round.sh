@@ -16,6 +16,9 @@ rocprofv3 --kernel-trace --stats -d /tmp/p_full -o bench -- $F > "$OUT/full.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -o bench -- $A > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -o bench -- $A > "$OUT/write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_mfma -o bench -- $A > "$OUT/mfma.log" 2>&1
+B="python $R/tools/block_traffic_run.py"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_bfetch -o bench -- $B > "$OUT/bfetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_bwrite -o bench -- $B > "$OUT/bwrite.log" 2>&1
 cd "$R"
 db() { find "$1" -name '*.db' | head -1; }
 python tools/rocpd_summary.py stats "$(db /tmp/p_stats)" > "$OUT/${TAG}_kernel_stats.txt"
@@ -24,6 +27,7 @@ python tools/rocpd_summary.py gaps "$(db /tmp/p_full)" > "$OUT/${TAG}_fullstep_i
 python tools/rocpd_summary.py pmc "$(db /tmp/p_fetch)" > "$OUT/${TAG}_pmc_fetch.txt"
 python tools/rocpd_summary.py pmc "$(db /tmp/p_write)" > "$OUT/${TAG}_pmc_write.txt"
 python tools/rocpd_summary.py traffic "$(db /tmp/p_fetch)" "$(db /tmp/p_write)" > "$OUT/${TAG}_traffic.json"
+python tools/rocpd_summary.py block_traffic "$(db /tmp/p_bfetch)" "$(db /tmp/p_bwrite)" 24 > "$OUT/${TAG}_block_traffic.json"
 Q=$(db /tmp/p_mfma); [ -n "$Q" ] && python tools/rocpd_summary.py pmc "$Q" > "$OUT/${TAG}_pmc_mfma.txt"
 cp "$OUT/bench.json" "$OUT/${TAG}_bench.json"
 rm -f "$OUT"/*.log

@@ -186,5 +186,29 @@ def traffic(db_fetch, db_write):
     print(json.dumps(out, indent=1))
 
 
+def block_traffic(db_fetch, db_write, n_blocks):
+    """HBM bytes of ONE block's forward + backward adapter calls: every dispatch of this library's kernels in the two PMC passes over
+    tools/block_traffic_run.py (the operand repack k_pack excluded: it runs once per optimizer step for the whole model), summed and
+    divided by the number of block passes the command ran.  Same corrections as `traffic`."""
+    import json
+    n_blocks = int(n_blocks)
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    by_k = {}
+    for db, cn in ((db_fetch, "FETCH_SIZE"), (db_write, "WRITE_SIZE")):
+        cur = sqlite3.connect(db).cursor()
+        for name, v in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (cn,)):
+            k = short(name)
+            if not (k.startswith("k_") or k.startswith("fl::")) or k.startswith("k_pack"):
+                continue
+            tot[cn] += v
+            by_k.setdefault(k[:60], {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})[cn] += v
+    per = lambda d: int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 / n_blocks)
+    print(json.dumps({"hbm_bytes_per_block": per(tot), "fetch_kib_per_block": round(tot["FETCH_SIZE"] / n_blocks, 1),
+                      "write_kib_per_block": round(tot["WRITE_SIZE"] / n_blocks, 1), "block_passes": n_blocks,
+                      "by_kernel_bytes_per_block": {k: per(d) for k, d in sorted(by_k.items(), key=lambda kv: -per(kv[1]))},
+                      "what": "fwd + bwd of one ViT block's two adapters (plain entry points, M = 41,472, r = 16): 2 x FETCH_SIZE + WRITE_SIZE "
+                              "(KiB, separate rocprofv3 --pmc passes over tools/block_traffic_run.py), k_pack excluded"}, indent=1))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "stats_all": stats_all, "gaps": gaps, "pmc": pmc, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "stats_all": stats_all, "gaps": gaps, "pmc": pmc, "traffic": traffic, "block_traffic": block_traffic}[sys.argv[1]](*sys.argv[2:])
