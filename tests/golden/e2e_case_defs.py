@@ -96,7 +96,26 @@ def toy_tokenizer_32(texts, context_length=32):
     return toy_tokenizer(texts, context_length=context_length)
 
 
+def lora_section_of(yaml_name):
+    """The ``lora:`` section of one of THIS repository's configs/*.yaml as LoRAConfig keyword arguments (the ten keys the reference's
+    CLI requires, train_sam3_lora_native.py:716-731) -- the generator feeds it to the reference's injector, the test to this library's."""
+    import os
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sec = yaml.safe_load(open(os.path.join(root, "configs", yaml_name)))["lora"]
+    keys = ("rank", "alpha", "dropout", "target_modules", "apply_to_vision_encoder", "apply_to_text_encoder", "apply_to_geometry_encoder",
+            "apply_to_detr_encoder", "apply_to_detr_decoder", "apply_to_mask_decoder")
+    return {k: sec[k] for k in keys}
+
+
+# Whole-step fixtures of the two BASELINE configurations the benchmark does not time, on the WIDE model's dimensions with the adapters
+# taken from the YAML files themselves: configs[3] = configs/large_r32_config.yaml (r = 32, alpha = 64 on the trunk's fc1 / fc2, the text
+# tower's c_fc / c_proj and the DETR layers' linear1 / linear2) and configs[0] = configs/minimal_lora_config.yaml (r = 4 on the vision
+# encoder's fc1 / fc2 only).
+YAML_CASES = {"wide_large_r32": "large_r32_config.yaml", "wide_minimal_r4": "minimal_lora_config.yaml"}
 CONFIGS = {"tiny": (TINY, RES, LORA, LR), "wide": (WIDE, WIDE_RES, LORA_WIDE, LR_WIDE), "full": (FULL, FULL_RES, LORA_FULL, LR_WIDE)}
+for _name, _yaml in YAML_CASES.items():
+    CONFIGS[_name] = (WIDE, WIDE_RES, lora_section_of(_yaml), LR_WIDE)
 
 
 def seeded_parameter(name: str, shape) -> torch.Tensor:

@@ -359,7 +359,7 @@ def main():
         losses.append(total.item())
     res["losses"] = np.array(losses, np.float64)
     if which != "tiny":         # the big per-query mask tensors are pinned by the tiny fixture; keep this one small
-        for k in [k for k in res if k.endswith(("pred_masks", "pred_masks_o2m", "encoder_hidden_states"))]:
+        for k in [k for k in res if k.endswith(("pred_masks", "pred_masks_o2m", "encoder_hidden_states")) and not k.startswith("ref_autocast_bf16/")]:
             res[k] = res[k][:, :4] if res[k].ndim == 4 else res[k][::8]
     if full:                    # 1008^2 image and masks: the test rebuilds the image from its seed; masks at 4 queries, every 4th pixel
         del res["batch/img_batch"]

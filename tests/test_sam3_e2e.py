@@ -443,6 +443,74 @@ def test_wide_training_step_fp32_matches_reference(gold_wide):
     assert max(m["loss_curve_rel"]) <= 1e-3, (m["losses"], m["loss_curve_rel"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", sorted(D.YAML_CASES))
+def test_yaml_configurations_whole_step_matches_reference(case, layout):
+    """BASELINE configs[3] and configs[0] as WHOLE training steps: the adapters come from this repository's YAML files themselves --
+    configs/large_r32_config.yaml (r = 32, alpha = 64 on the trunk's fc1 / fc2, the text tower's c_fc / c_proj, the DETR layers'
+    linear1 / linear2: 34 modules on the wide model) and configs/minimal_lora_config.yaml (r = 4 on the vision encoder's fc1 / fc2: 16
+    modules) -- loaded by the trainer's own config reader and injected by this library's ``apply_lora_to_model``; the fixtures
+    (tests/golden/e2e_wide_large_r32.npz / e2e_wide_minimal_r4.npz) are the reference's injector + model + loss + AdamW on the same
+    YAML section (make_e2e_golden.py <case>).  Injection manifest identical; fp32 layout: outputs, loss terms, A/B gradients, four-step
+    loss curve at north_star's 1e-3 (gradients 5e-3), matcher indices bit-exact; bf16 layout: within the reference's own
+    autocast(bf16) deviation for this configuration (ref_autocast_bf16.json)."""
+    from sam3_lora_amd.trainer import load_config, lora_config_from, move_to_device
+    gold = np.load(os.path.join(os.path.dirname(GOLD), f"e2e_{case}.npz"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = lora_config_from(load_config(os.path.join(root, "configs", D.YAML_CASES[case])))
+    assert cfg.to_dict()["rank"] == D.CONFIGS[case][2]["rank"] and sorted(cfg.target_modules) == sorted(D.CONFIGS[case][2]["target_modules"])
+    dev = torch.device("cuda")
+    model = build_wide(gold, act_checkpoint=False, match_in_forward=False)
+    layers = _inject(model, gold, D.CONFIGS[case][2])            # asserts the reference's module manifest
+    assert len(layers) == {"wide_large_r32": 34, "wide_minimal_r4": 16}[case]
+    model.to(dev).train()
+    if layout == "bf16":
+        from sam3_lora_amd.vit import to_training_layout
+        to_training_layout(model)
+    m = run_training_steps(model, layers, gold, move_to_device(make_batch_wide(), dev), D.STEPS, D.CONFIGS[case][3], D.WD)
+    _record(f"{case}_{layout}", m)
+    assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
+    assert len(m["grads"]) >= (6 if case == "wide_large_r32" else 4)
+    if layout == "fp32":
+        assert m["indices_equal"]
+        assert max(m["outputs"].values()) <= 1e-3, m["outputs"]
+        assert max(m["loss_terms"].values()) <= 1e-3, m["loss_terms"]
+        assert max(m["grads"].values()) <= 5e-3, m["grads"]
+        assert max(m["loss_curve_rel"]) <= 1e-3, (m["losses"], m["loss_curve_rel"])
+        return
+    yard = _yardstick(case)
+    logit_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_logits"))
+    box_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes"))
+    # (this configuration's yardstick, floored at the wide fixture's: two of its entries are this small by luck of one run)
+    floor = _yardstick("wide")
+    lim = lambda k, mult=1.0: mult * max(yard[k], floor[k])
+    assert logit_err <= lim("pred_logits") and box_err <= lim("pred_boxes"), (logit_err, box_err, yard)
+    assert m["outputs"]["presence_logit_dec"] <= lim("presence_logit_dec") and m["outputs"]["pred_masks"] <= lim("pred_masks", 2.0), (m["outputs"], yard)
+    assert m["loss_terms"]["core_loss"] <= lim("core_loss"), (m["loss_terms"]["core_loss"], yard)
+    assert all(np.isfinite(m["losses"]))
+
+
+@pytest.mark.parametrize("case", sorted(D.YAML_CASES))
+def test_yaml_configurations_inject_the_references_modules(case):
+    """No GPU: the YAML files of BASELINE configs[3] / configs[0] through the trainer's config reader and this library's root
+    injector adapt exactly the modules the reference's injector adapted (names and order), with the reference's parameter count."""
+    from sam3_lora_amd import lora_layers as L
+    from sam3_lora_amd.trainer import load_config, lora_config_from
+    gold = np.load(os.path.join(os.path.dirname(GOLD), f"e2e_{case}.npz"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = lora_config_from(load_config(os.path.join(root, "configs", D.YAML_CASES[case])))
+    model = build_wide(gold)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        L.apply_lora_to_model(model, cfg)
+    names = [n for n, m in model.named_modules() if isinstance(m, L.LoRALinear)]
+    assert names == [str(n) for n in gold["lora_module_names"]]
+    stats = L.count_parameters(model)
+    want = sum(m.lora.lora_A.numel() + m.lora.lora_B.numel() for m in model.modules() if isinstance(m, L.LoRALinear))
+    assert stats["trainable_parameters"] == want and all(p.requires_grad == ("lora_" in n) for n, p in model.named_parameters())
+
+
 GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_full.npz")
 
 
