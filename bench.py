@@ -1217,13 +1217,15 @@ def parity_gates(dev, args):
               "pred_masks": cls("pred_masks"), "core_loss": rec["loss_terms"]["core_loss"],
               "worst_AB_grad": max(max(rec["grads_full"].values()), rec["grads_sampled_worst"]),
               "outputs_with_different_matching": len(rec["outputs_with_different_matching"]), "outputs_matched": 6}
-        ok = (sm["pred_logits"] <= yard["pred_logits"] and sm["pred_boxes"] <= yard["pred_boxes"] and sm["presence_logit_dec"] <= yard["presence_logit_dec"]
+        S = T.FULL_BF16_SLACK        # the test's bars (run-to-run spread of both sides: tests/test_sam3_e2e.py)
+        ok = (sm["pred_logits"] <= S * yard["pred_logits"] and sm["pred_boxes"] <= S * yard["pred_boxes"] and sm["presence_logit_dec"] <= S * yard["presence_logit_dec"]
               and sm["pred_masks"] <= 2 * yard["pred_masks"] and sm["core_loss"] <= max(yard["core_loss"], 1e-3)
               and sm["worst_AB_grad"] <= yard["worst_AB_grad"] and sm["outputs_with_different_matching"] <= yard["outputs_with_different_matching"])
         gates["full_size_step_vs_reference"] = dict(sm, reference_autocast_bf16_vs_its_fp32=yard, **{"pass": bool(ok)}, what=(
             "one training step of the reference's fp32 CPU run at the REAL model size (tests/golden/e2e_full.npz: depth 32, 1008^2, 64 adapters, "
             "one image) re-run here in the layout this line times: max-abs error over max|ref| per output class, loss and worst A/B gradient, "
-            "outputs (final + 5 auxiliary) whose Hungarian matching differs; bar = the reference's own autocast(bf16) deviation at that size"))
+            "outputs (final + 5 auxiliary) whose Hungarian matching differs; bar = the reference's own autocast(bf16) deviation at that size "
+            "(x 1.5 on logits / boxes / presence, x 2 on masks: the bars of test_full_size_training_step_bf16_layout_against_reference)"))
         torch.cuda.empty_cache()
     except Exception as e:
         gates["full_size_step_vs_reference"] = {"error": f"{type(e).__name__}: {str(e)[:300]}", "pass": False}

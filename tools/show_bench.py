@@ -8,7 +8,7 @@ if "roofline" in d:
 if "step" in d.get("roofline", {}):
     print("whole step vs roofline", d["roofline"]["step"])
 for k in d.get("kernels", []):
-    print(f"  {k['kernel']:9s} dim={k['dim']:5d} n={k['launches']:4d} avg={k['avg_us']:8.2f} med={k['median_us']:8.2f} min={k['min_us']:8.2f} tot={k['total_us']:9.1f} {k['GBps']:7.1f} GB/s")
+    print(f"  {k['kernel']:9s} dim={k['dim']:5d} n={k['launches']:4d} avg={k['avg_us']:8.2f} med={k['median_us']:8.2f} min={k['min_us']:8.2f} tot={k['total_us']:9.1f} {(k['GBps'] or 0):7.1f} GB/s")
 for k in d.get("ops", []):
     print(f"  {k['op']:34s} {k['avg_us']:8.2f} us {k['GBps']:7.1f} GB/s frac {k['frac_of_peak']}")
 if "trunk_step" in d:
