@@ -259,7 +259,8 @@ def insitu_kernels(w, steps=2):
     e = w.x1[0].element_size()
     single = os.environ.get("SAM3_LORA_SINGLE_ROUND", "0") not in ("", "0")
     RG = 16 if r <= 16 else 32                                   # rank tile(s) of one group
-    RP = RG * (2 if (e == 2 and not single) else 1)              # bf16: t / gt travel as hi | lo pairs (2 RG columns)
+    hl_max = int(os.environ.get("SAM3_LORA_HL_MAX_RANK", "32") or 32)
+    RP = RG * (2 if (e == 2 and not single and r <= hl_max) else 1)     # bf16: t / gt travel as hi | lo pairs (2 RG columns)
     one_pass = r <= 16 and os.environ.get("SAM3_LORA_TWO_PASS_GY", "0") in ("", "0")
     names = {_ffi.STAGE_PACK: "k_pack", _ffi.STAGE_T1: "k_t1", _ffi.STAGE_T2: "k_t2",
              _ffi.STAGE_T3_GB: "k_t3+gt" if one_pass else "k_t3", _ffi.STAGE_T3_GA: "k_t3",
@@ -1265,7 +1266,7 @@ def overlap_measurement(full, world):
         full.backward_end_event = None
         buckets = [{"bucket": b, "origin": o, "bytes": 4 * (red.buckets[b][1] - red.buckets[b][0]),
                     "start_ms_after_backward_end": round(ev.elapsed_time(e0), 3), "end_ms_after_backward_end": round(ev.elapsed_time(e1), 3)}
-                   for (b, e0, e1), (_, o) in zip(red.launch_events, red.launch_log)]
+                   for (b, e0, e1, o) in red.launch_events]
     saved = red.overlap
     red.overlap = False
     exposed = run(3)

@@ -2564,22 +2564,35 @@ int sam3_lora_bwd_act_q8(const void* gy, const void* x, const void* tT_saved, co
 }
 
 // ---- the adapter inside the frozen GEMM (fused_linear.inc)
-static int fused_cu_count() {
-    static std::atomic<int> n{0};
-    int v = n.load(std::memory_order_relaxed);
-    if (v == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        v = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ? prop.multiProcessorCount : 256;
-        n.store(v, std::memory_order_relaxed);
+// per-device facts the persistent kernel needs: CU count (grid size) and whether a workgroup may hold all 160 KB of LDS (gfx950).
+// Cached per device ordinal of the CURRENT device at each call: a process may drive several devices.
+struct FusedDevInfo {
+    std::atomic<int> cus{0}, lds_ok{-1};
+};
+static FusedDevInfo g_fused_dev[64];
+static FusedDevInfo* fused_dev_info() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    FusedDevInfo* d = &g_fused_dev[dev];
+    if (d->cus.load(std::memory_order_relaxed) == 0) {
+        int cus = 0, lds = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const bool known = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess;
+        d->lds_ok.store((!known || lds >= (int)fl::TileGeo<fl::CfgBig>::LDS_BYTES) ? 1 : 0, std::memory_order_relaxed);
+        d->cus.store(cus, std::memory_order_relaxed);
     }
-    return v;
+    return d;
 }
+static int fused_cu_count() { return fused_dev_info()->cus.load(std::memory_order_relaxed); }
 
 int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, int dtype) {
-    return dtype == SAM3_LORA_BF16 && rank >= 1 && rank <= 32 && n_groups(rank, dtype) == 1 && in_features > 0 && out_features > 0 &&
-           in_features % 64 == 0 && out_features % 8 == 0;
+    if (!(dtype == SAM3_LORA_BF16 && rank >= 1 && rank <= 32 && n_groups(rank, dtype) == 1 && in_features > 0 && out_features > 0 &&
+          in_features % 64 == 0 && out_features % 8 == 0))
+        return 0;
+    // k_fused_linear declares 160 KB of static LDS: the current device must grant that to one workgroup (gfx950 does).  Without a
+    // device (the build check) the shape answer stands.
+    FusedDevInfo* d = fused_dev_info();
+    return d->lds_ok.load(std::memory_order_relaxed) != 0 ? 1 : 0;
 }
 
 size_t sam3_lora_linear_fwd_workspace_bytes(int64_t M, int in_features, int out_features, int rank, int dtype) {

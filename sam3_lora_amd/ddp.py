@@ -71,9 +71,15 @@ class LoRAGradReducer:
         per = max(1, bucket_bytes // 4)
         self.skip_unused = True    # leave .grad = None on parameters no rank produced a gradient for (torch DDP's behaviour)
         self.fired = set()         # indices of the parameters whose gradient arrived in the armed backward
+        # host staging of the used-flags (up: this rank's, before the last bucket goes; back: the reduced ones, for finish()); pinned,
+        # each guarded by an event so that the asynchronous copies never race the next step's rewrite and finish() waits for exactly
+        # the last bucket's reduction instead of synchronising the device
         self._flags_host = torch.zeros(len(self.params), dtype=torch.float32)
+        self._flags_back = torch.zeros(len(self.params), dtype=torch.float32)
+        self._flags_up_event = self._flags_back_event = None
         if dev.type == "cuda":
             self._flags_host = self._flags_host.pin_memory()
+            self._flags_back = self._flags_back.pin_memory()
         hi = len(self.params)
         while hi > 0:
             lo = hi - 1
@@ -179,12 +185,27 @@ class LoRAGradReducer:
             if len(self.fired) == len(self.params):
                 flags.fill_(1.0)
             else:
+                if self._flags_up_event is not None:        # the previous step's H2D copy of this buffer has been consumed
+                    self._flags_up_event.synchronize()
                 self._flags_host.zero_()
                 if self.fired:
                     self._flags_host[sorted(self.fired)] = 1.0
                 flags.copy_(self._flags_host, non_blocking=True)
+                if self.device.type == "cuda":
+                    self._flags_up_event = torch.cuda.Event()
+                    self._flags_up_event.record(torch.cuda.current_stream(self.device))
         s, e, _, _ = self.buckets[b]
         chunk = self.flat[s:e]
+        last = b == len(self.buckets) - 1
+        # the reduced flags travel back to pinned host memory behind the last bucket's all-reduce, only when this rank will have to
+        # look at them (it has locally unused parameters)
+        want_flags = last and self.skip_unused and len(self.fired) < len(self.params) and self.device.type == "cuda"
+
+        def flags_back(work):
+            work.wait()                                     # stream-level: the stream this runs on waits for the reduction
+            self._flags_back.copy_(self.flat[:len(self.params)], non_blocking=True)
+            self._flags_back_event = torch.cuda.Event()
+            self._flags_back_event.record(torch.cuda.current_stream(self.device))
         if self.overlap:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
@@ -194,9 +215,13 @@ class LoRAGradReducer:
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 if self.trace:
                     e1.record(self._side)
-                    self.launch_events.append((b, e0, e1))
+                    self.launch_events.append((b, e0, e1, origin))
+                if want_flags:
+                    flags_back(self._works[-1])
         else:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if want_flags:
+                flags_back(self._works[-1])
 
     def finish(self):
         """After backward: reduce whatever the hooks could not launch (buckets holding a locally unused parameter, and
@@ -216,8 +241,14 @@ class LoRAGradReducer:
             # a parameter unused on EVERY rank keeps .grad = None (the optimizer then skips it, as after the reference's
             # zero_grad()); one unused only here was reduced as zeros + the other ranks' gradients.  Only a rank that has
             # locally unused parameters needs to look (a globally unused one is locally unused everywhere).
-            globally = locally_unused if not exchange else \
-                [i for i, v in zip(locally_unused, flags[locally_unused].tolist()) if v == 0.0]
+            if not exchange:
+                globally = locally_unused
+            elif self._flags_back_event is not None:        # wait for the last bucket's reduction + its small D2H copy, nothing else
+                self._flags_back_event.synchronize()
+                self._flags_back_event = None
+                globally = [i for i in locally_unused if float(self._flags_back[i]) == 0.0]
+            else:                                           # CPU tensors (gloo tests): the reduction has been waited for above
+                globally = [i for i, v in zip(locally_unused, flags[locally_unused].tolist()) if v == 0.0]
             for i in globally:
                 self.params[i].grad = None
         self._works = []

@@ -371,6 +371,19 @@ def set_fused_linear_fp8(on: Optional[bool]) -> None:
     _FUSED["fp8"] = on
 
 
+def _fused_layout_ok(x2: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    """The layouts sam3_lora_linear_fwd addresses (16-byte aligned bases and row pitches, unit column stride of W, an 8-byte aligned
+    bias, row pitches below 4 M elements); anything else keeps the two-pass form, which takes any strides."""
+    e = x2.element_size()
+    if W.dim() != 2 or W.stride(1) != 1 or x2.stride(1) != 1:
+        return False
+    if (x2.data_ptr() | W.data_ptr()) & 15 or (x2.stride(0) * e) & 15 or (W.stride(0) * e) & 15:
+        return False
+    if max(x2.stride(0), W.stride(0)) >= (1 << 22):
+        return False
+    return bias is None or (bias.is_contiguous() and bias.data_ptr() % 8 == 0)
+
+
 def fused_linear_fp8_enabled() -> bool:
     """SAM3_LORA_FUSED_LINEAR_FP8=0: the fp8 frozen-W mode keeps hipBLASLt's fp8 GEMM + the adapter pass at the fc1 site."""
     if _FUSED.get("fp8") is None:
@@ -724,7 +737,7 @@ class _LoRAMlpFn(torch.autograd.Function):
         cdt = W1.dtype
         x2 = _rows(x if x.dtype == cdt else x.to(cdt))
         need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
-        fused1 = (fused_linear_enabled() and not q8_ok and not fp8.eligible(x2, W1)
+        fused1 = (fused_linear_enabled() and not q8_ok and not fp8.eligible(x2, W1) and _fused_layout_ok(x2, W1, b1)
                   and linear_fwd_supported(W1.shape[1], W1.shape[0], _rank_of(_master(A1), layout), cdt))
         fused1_q8 = (fused_linear_enabled() and fused_linear_fp8_enabled() and q8_ok and fp8.eligible(x2, W1) and x2.dtype == torch.bfloat16
                      and W1.shape[1] % 128 == 0

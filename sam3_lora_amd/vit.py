@@ -624,6 +624,8 @@ def _tree_cast(obj, dtype):
         if obj.dtype in (torch.float32, torch.bfloat16) and obj.dtype != dtype:
             return obj.to(dtype)
         return obj
+    if isinstance(obj, tuple) and hasattr(obj, "_fields"):        # namedtuple: positional constructor
+        return type(obj)(*(_tree_cast(o, dtype) for o in obj))
     if isinstance(obj, (list, tuple)):
         return type(obj)(_tree_cast(o, dtype) for o in obj)
     if isinstance(obj, dict):
@@ -632,8 +634,20 @@ def _tree_cast(obj, dtype):
 
 
 def _cast_inputs_hook(dtype, skip=()):
-    def hook(_module, args, kwargs):
-        return _tree_cast(args, dtype), {k: (v if k in skip else _tree_cast(v, dtype)) for k, v in kwargs.items()}
+    """Forward pre-hook casting floating-point tensor arguments to ``dtype``; arguments named in ``skip`` are left alone whether they
+    arrive by keyword or by position (bound through the module's forward signature: a positional ``memory`` would otherwise get an fp32
+    copy of all 5184 x batch memory tokens at the decoder's entry)."""
+    def hook(module, args, kwargs):
+        skip_pos = ()
+        if skip and args:
+            import inspect
+            try:
+                names = [n for n in inspect.signature(module.forward).parameters][:len(args)]
+                skip_pos = tuple(i for i, n in enumerate(names) if n in skip)
+            except (TypeError, ValueError):
+                skip_pos = ()
+        new_args = tuple(a if i in skip_pos else _tree_cast(a, dtype) for i, a in enumerate(args))
+        return new_args, {k: (v if k in skip else _tree_cast(v, dtype)) for k, v in kwargs.items()}
     return hook
 
 
@@ -645,6 +659,13 @@ def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloa
     import fnmatch
     islands = tuple(DEFAULT_FP32_ISLANDS if fp32_islands is None else fp32_islands)
     mods = dict(model.named_modules())
+    missing = tuple(i for i in islands if i not in mods)
+    if missing and any(n == "transformer" or n.endswith(".transformer") for n in mods):
+        # e.g. the model wrapped under a `module.` / `detector.` prefix: dropping the names silently would give the all-bf16 layout
+        # (round 3's precision: presence logit 6e-2 instead of 8e-3) without anyone noticing
+        import warnings
+        warnings.warn(f"to_training_layout: fp32 islands {missing} are not sub-modules of this model (prefix the names as in "
+                      f"named_modules()); those parts follow {frozen_dtype}", stacklevel=2)
     islands = tuple(i for i in islands if i in mods)
     hole_pats = tuple(DEFAULT_FP32_HOLES if fp32_holes is None else fp32_holes)
     holes = tuple(n for n in mods if any(fnmatch.fnmatchcase(n, p) for p in hole_pats)
