@@ -71,7 +71,7 @@ class Fp8Quantizer:
         lib = _ffi.load()
         if self.amax is None or self.amax.device != x2.device:
             self.amax = torch.zeros(2, _ffi.FP8_AMAX_FLOATS, device=x2.device)
-            self.scale = torch.empty(1, device=x2.device)
+            self.scale = torch.ones(1, device=x2.device)        # what a call with nothing observed before it falls back to
             # first call: calibrate on the tensor itself (finite values only, as the kernels' running amax)
             self.amax[0, 0] = torch.nan_to_num(x2.detach().abs().float(), nan=0.0, posinf=0.0).max()
             self.k = 0

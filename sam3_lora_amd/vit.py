@@ -660,7 +660,7 @@ def to_training_layout(model: nn.Module, frozen_dtype: torch.dtype = torch.bfloa
     islands = tuple(DEFAULT_FP32_ISLANDS if fp32_islands is None else fp32_islands)
     mods = dict(model.named_modules())
     missing = tuple(i for i in islands if i not in mods)
-    if missing and any(n == "transformer" or n.endswith(".transformer") for n in mods):
+    if missing and len(missing) == len(islands) and any(n == "transformer" or n.endswith(".transformer") for n in mods):
         # e.g. the model wrapped under a `module.` / `detector.` prefix: dropping the names silently would give the all-bf16 layout
         # (round 3's precision: presence logit 6e-2 instead of 8e-3) without anyone noticing
         import warnings

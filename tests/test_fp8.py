@@ -35,6 +35,36 @@ def test_quantiser_matches_torch_cast_bitwise_and_tracks_amax(fmt, src):
     assert torch.isfinite(out4.float()).all() and out4.float().abs().max().item() == fmax
 
 
+def test_an_empty_observation_keeps_the_previous_scale():
+    """Delayed scaling after a call that observed NOTHING (an all-zero tensor: a gradient that vanished for a step, a fully masked
+    batch): the amax it gathered is 0.  The next call must not scale with it -- "amax = tiny" multiplies a real tensor by 7.5e9 and
+    saturates every element to +-max, finite garbage that turns non-finite a few layers on (the suspected path of the one non-finite
+    fp8 run of round 4) -- it keeps the scale of the role's last real observation.  Fails on the round-4 library: every element
+    of the third image is +-448 there."""
+    from sam3_lora_amd import _ffi
+    from sam3_lora_amd.fp8 import Fp8Quantizer
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(512, 1024, device=DEV, generator=g).bfloat16()
+    q = Fp8Quantizer(_ffi.FP8_E4M3)
+    img0, s0 = q(x)                                     # calibrates on x; gathers amax(x) for the next call
+    s0 = s0.clone()
+    img1, s1 = q(torch.zeros_like(x))                   # scales with amax(x); observes nothing
+    assert torch.allclose(s1, s0) and float(img1.float().abs().max()) == 0.0
+    img2, s2 = q(x)                                     # previous amax = 0: keeps s0
+    assert torch.allclose(s2, s0), (float(s2), float(s0))
+    deq = img2.float() * s2
+    assert float((deq - x.float()).abs().max()) <= 2.0 ** -4 * float(x.float().abs().max())
+    assert float((img2.float().abs() == 448.0).float().mean()) < 1e-3          # not saturated wholesale
+    img3, s3 = q(x)                                     # and the call after that scales with the amax img2's call gathered
+    assert torch.allclose(s3, s0) and torch.equal(img3.view(torch.uint8), img0.view(torch.uint8))
+    # the very first call on an all-zero tensor (nothing to calibrate on): scale 1, a zero image, no NaN
+    q2 = Fp8Quantizer(_ffi.FP8_E5M2)
+    z, sz = q2(torch.zeros_like(x))
+    assert float(sz) == 1.0 and float(z.float().abs().max()) == 0.0
+    img4, s4 = q2(x)                                    # still nothing observed before it: scale 1
+    assert float(s4) == 1.0 and torch.isfinite(img4.float()).all()
+
+
 def test_fp8_frozen_linears_track_the_bf16_build():
     """LoRA-adapted MLP (fused node) and a plain frozen Linear: outputs and input gradients of the fp8 route within 8 % of
     the bf16 build's max magnitude (two e4m3 operands: 2^-4 relative per element, averaged over K), adapter gradients
