@@ -946,6 +946,30 @@ def main():
                                 "bias + GELU as one MFMA kernel (sam3_lora_linear_fwd), off = hipBLASLt GEMM + sam3_lora_fwd_act"}
             finally:
                 set_fused_linear(dflt)
+        if not args.fp8_frozen and args.act_dtype == "bf16" and not args.no_fused_ab:
+            # the two forms of SURVEY 8(f)-1 that are NOT the default, each switched on for a few steps of the same process: fc2's forward
+            # through sam3_lora_linear_fwd, and the backward mirror gh = (ga W2 + s gt2 A2^T) GELU'(h) as one kernel (sam3_lora_linear_dgrad_act)
+            from sam3_lora_amd.functional import set_knob
+            vres = {}
+            for knob, what in (("SAM3_LORA_FUSED_FC2", "fc2 forward (K = 4736, N = 1024) as one MFMA kernel instead of hipBLASLt + sam3_lora_fwd"),
+                               ("SAM3_LORA_MIRROR", "fc2's input gradient x GELU'(h) as one MFMA kernel (sam3_lora_linear_dgrad_act) + the adapter's weight "
+                                                    "gradients from the stored activation, instead of hipBLASLt + sam3_lora_bwd_act (which recomputes it)")):
+                set_knob(knob, True)
+                try:
+                    for _ in range(2):
+                        full.step()
+                    v_steps = max(3, min(args.steps, 6))
+                    dtv = timed(full.step, v_steps)
+                    vres[knob] = {"ms_per_step": round(dtv / v_steps * 1e3, 3), "value": round(world * args.batch * v_steps / dtv, 2),
+                                  "loss": round(full.last_loss.item(), 4), "what": what}
+                except Exception as e:
+                    vres[knob] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+                finally:
+                    set_knob(knob, None)
+            for _ in range(2):      # back on the default path before anything else is timed
+                full.step()
+            if rank == 0:
+                out["fused_gemm_variants_not_default"] = vres
         if not args.no_fp8 and not args.fp8_frozen and args.act_dtype == "bf16":
             # BASELINE configs[4]'s mode on the same workload: frozen base GEMMs on the fp8 MFMA kernels
             loss_bf16 = full.last_loss.item()

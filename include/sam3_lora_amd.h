@@ -238,6 +238,26 @@ int sam3_lora_linear_fwd_q8(const void* x, const void* x_q8, int64_t ldxq, const
                             void* q8_out, int64_t ldq, int fmt, const float* amax_in, float* amax_out, float* scale_out);
 
 /*
+ * The mirror of sam3_lora_linear_fwd for the input gradient of an adapted Linear that follows an activation (fc2 of timm's Mlp,
+ * sam3/model/vitdet.py:585-590: a = GELU(h), y = fc2(a)): ONE kernel for
+ *
+ *     gx_out[M, in] = ( gy[M, out] @ Wt[in, out]^T  +  scaling * (gy @ B_c^T) @ A_c^T ) * act'(pre_act[M, in])
+ *
+ * i.e. autograd's `gy @ W` of the frozen layer plus the adapter's input gradient, times GELU'(h), fp32 accumulation and one
+ * rounding.  `Wt` is the TRANSPOSED frozen weight ([in, out] row-major: the caller keeps that copy once, the weight is frozen); A / B
+ * are the fp32 masters in the caller's layout (no SAM3_LORA_PREPACKED here); no dropout mask on the branch (SAM3_LORA_ENOTSUP with the
+ * adapter's dropout active: use the two-pass form).  The weight gradients still come from sam3_lora_bwd with gx_inout = NULL.
+ * Workspace: sam3_lora_linear_fwd_workspace_bytes(M, out_features, in_features, rank, dtype).
+ * Built to decide SURVEY 8f-1's "backward mirror" with a measurement: it LOSES to hipBLASLt + sam3_lora_bwd_act (whose pass also forms
+ * the layer's gA from the recomputed activation) at the benchmark's fc2 site -- DESIGN.md section 4a -- and is off by default
+ * (SAM3_LORA_MIRROR=1 in the fused MLP node).
+ */
+int sam3_lora_linear_dgrad_act(const void* gy, const void* Wt, const void* A, const void* B, void* gx_out,
+                               int64_t M, int in_features, int out_features, int rank, int64_t ldgy, int64_t ldwt, int64_t ldgx,
+                               int layout, float scaling, int dtype, void* workspace, size_t workspace_bytes, void* stream,
+                               int act, const void* pre_act, int64_t ldpre);
+
+/*
  * Merge for adapter-free inference: Wm[out, in] = W[out, in] + scaling * (A_c @ B_c)^T, fp32.
  * Replaces sam3_lora/lora/lora_layer.py:81-88 (merge_weights) and :160-178.
  */
@@ -266,7 +286,8 @@ unsigned sam3_lora_debug_set_stages(unsigned mask);
 
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
  * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_WGS,
- * SAM3_LORA_FUSED_HALF, SAM3_LORA_FUSED_TILE, SAM3_LORA_HL_MAX_RANK) are read from the
+ * SAM3_LORA_FUSED_HALF, SAM3_LORA_FUSED_TILE, SAM3_LORA_FUSED_PROBE, SAM3_LORA_HL_MAX_RANK, SAM3_LORA_BWD_V2, SAM3_LORA_BWD_XGX,
+ * SAM3_LORA_T3W_WGS, SAM3_LORA_XCD_ORDER, SAM3_LORA_GA_IN_T2, SAM3_LORA_T1_BK; INTEGRATION.md section D says what each selects) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);

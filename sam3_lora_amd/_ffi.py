@@ -29,6 +29,7 @@ EXPORTS = (
     "sam3_lora_packed_bytes", "sam3_lora_pack", "sam3_lora_pack_many", "sam3_lora_fwd_act", "sam3_lora_bwd_act",
     "sam3_lora_fwd_act_q8", "sam3_lora_bwd_act_q8", "sam3_lora_bwd_act_recomputes_input",
     "sam3_lora_linear_fwd", "sam3_lora_linear_fwd_supported", "sam3_lora_linear_fwd_workspace_bytes", "sam3_lora_linear_fwd_q8",
+    "sam3_lora_linear_dgrad_act",
 )
 ACT_NONE, ACT_GELU = 0, 1
 PREPACKED = 0x100
@@ -120,6 +121,14 @@ def _declare(lib):
         c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
         c_int, c_void_p, c_int64,                              # act, act_out, ldact
     ] + q8_tail
+    lib.sam3_lora_linear_dgrad_act.restype = c_int
+    lib.sam3_lora_linear_dgrad_act.argtypes = [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,      # gy, Wt, A, B, gx_out
+        c_int64, c_int, c_int, c_int,                          # M, in, out, rank
+        c_int64, c_int64, c_int64, c_int, c_float, c_int,      # ldgy, ldwt, ldgx, layout, scaling, dtype
+        c_void_p, c_size_t, c_void_p,                          # workspace, bytes, stream
+        c_int, c_void_p, c_int64,                              # act, pre_act, ldpre
+    ]
     lib.sam3_lora_bwd_act_recomputes_input.restype = c_int
     lib.sam3_lora_bwd_act_recomputes_input.argtypes = [c_int, c_int, ctypes.c_float]
     lib.sam3_lora_debug_reload_knobs.restype = None

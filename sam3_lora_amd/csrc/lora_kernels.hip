@@ -2601,6 +2601,9 @@ size_t sam3_lora_linear_fwd_workspace_bytes(int64_t M, int in_features, int out_
     return fwd_ws(M, in_features, out_features, rank, dtype).total + al256((size_t)out_features * 128 * 2);
 }
 
+struct LinearMirror {    // sam3_lora_linear_dgrad_act: the epilogue multiplies by act'(pre_act) instead of applying an activation
+    const void* pre_act; long long ldpre;
+};
 struct LinearF8 {        // the fp8 frozen-W form of sam3_lora_linear_fwd (sam3_lora_linear_fwd_q8)
     const void* x_q8; long long ldxq;
     const void* w_q8; long long ldwq;
@@ -2611,7 +2614,8 @@ struct LinearF8 {        // the fp8 frozen-W form of sam3_lora_linear_fwd (sam3_
 static int linear_fwd_impl(const void* x, const void* W, const void* bias, const void* A, const void* B, void* y_out, void* tT_out,
                            int64_t M, int in_features, int out_features, int rank, int64_t ldx, int64_t ldw, int64_t ldy,
                            int layout, float scaling, float drop_p, uint64_t seed, uint64_t offset, int dtype, void* workspace,
-                           size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact, const LinearF8* f8) {
+                           size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact, const LinearF8* f8,
+                           const LinearMirror* mirror = nullptr) {
     g_err[0] = 0;
     if (drop_p < 0.f || drop_p > 1.f) return fail(SAM3_LORA_EINVAL, "drop_p must be in [0, 1] (got %g)", drop_p);
     int rc;
@@ -2642,9 +2646,15 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");
     if (pre && ((uintptr_t)A & 255)) return fail(SAM3_LORA_EINVAL, "packed operands must be 256-byte aligned");
     if (act != SAM3_LORA_ACT_NONE && act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "unknown activation %d", act);
-    if (act && (rc = check_act(act_out, ldact, out_features, dtype, "act_out"))) return rc;
+    if (act && !mirror && (rc = check_act(act_out, ldact, out_features, dtype, "act_out"))) return rc;
+    if (mirror) {
+        if (f8 || drop_p != 0.f) return fail(SAM3_LORA_ENOTSUP, "dgrad: bf16 operands, no dropout mask on the branch");
+        if (act != SAM3_LORA_ACT_GELU) return fail(SAM3_LORA_EINVAL, "dgrad: the activation whose derivative is applied must be given");
+        if ((rc = check_act(mirror->pre_act, mirror->ldpre, out_features, dtype, "pre_act"))) return rc;
+        if (256LL * mirror->ldpre * 2 >= (1LL << 31)) return fail(SAM3_LORA_ENOTSUP, "fused linear: row pitches beyond 4 M elements are not addressable by the tile descriptors");
+    }
     if (tT_out && ((uintptr_t)tT_out & 15)) return fail(SAM3_LORA_EINVAL, "tT_out must be 16-byte aligned");
-    if (256LL * ldx * 2 >= (1LL << 31) || (!f8 && 256LL * ldw * 2 >= (1LL << 31)) || 256LL * ldy * 2 >= (1LL << 31) || (act && 256LL * ldact * 2 >= (1LL << 31)))
+    if (256LL * ldx * 2 >= (1LL << 31) || (!f8 && 256LL * ldw * 2 >= (1LL << 31)) || 256LL * ldy * 2 >= (1LL << 31) || (act && !mirror && 256LL * ldact * 2 >= (1LL << 31)))
         return fail(SAM3_LORA_ENOTSUP, "fused linear: row pitches beyond 4 M elements are not addressable by the tile descriptors");
     const FwdWs w = fwd_ws(M, in_features, out_features, rank, dtype);
     const size_t need = w.total + al256((size_t)out_features * 128 * 2);
@@ -2687,6 +2697,7 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
         fa.bias = (const bf16_t*)bias;
         fa.Y = (bf16_t*)y_out; fa.ldy = ldy;
         fa.A = (bf16_t*)act_out; fa.lda = ldact;
+        fa.H = mirror ? (const bf16_t*)mirror->pre_act : nullptr; fa.ldh = mirror ? mirror->ldpre : 0;
         fa.M = M; fa.Mp = Mp; fa.N = out_features; fa.K = in_features;
         fa.X8 = nullptr; fa.W8 = nullptr; fa.ldx8 = fa.ldw8 = 0; fa.sx = fa.sw = nullptr;
         fa.q8 = Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
@@ -2698,7 +2709,7 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
         }
         // tile configuration: 1 = fl::CfgPair (256 x 128 x 32, two workgroups per CU), 0 = fl::CfgBig (256 x 256 x 64, one)
         // tile configuration: 0 = fl::CfgBig, 1 = fl::CfgPair, 2 = fl::CfgRing (256 x 256 x 32, four-stage ring)
-        const int tile_cfg = f8 ? 0 : (int)env_int("SAM3_LORA_FUSED_TILE", 0);
+        const int tile_cfg = (f8 || mirror) ? 0 : (int)env_int("SAM3_LORA_FUSED_TILE", 0);
         const int pair = tile_cfg == 1, ring = tile_cfg == 2;
         const int bm = pair ? fl::CfgPair::BM : fl::CfgBig::BM, bn = pair ? fl::CfgPair::BN : fl::CfgBig::BN;
         fa.tiles_m = (int)((M + bm - 1) / bm);
@@ -2717,7 +2728,11 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
         hipLaunchKernelGGL((fl::k_fused_linear<fl::CFG_, ACT_, TROW_>), dim3((unsigned)grid), dim3(fl::TileGeo<fl::CFG_>::NTHREADS), 0, st, fa)
 #define SAM3_FL_CFG(ACT_, TROW_) do { if (pair) SAM3_FL_LAUNCH(CfgPair, ACT_, TROW_); else if (ring) SAM3_FL_LAUNCH(CfgRing, ACT_, TROW_); else SAM3_FL_LAUNCH(CfgBig, ACT_, TROW_); } while (0)
         const int probe = (int)env_int("SAM3_LORA_FUSED_PROBE", 0);
-        if (f8) {
+        if (mirror) {
+#define SAM3_FL_MIRROR(TROW_) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 2, TROW_>), dim3((unsigned)grid), dim3(512), 0, st, fa)
+            if (trow == 128) SAM3_FL_MIRROR(128); else if (trow == 64) SAM3_FL_MIRROR(64); else SAM3_FL_MIRROR(32);
+#undef SAM3_FL_MIRROR
+        } else if (f8) {
 #define SAM3_FL_F8(ACT_, TROW_) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, ACT_, TROW_, 0, true>), dim3((unsigned)grid), dim3(512), 0, st, fa)
             if (act) { if (trow == 128) SAM3_FL_F8(1, 128); else if (trow == 64) SAM3_FL_F8(1, 64); else SAM3_FL_F8(1, 32); }
             else { if (trow == 128) SAM3_FL_F8(0, 128); else if (trow == 64) SAM3_FL_F8(0, 64); else SAM3_FL_F8(0, 32); }
@@ -2744,6 +2759,20 @@ int sam3_lora_linear_fwd(const void* x, const void* W, const void* bias, const v
                          size_t workspace_bytes, void* stream, int act, void* act_out, int64_t ldact) {
     return linear_fwd_impl(x, W, bias, A, B, y_out, tT_out, M, in_features, out_features, rank, ldx, ldw, ldy, layout, scaling, drop_p, seed,
                            offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact, nullptr);
+}
+
+int sam3_lora_linear_dgrad_act(const void* gy, const void* Wt, const void* A, const void* B, void* gx_out, int64_t M, int in_features,
+                               int out_features, int rank, int64_t ldgy, int64_t ldwt, int64_t ldgx, int layout, float scaling, int dtype,
+                               void* workspace, size_t workspace_bytes, void* stream, int act, const void* pre_act, int64_t ldpre) {
+    // the transposed adapter: gx = gy Wt^T + s (gy B_c^T) A_c^T is the forward of a layer [out -> in] whose weight is Wt[in, out] and whose
+    // adapter has A' = B_c^T, B' = A_c^T -- i.e. the caller's B and A tensors read in the OTHER layout
+    g_err[0] = 0;
+    if (layout & SAM3_LORA_PREPACKED) return fail(SAM3_LORA_ENOTSUP, "dgrad: the operand blob holds the forward's images; pass the fp32 masters");
+    if (layout != SAM3_LORA_LAYOUT_ROOT && layout != SAM3_LORA_LAYOUT_PACKAGE) return fail(SAM3_LORA_EINVAL, "unknown layout %d", layout);
+    const LinearMirror mir{pre_act, (long long)ldpre};
+    const int other = layout == SAM3_LORA_LAYOUT_ROOT ? SAM3_LORA_LAYOUT_PACKAGE : SAM3_LORA_LAYOUT_ROOT;
+    return linear_fwd_impl(gy, Wt, nullptr, B, A, gx_out, nullptr, M, out_features, in_features, rank, ldgy, ldwt, ldgx, other, scaling, 0.f, 0, 0,
+                           dtype, workspace, workspace_bytes, stream, act, nullptr, 0, nullptr, &mir);
 }
 
 int sam3_lora_linear_fwd_q8(const void* x, const void* x_q8, int64_t ldxq, const float* scale_x, const void* w_q8, int64_t ldwq,

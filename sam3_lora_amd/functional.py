@@ -371,6 +371,24 @@ def set_fused_linear_fp8(on: Optional[bool]) -> None:
     _FUSED["fp8"] = on
 
 
+_KNOBS = {}
+
+
+def _knob(name: str) -> bool:
+    """A/B knobs of the fused MLP node, read from the environment once (``set_knob`` overrides)."""
+    if name not in _KNOBS:
+        import os
+        _KNOBS[name] = os.environ.get(name, "0") not in ("", "0")
+    return bool(_KNOBS[name])
+
+
+def set_knob(name: str, on: Optional[bool]) -> None:
+    if on is None:
+        _KNOBS.pop(name, None)
+    else:
+        _KNOBS[name] = bool(on)
+
+
 def _fused_layout_ok(x2: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
     """The layouts sam3_lora_linear_fwd addresses (16-byte aligned bases and row pitches, unit column stride of W, an 8-byte aligned
     bias, row pitches below 4 M elements); anything else keeps the two-pass form, which takes any strides."""
@@ -476,6 +494,31 @@ def lora_linear_fwd_q8_(x2: torch.Tensor, xq: torch.Tensor, sx: torch.Tensor, wq
         ptr(qimg), qimg.stride(0) if qimg is not None else 0, int(qfmt), ptr(am_in), ptr(am_out), ptr(qscale))
     _ffi.check(rc, "sam3_lora_linear_fwd_q8")
     return y, a, tT
+
+
+def lora_linear_dgrad_act_(gy2: torch.Tensor, Wt: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float, layout: int,
+                           gelu_pre: torch.Tensor) -> torch.Tensor:
+    """Input gradient of an adapted Linear behind a GELU as ONE kernel (sam3_lora_linear_dgrad_act):
+    ``(gy2 @ Wt^T + scaling * (gy2 @ B_c^T) @ A_c^T) * GELU'(gelu_pre)`` with ``Wt`` = the transposed frozen weight ``[in, out]``."""
+    lib = _ffi.load()
+    _require_cuda(gy2, Wt, A, B, gelu_pre)
+    M, fout = gy2.shape
+    fin = Wt.shape[0]
+    rank = _rank_of(A, layout)
+    if gy2.dtype != torch.bfloat16 or Wt.dtype != gy2.dtype or gelu_pre.dtype != gy2.dtype or Wt.shape[1] != fout or Wt.stride(1) != 1 \
+            or gelu_pre.shape != (M, fin):
+        raise LoRAKernelError("sam3_lora_amd: dgrad takes bf16 gy [M, out], Wt [in, out] with unit column stride and pre_act [M, in]")
+    nws = lib.sam3_lora_linear_fwd_workspace_bytes(M, fout, fin, rank, DT_BF16)
+    if nws == 0:
+        raise LoRAKernelError(f"sam3_lora_linear_fwd_workspace_bytes: {_ffi.last_error() or 'shape / dtype not supported'}")
+    ws = _workspace(gy2.device, nws)
+    gx = torch.empty(M, fin, dtype=gy2.dtype, device=gy2.device)
+    rc = lib.sam3_lora_linear_dgrad_act(
+        gy2.data_ptr(), Wt.data_ptr(), A.data_ptr(), B.data_ptr(), gx.data_ptr(), M, fin, fout, rank, gy2.stride(0), Wt.stride(0),
+        gx.stride(0), int(layout), float(scaling), DT_BF16, ws.data_ptr(), ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream(gy2.device).cuda_stream), _ffi.ACT_GELU, gelu_pre.data_ptr(), gelu_pre.stride(0))
+    _ffi.check(rc, "sam3_lora_linear_dgrad_act")
+    return gx
 
 
 def lora_bwd_(gy2: torch.Tensor, x2: torch.Tensor, tT: Optional[torch.Tensor], A: torch.Tensor, B: torch.Tensor,
@@ -766,16 +809,26 @@ class _LoRAMlpFn(torch.autograd.Function):
             qa = fp8.producer_slots(W2, "x", h.shape[0], h.shape[1], h.device) if (q8_ok and h.dtype == torch.bfloat16) else None
             t1 = lora_fwd_(x2, _master(A1), _master(B1), h, s1, layout, save_t=need_w, drop_p=drop_p, seed=seed1, packed=pk1,
                            gelu_out=a, q8=qa)
-        with torch.autocast("cuda", enabled=False):
-            y = fp8.fp8_linear_q(qa[0], qa[4], W2, b2) if qa is not None else _frozen_fwd(a, W2, b2)
+        fused2 = (_knob("SAM3_LORA_FUSED_FC2") and fused_linear_enabled() and qa is None and not fp8.eligible(a, W2) and _fused_layout_ok(a, W2, b2)
+                  and linear_fwd_supported(W2.shape[1], W2.shape[0], _rank_of(_master(A2), layout), cdt))
         ctx.q8_ok = q8_ok
-        t2 = lora_fwd_(a, _master(A2), _master(B2), y, s2, layout, save_t=need_w, drop_p=drop_p, seed=seed2, packed=pk2)
+        if fused2:
+            # fc2 (K = 4736, N = 1024) through the same one-kernel form: an A/B knob -- 648 tiles = 2.5 rounds of a 256-CU grid and a
+            # 74-step K loop lose to hipBLASLt's stream-K kernel here; off by default
+            y, _, t2 = lora_linear_fwd_(a, W2, b2, _master(A2), _master(B2), s2, layout, save_t=need_w, drop_p=drop_p, seed=seed2,
+                                        packed=pk2, gelu=False)
+        else:
+            with torch.autocast("cuda", enabled=False):
+                y = fp8.fp8_linear_q(qa[0], qa[4], W2, b2) if qa is not None else _frozen_fwd(a, W2, b2)
+            t2 = lora_fwd_(a, _master(A2), _master(B2), y, s2, layout, save_t=need_w, drop_p=drop_p, seed=seed2, packed=pk2)
         ctx.meta = (s1, s2, layout, drop_p, seed1, seed2, x.shape, x.dtype)
         ctx.pk = (pk1, pk2)
         ctx.wt = (Wt1, Wt2)
         # a = GELU(h) is fc2's input; the backward needs it for gA2 only, and where the kernels can they recompute it from h
         # inside the pass that applies GELU'(h) (sam3_lora_bwd_act with x == NULL): not saved then (393 MB per block at batch 8)
-        ctx.recompute_a = bool(need_w and t2 is not None
+        ctx.mirror = bool(_knob("SAM3_LORA_MIRROR") and drop_p == 0.0 and h.dtype == torch.bfloat16 and not q8_ok and not fp8.eligible(a, W2)
+                          and linear_fwd_supported(W2.shape[0], W2.shape[1], _rank_of(_master(A2), layout), cdt))
+        ctx.recompute_a = bool(need_w and t2 is not None and not ctx.mirror
                                and bwd_act_recomputes_input(_rank_of(_master(A2), layout), h.dtype, drop_p))
         ctx.save_for_backward(x2, h, a.new_empty(0) if ctx.recompute_a else a, W1, W2, A1, B1, A2, B2, t1, t2)
         return y.view(*x.shape[:-1], y.shape[-1])
@@ -799,6 +852,26 @@ class _LoRAMlpFn(torch.autograd.Function):
         else:
             gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
         from . import fp8
+        if ctx.mirror and need_x and gy2.shape[0] > 0:
+            # SURVEY 8f-1's backward mirror behind SAM3_LORA_MIRROR=1 (an A/B knob): gh as ONE MFMA kernel, the weight
+            # gradients from the adapter backward without gx (it then reads the stored activation for gA)
+            Wt2 = ctx.wt[1] if (ctx.wt[1] is not None and ctx.wt[1].dtype == gy2.dtype and ctx.wt[1].shape == (W2.shape[1], W2.shape[0])
+                                and ctx.wt[1].stride(1) == 1) else W2.t().contiguous()
+            ga = lora_linear_dgrad_act_(gy2, Wt2, A2m, B2m, s2, layout, gelu_pre=h)
+            if need_w:
+                lora_bwd_(gy2, a, t2, A2m, B2m, None, gA2, gB2, s2, layout, accumulate=direct, packed=pk2)
+            gx2 = None
+            with torch.autocast("cuda", enabled=False):
+                gx2 = _dx(ga, W1, ctx.wt[0])
+            lora_bwd_(ga, x2, t1, A1m, B1m, gx2, gA1, gB1, s1, layout, accumulate=direct, drop_p=drop_p, seed=seed1, packed=pk1)
+            gx = gx2.view(x_shape).to(x_dtype)
+            if direct:
+                z = _zero_grad_like
+                return (gx, None, None, z(A1), z(B1), None, None, None, z(A2), z(B2), None, None, None, None, None, None, None,
+                        None, None, None, None)
+            g = lambda t, p_, i: (t.to(p_.dtype) if (t is not None and ctx.needs_input_grad[i]) else None)
+            return (gx, None, None, g(gA1, A1, 3), g(gB1, B1, 4), None, None, None, g(gA2, A2, 8), g(gB2, B2, 9), None, None,
+                    None, None, None, None, None, None, None, None, None)
         with torch.autocast("cuda", enabled=False):
             ga = _dx(gy2, W2, ctx.wt[1])                             # frozen GEMM
         # fc2's adapter backward; its in-place pass over ga also applies GELU'(h): ga leaves as gh -- and, in the fp8 frozen-W

@@ -237,3 +237,61 @@ def test_unsupported_shapes_say_so():
     W = torch.zeros(64, 1000, device=DEV, dtype=torch.bfloat16)
     with pytest.raises(Fn.LoRAKernelError):
         Fn.lora_linear_fwd_(x, W, None, torch.zeros(1000, 4, device=DEV), torch.zeros(4, 64, device=DEV), 1.0, 0)
+
+
+@pytest.mark.parametrize("M,fin,fout,rank,layout", [(777, 520, 128, 16, 0), (1000, 776, 192, 8, 1), (2048, 4736, 1024, 16, 0)])
+def test_dgrad_mirror_is_one_rounding_from_the_oracle(M, fin, fout, rank, layout):
+    """sam3_lora_linear_dgrad_act (SURVEY 8f-1's backward mirror): gx = (gy W + s (gy B_c^T) A_c^T) GELU'(h) as one kernel -- the
+    frozen layer's input gradient, the adapter's (autograd of lora_layers.py:49-55) and the activation derivative of the layer before
+    it (vitdet.py:585-590) -- against fp64: every element within ONE bf16 rounding; both parameter layouts, ragged shapes, the
+    benchmark's fc2 shape.  And through the fused MLP node with SAM3_LORA_MIRROR=1: the same gradients as the default path."""
+    g = torch.Generator(device=DEV).manual_seed(M + rank)
+    gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    W = (torch.randn(fout, fin, device=DEV, generator=g) / fout ** 0.5).bfloat16()          # frozen weight [out, in]
+    h = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    Ac = torch.randn(fin, rank, device=DEV, generator=g) / fin ** 0.5                       # canonical A_c [in, r], B_c [r, out]
+    Bc = torch.randn(rank, fout, device=DEV, generator=g) * 0.1
+    A, B = (Ac, Bc) if layout == 0 else (Ac.t().contiguous(), Bc.t().contiguous())
+    s = 2.0
+    gx = Fn.lora_linear_dgrad_act_(gy, W.t().contiguous(), A, B, s, layout, gelu_pre=h)
+    hd = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(hd).sum().backward()
+    want = (gy.double() @ W.double() + s * ((gy.double() @ Bc.double().t()) @ Ac.double().t())) * hd.grad
+    err = (gx.double() - want).abs()
+    bound = 2.0 ** -8 * want.abs() + 3e-5 * want.abs().max()
+    assert (err <= bound).all(), (int((err > bound).sum()), float((err / want.abs().max()).max()))
+    gx2 = Fn.lora_linear_dgrad_act_(gy, W.t().contiguous(), A, B, s, layout, gelu_pre=h)
+    assert torch.equal(gx, gx2)
+
+
+def test_mlp_node_with_the_mirror_knob_gives_the_default_paths_gradients():
+    import lora_layers as L
+    from sam3_lora_amd.vit import Mlp
+    outs = {}
+    for knob in (False, True):
+        Fn.set_knob("SAM3_LORA_MIRROR", knob)
+        try:
+            torch.manual_seed(0)
+            mlp = Mlp(256, 1024)
+            mlp.fc1, mlp.fc2 = L.LoRALinear(mlp.fc1, rank=16, alpha=32), L.LoRALinear(mlp.fc2, rank=16, alpha=32)
+            with torch.no_grad():
+                mlp.fc1.lora.lora_B.normal_(0, 0.02), mlp.fc2.lora.lora_B.normal_(0, 0.02)
+            mlp.to(DEV)
+            for m in mlp.modules():
+                if isinstance(m, torch.nn.Linear):
+                    m.to(torch.bfloat16).requires_grad_(False)
+            x = torch.randn(4, 300, 256, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).bfloat16().requires_grad_(True)
+            y = mlp(x)
+            (y.float() * torch.arange(y.numel(), device=DEV).view_as(y).float().cos()).sum().backward()
+            outs[knob] = (y.detach().float(), x.grad.float(), mlp.fc1.lora.lora_A.grad.clone(), mlp.fc1.lora.lora_B.grad.clone(),
+                          mlp.fc2.lora.lora_A.grad.clone(), mlp.fc2.lora.lora_B.grad.clone())
+        finally:
+            Fn.set_knob("SAM3_LORA_MIRROR", None)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert torch.equal(outs[True][0], outs[False][0])
+    # gh is rounded once in the mirror and twice in the two-pass form: everything downstream of it agrees to bf16 resolution
+    assert rel(outs[True][1], outs[False][1]) <= 2e-2, rel(outs[True][1], outs[False][1])
+    for i in (2, 3):
+        assert rel(outs[True][i], outs[False][i]) <= 1e-2, (i, rel(outs[True][i], outs[False][i]))
+    for i in (4, 5):        # fc2's own weight gradients do not depend on gh
+        assert rel(outs[True][i], outs[False][i]) <= 1e-4, (i, rel(outs[True][i], outs[False][i]))

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 A="python $R/bench.py --adapter-only --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
-F="python $R/bench.py --full-only --steps 4 --warmup 2 --no-fp8 --no-cpu-baseline --no-fused-ab --no-literal"
+F="python $R/bench.py --full-only --steps 4 --warmup 2 --no-fp8 --no-cpu-baseline --no-fused-ab --no-literal --no-fp32-layout --no-parity --no-data-step"
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o bench -- $A > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/p_full -o bench -- $F > "$OUT/full.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -o bench -- $A > "$OUT/fetch.log" 2>&1
