@@ -79,7 +79,7 @@ def _golden(golden_dir, name):
 def test_library_is_the_hip_one():
     from sam3_lora_amd import _ffi
     lib = _ffi.load()
-    assert lib.sam3_lora_abi_version() == 5
+    assert lib.sam3_lora_abi_version() == _ffi.ABI_VERSION == 6
     assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
 
 
