@@ -40,6 +40,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include "sam3_lora_amd.h"
@@ -1657,7 +1658,8 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_FUSED_HALF", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0},  {"SAM3_LORA_FUSED_PROBE", false, 0},
                   {"SAM3_LORA_HL_MAX_RANK", false, 0},
                   {"SAM3_LORA_T1_BK", false, 0},
-                  {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_BWD_XGX", false, 0},   {"SAM3_LORA_T3W_WGS", false, 0}};
+                  {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_BWD_XGX", false, 0},   {"SAM3_LORA_T3W_WGS", false, 0},
+                  {"SAM3_LORA_BWD_FORK", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -2338,6 +2340,45 @@ int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout
                     offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact);
 }
 
+// ---- the two independent passes of a backward call on two streams (built, measured, OFF) ----------------------------------------
+// Once gt exists, `gA = x^T gt` (k_t3 over x) and `gx += gt A^T` (k_t2 over gx) touch disjoint outputs, and at in_features = 1024
+// each is a 20-37 us launch at 0.40-0.59 of the HBM peak.  SAM3_LORA_BWD_FORK=1 (passes of >= 32 MB) / 2 (always) forks the call
+// inside itself: an event on the caller's stream, k_t3 and the sum of ITS partials on a library-owned stream of the same device,
+// and the caller's stream waits for that stream's event before the call hands control back -- the caller sees one stream.  Bits
+// are unchanged (test_forked_backward_is_bit_identical_to_the_one_stream_form).  MEASURED on MI355X, M = 41,472, same process,
+// three interleaved rounds (profiles/r05t_backward_fork_rejected.json): fc1 backward 150 us forked against 134 us on one stream,
+// fc2 backward 271 against 245 -- the two cross-queue dependencies (barrier packets resolved by the command processor) cost
+// more than the overlap of two short kernels returns.  Default 0.
+// Never while the caller's stream is being captured into a graph, nor while sam3_lora_prof_start is timing launches.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int state = 0;              // 0 = not tried, 1 = ready, -1 = could not be created
+    std::mutex busy;            // one forked region at a time per device: its events are reused
+};
+static SideStream g_side[64];
+static std::mutex g_side_init;
+static SideStream* side_stream_for(hipStream_t st, long long stream_bytes) {
+    const long long mode = env_int("SAM3_LORA_BWD_FORK", 0);
+    if (mode == 0 || (mode == 1 && stream_bytes < (32LL << 20)) || g_prof.mask) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SideStream* d = &g_side[dev];
+    if (d->state == 0) {
+        std::lock_guard<std::mutex> g(g_side_init);
+        if (d->state == 0) {
+            const bool ok = hipStreamCreateWithFlags(&d->s, hipStreamNonBlocking) == hipSuccess &&
+                            hipEventCreateWithFlags(&d->fork, hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&d->join, hipEventDisableTiming) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            d->state = ok ? 1 : -1;
+        }
+    }
+    return d->state == 1 ? d : nullptr;
+}
+
 // backward of one rank group (see fwd_group for A_g / B_g); gA_g / gB_g point at the group's slice of the gradients.
 // `act2` (GELU' on gx) must only be requested for the last group: gx is complete then.
 static void bwd_group(const void* gy, const void* x, const void* tT_saved, const void* A_g, const void* B_g, bool pre,
@@ -2367,6 +2408,8 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
     const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
     bool one_pass = false, ga_in_pass = false, v2 = false;
+    SideStream* side = nullptr;
+    std::unique_lock<std::mutex> side_lock;
     if (f32) {
         const float* T32 = (const float*)tT_saved;
         if (!T32) {     // no saved t: recompute t = drop(x) . A_c
@@ -2433,8 +2476,25 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && RG == 16 && !dk.thr && (x == nullptr || ga_in_t2_enabled());
         // (x == NULL with the in-pass form switched off by a partial debug stage mask: nothing can read the input -- skip, the
         // header says a partial mask leaves the outputs meaningless)
-        if (gA_g && s3a && !ga_in_pass && x)
-            launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
+        if (gA_g && s3a && !ga_in_pass && x) {
+            if (gx_inout && s2 && stage_on(SAM3_LORA_STAGE_REDUCE))
+                side = side_stream_for(st, M * (long long)in_features * 2);
+            hipStream_t sa = st;
+            if (side) {
+                side_lock = std::unique_lock<std::mutex>(side->busy);
+                hipEventRecord(side->fork, st);
+                hipStreamWaitEvent(side->s, side->fork, 0);
+                sa = side->s;
+            }
+            launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, sa, dk);      // gA^T = gt^T . x
+            if (side) {     // gA's fixed-order sum follows its partials on that stream; gB's rides on k_t2 below
+                const ReduceJob ja{PA, gA_g, w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
+                const ReduceJob none{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
+                hipLaunchKernelGGL(k_reduce, dim3((unsigned)(((long long)rank * in_features + 63) / 64), 1), dim3(256), 0, sa, ja, none,
+                                   scale, accumulate);
+                hipEventRecord(side->join, sa);
+            }
+        }
     }
     // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
     const bool want_reduce = (gA_g || gB_g) && stage_on(SAM3_LORA_STAGE_REDUCE);
@@ -2446,6 +2506,10 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         ride.accumulate = accumulate;
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
         ride.nblk = (int)(((nb > na ? nb : na) + 63) / 64);
+        if (side) {     // gA was summed on the side stream
+            ride.j1 = ReduceJob{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
+            ride.nblk = (int)((nb + 63) / 64);
+        }
     }
     // the reduction rides on the bf16 rank-r update of gx (the last kernel of the call) when there is one
     // (with the gA partials produced BY that kernel the sum cannot ride on it: it follows as its own launch)
@@ -2459,6 +2523,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
         hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, ride.j0, ride.j1, scale, accumulate);
     }
+    if (side) hipStreamWaitEvent(st, side->join, 0);
 }
 
 static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,

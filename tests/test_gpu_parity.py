@@ -775,6 +775,40 @@ def test_riding_reduction_is_bit_identical_to_the_separate_launch(monkeypatch):
     assert not torch.equal(outs["1"][1], outs["1"][4])          # accumulate mode really added onto the 0.5
 
 
+@pytest.mark.parametrize("rank,p", [(16, 0.0), (16, 0.1), (32, 0.1), (8, 0.0)])
+def test_forked_backward_is_bit_identical_to_the_one_stream_form(monkeypatch, rank, p):
+    """Once gt exists the backward runs `gA = x^T gt` (k_t3 + the sum of its partials) on a library-owned stream beside
+    `gx += gt A^T` (k_t2, carrying gB's sum) on the caller's (SAM3_LORA_BWD_FORK: 2 = always, 0 = never; by default for passes of
+    >= 32 MB): same kernels, same fixed-order sums -> the same bits, overwrite and accumulate mode, saved and recomputed t, and
+    with other work queued on the caller's stream right behind the call (the join is an event the caller's stream waits for)."""
+    g = torch.Generator(device=DEV).manual_seed(11 + rank)
+    M, fin, fout = 3000, 520, 1160
+    x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
+    A = torch.randn(fin, rank, device=DEV, generator=g) / 16
+    B = torch.randn(rank, fout, device=DEV, generator=g) / 16
+    outs = {}
+    for fork in ("2", "0"):
+        monkeypatch.setenv("SAM3_LORA_BWD_FORK", fork)
+        _reload_knobs()
+        res = []
+        for accumulate in (False, True):
+            for saved in (True, False):
+                y = torch.zeros(M, fout, device=DEV, dtype=torch.bfloat16)
+                tT = Fn.lora_fwd_(x, A, B, y, 2.0, 0, save_t=True, drop_p=p, seed=9) if saved else None
+                gx = torch.ones(M, fin, device=DEV, dtype=torch.bfloat16)
+                gA, gB = torch.full_like(A, 0.5), torch.full_like(B, 0.25)
+                for _ in range(3):      # back-to-back calls reuse the side stream's events
+                    Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, 2.0, 0, accumulate=accumulate, drop_p=p, seed=9)
+                after = gA.sum() + gB.sum() + gx.float().sum()        # queued on the caller's stream behind the join
+                res += [gx, gA, gB, after]
+        outs[fork] = res
+    monkeypatch.delenv("SAM3_LORA_BWD_FORK", raising=False)
+    _reload_knobs()
+    for a, b in zip(outs["2"], outs["0"]):
+        assert torch.equal(a, b)
+
+
 def test_xcd_aware_tile_order_changes_placement_not_results(monkeypatch):
     """k_t2 / k_t3 / k_t3e number their tiles so that the column chunks of a row group run on one XCD (narrow launches by
     default; SAM3_LORA_XCD_ORDER=0 / 1 forces it off / on everywhere): a bijection of the workgroup ids -- forward and backward
