@@ -378,8 +378,8 @@ def test_fp8_frozen_whole_model_step_tracks_the_bf16_build(gold_wide):
     """BASELINE configs[4]'s mode on the whole (wide-fixture) model: frozen base GEMMs in fp8 (e4m3 weights / activations,
     e5m2 gradients; every Linear whose widths are multiples of 16), adapters bf16 / fp32 as always, against the SAME model in
     the bf16 layout -- there is no reference for fp8.  Stated bounds: first-step pred_logits / pred_boxes
-    within 0.15 of max |.| (e4m3 keeps 3 mantissa bits: 2^-4 per element, averaged over K), the four-step loss curve within
-    5 % (10 % on the first step when fp8 noise flips the fixture's near-tied assignment), everything finite; the numbers are recorded."""
+    within 0.08 / 0.05 of max |.| (e4m3 keeps 3 mantissa bits: 2^-4 per element, averaged over K; measured 0.026 / 0.009), the
+    four-step loss curve within 2 % (10 % on the first step when fp8 noise flips the fixture's near-tied assignment), everything finite; the numbers are recorded."""
     from sam3_lora_amd import fp8
     from sam3_lora_amd.trainer import move_to_device
     from sam3_lora_amd.vit import to_training_layout
@@ -405,15 +405,17 @@ def test_fp8_frozen_whole_model_step_tracks_the_bf16_build(gold_wide):
            "loss_curve_rel": [abs(a - b) / abs(b) for a, b in zip(mf["losses"], mb["losses"])], "indices_equal": mf["indices_equal"]}
     _record("fp8_vs_bf16_wide", rec)
     assert all(np.isfinite(mf["losses"]))
-    assert rec["pred_logits"] <= 0.15 and rec["pred_boxes"] <= 0.15, rec
+    # measured: logits 0.026 / boxes 0.009 with the default fp32 islands (profiles/r05s_parity_fp8_vs_bf16_wide.json), 0.054 / 0.033
+    # in round 3's all-bf16 layout; the loss curve 0.05-0.7 % with an equal assignment
+    assert rec["pred_logits"] <= 0.08 and rec["pred_boxes"] <= 0.05, rec
     # The wide fixture's assignment has a near-tie (two queries whose matching cost differs by less than the fp8 noise on the logits:
     # the all-bf16 layout of round 3 flipped it from run to run as well, profiles/r04g_bf16_islands_with_holes.json).  With e4m3
     # activations it goes either way; when it flips, the first step's loss carries the re-assigned pair (seen: 5.0 %), the
     # following steps re-converge (seen: 0.4-0.6 %).  Equal assignment: the whole curve within 5 %.
     if mf["indices_equal"]:
-        assert max(rec["loss_curve_rel"]) <= 0.05, rec
+        assert max(rec["loss_curve_rel"]) <= 0.02, rec
     else:
-        assert rec["loss_curve_rel"][0] <= 0.10 and max(rec["loss_curve_rel"][1:]) <= 0.05, rec
+        assert rec["loss_curve_rel"][0] <= 0.10 and max(rec["loss_curve_rel"][1:]) <= 0.02, rec
 
 
 def _record(name, m):
@@ -728,7 +730,10 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
     assert m["loss_terms"]["core_loss"] <= max(yard["core_loss"], 1e-3), (m["loss_terms"]["core_loss"], yard)
     assert max(m["loss_curve_rel"]) <= max(yard["core_loss"], 3e-3), (m["losses"], m["loss_curve_rel"])
     assert len(m["grads"]) >= 6
-    assert max(m["grads"].values()) <= 1.25 * yard["worst_AB_grad"], (m["grads"], yard)
+    # A/B gradients: never beyond the reference's own autocast deviation, and within twice what this build has measured on the
+    # fixture (worst adapter 0.155 tiny / 0.146 wide, profiles/r05s_parity_bf16_*.json; the wide yardstick alone -- 0.54 -- would
+    # let a real regression pass)
+    assert max(m["grads"].values()) <= min(1.25 * yard["worst_AB_grad"], 0.30), (m["grads"], yard)
 
 
 @pytest.mark.gpu

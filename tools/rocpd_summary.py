@@ -134,6 +134,21 @@ def gaps(db, delim="k_pack", min_us=20, top=30):
             print(f"             after   {short(r[0], 100)}")
 
 
+def seq(db, last=44):
+    """The last `last` dispatches in start order: start (us from the first of them), duration, and the idle gap since the
+    end of everything dispatched before -- what a dependent launch on one stream costs beyond its kernel time."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()[-int(last):]
+    t0, busy_end, gap_sum, dur_sum = rows[0][1], rows[0][1], 0, 0
+    print(f"{'kernel':60s} {'start_us':>10s} {'dur_us':>9s} {'gap_us':>8s}")
+    for n, s0, e0 in rows:
+        g = s0 - busy_end
+        gap_sum += max(g, 0); dur_sum += e0 - s0
+        print(f"{short(n, 60):60s} {(s0 - t0) / 1e3:10.2f} {(e0 - s0) / 1e3:9.2f} {g / 1e3:8.2f}")
+        busy_end = max(busy_end, e0)
+    print(f"# span {(busy_end - t0) / 1e3:.1f} us: kernels {dur_sum / 1e3:.1f} us, gaps {gap_sum / 1e3:.1f} us over {len(rows)} dispatches")
+
+
 def pmc(db):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, grid_size_x, grid_size_y, workgroup_size_x, counter_name, value "
@@ -211,4 +226,4 @@ def block_traffic(db_fetch, db_write, n_blocks):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "stats_all": stats_all, "gaps": gaps, "pmc": pmc, "traffic": traffic, "block_traffic": block_traffic}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "stats_all": stats_all, "gaps": gaps, "seq": seq, "pmc": pmc, "traffic": traffic, "block_traffic": block_traffic}[sys.argv[1]](*sys.argv[2:])
