@@ -2802,10 +2802,14 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
             if (act) { if (trow == 128) SAM3_FL_F8(1, 128); else if (trow == 64) SAM3_FL_F8(1, 64); else SAM3_FL_F8(1, 32); }
             else { if (trow == 128) SAM3_FL_F8(0, 128); else if (trow == 64) SAM3_FL_F8(0, 64); else SAM3_FL_F8(0, 32); }
 #undef SAM3_FL_F8
-        } else if (probe && !pair && trow == 64) {      // measurement aid (fl::k_fused_linear's PROBE): fill alone / matrix pipe alone
+        } else if (probe && ring && trow == 64 && !act && probe <= 2) {      // the same two probes on the four-stage ring
+            if (probe == 1) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgRing, 0, 64, 1>), dim3((unsigned)grid), dim3(512), 0, st, fa);
+            else hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgRing, 0, 64, 2>), dim3((unsigned)grid), dim3(512), 0, st, fa);
+        } else if (probe && !pair && !ring && trow == 64) {      // measurement aid (fl::k_fused_linear's PROBE): fill alone / matrix pipe alone
 #define SAM3_FL_PROBE(P_) do { if (act) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 1, 64, P_>), dim3((unsigned)grid), dim3(512), 0, st, fa); \
                                else hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 0, 64, P_>), dim3((unsigned)grid), dim3(512), 0, st, fa); } while (0)
-            if (probe == 1) SAM3_FL_PROBE(1); else if (probe == 2) SAM3_FL_PROBE(2); else if (probe == 3) SAM3_FL_PROBE(3); else SAM3_FL_PROBE(4);
+            if (probe == 1) SAM3_FL_PROBE(1); else if (probe == 2) SAM3_FL_PROBE(2); else if (probe == 3) SAM3_FL_PROBE(3);
+            else if (probe == 5) SAM3_FL_PROBE(5); else if (probe == 6) SAM3_FL_PROBE(6); else SAM3_FL_PROBE(4);
 #undef SAM3_FL_PROBE
         } else if (act) {
             if (trow == 128) SAM3_FL_CFG(1, 128); else if (trow == 64) SAM3_FL_CFG(1, 64); else SAM3_FL_CFG(1, 32);

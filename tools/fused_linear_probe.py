@@ -68,7 +68,9 @@ def main():
                 ("PROBE_fill_only_gelu", fused, {"SAM3_LORA_FUSED_PROBE": "1"}), ("PROBE_fill_only_noact", fused_noact, {"SAM3_LORA_FUSED_PROBE": "1"}),
                 ("PROBE_mfma_only_gelu", fused, {"SAM3_LORA_FUSED_PROBE": "2"}), ("PROBE_mfma_only_noact", fused_noact, {"SAM3_LORA_FUSED_PROBE": "2"}),
                 ("PROBE_no_global_stores_gelu", fused, {"SAM3_LORA_FUSED_PROBE": "3"}), ("PROBE_no_global_stores_noact", fused_noact, {"SAM3_LORA_FUSED_PROBE": "3"}),
-                ("PROBE_no_gelu_arithmetic", fused, {"SAM3_LORA_FUSED_PROBE": "4"})]
+                ("PROBE_no_gelu_arithmetic", fused, {"SAM3_LORA_FUSED_PROBE": "4"}),
+                ("PROBE_fill_only_noact_ring", fused_noact, {"SAM3_LORA_FUSED_PROBE": "1", "SAM3_LORA_FUSED_TILE": "2"}),
+                ("PROBE_mfma_only_noact_ring", fused_noact, {"SAM3_LORA_FUSED_PROBE": "2", "SAM3_LORA_FUSED_TILE": "2"})]
     for r in range(5):
         for name, f, env in variants:
             for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_FUSED_PROBE"):
