@@ -1659,7 +1659,7 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_HL_MAX_RANK", false, 0},
                   {"SAM3_LORA_T1_BK", false, 0},
                   {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_BWD_XGX", false, 0},   {"SAM3_LORA_T3W_WGS", false, 0},
-                  {"SAM3_LORA_BWD_FORK", false, 0}};
+                  {"SAM3_LORA_BWD_FORK", false, 0},    {"SAM3_LORA_FUSED_EARLY", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -2783,6 +2783,7 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
             fa.half_col = (rem > 0 && rem <= bn / 2 && env_int("SAM3_LORA_FUSED_HALF", 1) != 0) ? 1 : 0;
             fa.ncf = fa.half_col ? out_features / bn : (out_features + bn - 1) / bn;
         }
+        fa.early = env_int("SAM3_LORA_FUSED_EARLY", 0) != 0 ? 1 : 0;      // measured slower (fused_linear.inc, EARLY): off
         const long long ntiles = (long long)fa.tiles_m * (fa.ncf + fa.half_col);
         long long grid = env_int("SAM3_LORA_FUSED_WGS", (long long)fused_cu_count() * (pair ? fl::CfgPair::WGS_PER_CU : 1));
         if (grid > ntiles) grid = ntiles;

@@ -37,7 +37,7 @@ def _reload():
 def _knobs_back():
     yield
     if torch.cuda.is_available():
-        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_HL_MAX_RANK"):
+        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_FUSED_EARLY", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_HL_MAX_RANK"):
             os.environ.pop(k, None)
         _reload()
         Fn.set_fused_linear(None)
@@ -136,9 +136,11 @@ def test_persistent_tile_walk_is_bit_identical_for_any_grid():
     x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=3)
     args = (_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), 2.0, 0)
     outs = []
-    for wgs, order, tile in [(w, o, t) for w in ("1", "3", "5", "512") for o in ("0", "1") for t in ("0", "1", "2")]:
-        if True:        # grid size, half-tile scheduling (placement only) and tile configuration (same K order per output element)
+    for wgs, order, tile, early in [(w, o, t, e) for w in ("1", "3", "5", "512") for o in ("0", "1") for t in ("0", "1", "2") for e in ("1", "0")]:
+        if tile == "0" or early == "1":        # grid size, half-tile scheduling (placement only), tile configuration (same K order per output
+            # element) and, for the default configuration, the tile switch with / without the next tile's two K steps issued ahead of the stores
             os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_HALF"], os.environ["SAM3_LORA_FUSED_TILE"] = wgs, order, tile
+            os.environ["SAM3_LORA_FUSED_EARLY"] = early
             _reload()
             for _ in range(3):              # repeated: a race between DMA and read would show as run-to-run differences
                 y, a, _ = Fn.lora_linear_fwd_(*args, gelu=True)
@@ -295,3 +297,28 @@ def test_mlp_node_with_the_mirror_knob_gives_the_default_paths_gradients():
         assert rel(outs[True][i], outs[False][i]) <= 1e-2, (i, rel(outs[True][i], outs[False][i]))
     for i in (4, 5):        # fc2's own weight gradients do not depend on gh
         assert rel(outs[True][i], outs[False][i]) <= 1e-4, (i, rel(outs[True][i], outs[False][i]))
+
+
+@pytest.mark.parametrize("gelu", [True, False])
+def test_early_tile_switch_is_bit_identical_at_the_benchmark_shape(gelu):
+    """The tile switch that issues the next tile's first two K steps BEFORE the epilogue's stores and waits with counted vmcnt
+    (SAM3_LORA_FUSED_EARLY=1; measured slower, not the default) against the drained form (=0) at M = 41,472, 1024 -> 4736, r = 16: 12 tiles per workgroup,
+    half tiles in the mix, four launches each -- a DMA read too early would show as differing bits."""
+    M, fin, fout, rank = 41472, 1024, 4736, 16
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
+    W = (torch.randn(fout, fin, device=DEV, generator=g) / 32).bfloat16()
+    b = (torch.randn(fout, device=DEV, generator=g) * 0.1).bfloat16()
+    A = (torch.rand(fin, rank, device=DEV, generator=g) - 0.5) / 2
+    B = torch.randn(rank, fout, device=DEV, generator=g) * 0.05
+    ref = None
+    for early in ("0", "1", "1", "1", "1"):
+        os.environ["SAM3_LORA_FUSED_EARLY"] = early
+        _reload()
+        y, a, _ = Fn.lora_linear_fwd_(x, W, b, A, B, 2.0, 0, gelu=gelu)
+        if ref is None:
+            ref = (y.clone(), a.clone() if gelu else None)
+        else:
+            assert torch.equal(y, ref[0])
+            if gelu:
+                assert torch.equal(a, ref[1])
