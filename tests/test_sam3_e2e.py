@@ -324,6 +324,54 @@ def test_training_step_through_hip_adapters_matches_reference(gold, ckpt):
     assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
 
 
+O2M_ALPHA, O2M_THRESHOLD, O2M_TOPK = 0.3, 0.4, 4        # trainer.build_criterion's BinaryOneToManyMatcher (the reference's values)
+
+
+def _o2m_report(out, gold, batch, margin=0.025):
+    """The final output's one-to-many assignment (``alpha p + (1 - alpha) IoU`` in the per-target top-k AND above 0.4) against the
+    reference's, re-derived from the reference's stored fp32 outputs.  It is a THRESHOLD decision: a pair whose reference score
+    lies within ``margin`` of the threshold (or of the top-k cut) is decided by the build's rounding noise -- the fixtures hold such
+    pairs (e2e_wide_minimal_r4: the only match of the final output scores 0.4002; e2e_wide: 0.4033 in an auxiliary output), and when
+    one flips, every ``*_o2m`` loss term of that output and with it the first step's total change by tens of percent.
+    Returns {"equal", "fragile_flip", "differing": [(b, q, t, reference score)]}; a difference that is not fragile is a failure."""
+    from sam3_lora_amd.losses import box_cxcywh_to_xyxy, box_iou
+    if "lora/pred_logits_o2m" not in gold.files or out.get("indices_o2m") is None:
+        return {"equal": True, "fragile_flip": False, "differing": []}
+    ft = batch.find_targets[0]
+    tgt, nb = ft.boxes_padded.float().cpu(), ft.num_boxes.cpu()
+    prob = torch.tensor(gold["lora/pred_logits_o2m"]).float().sigmoid().squeeze(-1)
+    iou, _ = box_iou(box_cxcywh_to_xyxy(torch.tensor(gold["lora/pred_boxes_o2m"]).float()), box_cxcywh_to_xyxy(tgt))
+    C = O2M_ALPHA * prob.unsqueeze(-1) + (1 - O2M_ALPHA) * iou
+    nq, nt = C.shape[1], C.shape[2]
+    cut = torch.quantile(C, 1 - O2M_TOPK / nq, dim=1, keepdim=True)
+    valid = (torch.arange(nt)[None] < nb[:, None]).unsqueeze(1)
+    ref = (C > cut) & (C > O2M_THRESHOLD) & valid
+    bi, si, ti = (t.cpu() for t in out["indices_o2m"])
+    offs = torch.cat([torch.zeros(1, dtype=torch.long), nb.long().cumsum(-1)[:-1]])
+    ours = torch.zeros_like(ref)
+    ours[bi, si, ti - offs[bi]] = True
+    diff = torch.nonzero(ours != ref)
+    near = (C - O2M_THRESHOLD).abs().minimum((C - cut).abs()) <= margin
+    differing = [(int(b), int(q), int(t), round(float(C[b, q, t]), 4)) for b, q, t in diff]
+    return {"equal": len(differing) == 0, "fragile_flip": len(differing) > 0 and all(bool(near[b, q, t]) for b, q, t, _ in differing),
+            "differing": differing}
+
+
+def _assert_first_step_loss(m, bound, what):
+    """The first step's total against the reference -- unless the final output's one-to-many assignment flipped on a pair the
+    fixture leaves undecided (:func:`_o2m_report`): then every term that does not hang on that assignment is held to ``bound``
+    (floored at 5 %: single terms are smaller numbers than the total) and the total itself is not compared."""
+    o = m.get("o2m", {"equal": True})
+    assert o["equal"] or o["fragile_flip"], ("the one-to-many assignment differs on a pair that is NOT near its threshold", o)
+    if o["equal"]:
+        assert m["loss_terms"]["core_loss"] <= bound, (what, m["loss_terms"]["core_loss"], bound)
+        return True
+    final_o2m = {k for k in m["loss_terms"] if k.endswith("_o2m") and "_aux_" not in k}
+    worst = max(v for k, v in m["loss_terms"].items() if k not in final_o2m and k != "core_loss")
+    assert worst <= max(bound, 0.05), (what, o, m["loss_terms"])
+    return False
+
+
 def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True):
     """The loop of train_sam3_lora_native.py:887-943; returns what parity is judged on: element-wise errors of the first
     step's outputs against the reference (max |a - ref| / max |ref| per tensor), of the loss dictionary, of the stored A/B
@@ -358,6 +406,7 @@ def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True)
                     m["outputs"][f"aux{i}/{k}"] = float(np.abs(aux[k].detach().float().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12))
             got = torch.stack([out["indices"][0], out["indices"][1]]).cpu().numpy()
             m["indices_equal"] = bool(np.array_equal(got, gold["lora/indices"]))
+            m["o2m"] = _o2m_report(out, gold, batch)
             for k in gold.files:
                 if k.startswith("loss/") and "ce_f1" not in k and "acc" not in k:
                     ref = float(gold[k])
@@ -489,7 +538,8 @@ def test_yaml_configurations_whole_step_matches_reference(case, layout):
     lim = lambda k, mult=1.0: mult * max(yard[k], floor[k])
     assert logit_err <= lim("pred_logits") and box_err <= lim("pred_boxes"), (logit_err, box_err, yard)
     assert m["outputs"]["presence_logit_dec"] <= lim("presence_logit_dec") and m["outputs"]["pred_masks"] <= lim("pred_masks", 2.0), (m["outputs"], yard)
-    assert m["loss_terms"]["core_loss"] <= lim("core_loss"), (m["loss_terms"]["core_loss"], yard)
+    _assert_first_step_loss(m, lim("core_loss"), case)
+    assert max(m["loss_curve_rel"][1:]) <= max(lim("core_loss"), 2e-2), (m["losses"], m["loss_curve_rel"])
     assert all(np.isfinite(m["losses"]))
 
 
@@ -727,8 +777,8 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
     assert box_err <= yard["pred_boxes"], (box_err, yard)
     assert m["outputs"]["presence_logit_dec"] <= yard["presence_logit_dec"], (m["outputs"], yard)
     assert m["outputs"]["pred_masks"] <= 2.0 * yard["pred_masks"], (m["outputs"], yard)
-    assert m["loss_terms"]["core_loss"] <= max(yard["core_loss"], 1e-3), (m["loss_terms"]["core_loss"], yard)
-    assert max(m["loss_curve_rel"]) <= max(yard["core_loss"], 3e-3), (m["losses"], m["loss_curve_rel"])
+    same_o2m = _assert_first_step_loss(m, max(yard["core_loss"], 1e-3), which)
+    assert max(m["loss_curve_rel"][0 if same_o2m else 1:]) <= max(yard["core_loss"], 3e-3), (m["losses"], m["loss_curve_rel"])
     assert len(m["grads"]) >= 6
     # A/B gradients: never beyond the reference's own autocast deviation, and within twice what this build has measured on the
     # fixture (worst adapter 0.155 tiny / 0.146 wide, profiles/r05s_parity_bf16_*.json; the wide yardstick alone -- 0.54 -- would
