@@ -567,6 +567,7 @@ GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 
 
 FULL_BF16_SLACK = 1.5       # see test_full_size_training_step_bf16_layout_against_reference
+FULL_REMATCH_GAP = 0.05     # Hungarian cost units (the full fixture's assignments cost ~15): same test
 
 
 def _full_size_step(layout, islands=None, holes=None, post_layout=None):
@@ -648,7 +649,16 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None):
             got = torch.stack([node["indices"][0], node["indices"][1]]).cpu().numpy()
             same = bool(np.array_equal(got, gold[k]))
             rec["indices_equal"] = rec.get("indices_equal", True) and same
-            rec.setdefault("outputs_with_different_matching", []).extend([] if same else ["/".join(k.split("/")[1:-1]) or "final"])
+            name = "/".join(k.split("/")[1:-1]) or "final"
+            rec.setdefault("outputs_with_different_matching", []).extend([] if same else [name])
+            if not same:
+                # how much worse the REFERENCE's own cost matrix (its stored fp32 scores and boxes) rates this build's assignment
+                # than its optimum: a re-matching onto a near-tied assignment is rounding noise, onto any other one a defect
+                pre = "lora/" + ("" if name == "final" else name + "/")
+                Cr = matcher.cost_matrix(torch.tensor(gold[pre + "pred_logits"]).float().squeeze(-1), torch.tensor(gold[pre + "pred_boxes"]).float(),
+                                         torch.tensor(gold["batch/find_target/boxes_padded"]).float())[0].numpy()
+                cost = lambda idx: float(sum(Cr[q, t] for t, q in enumerate(idx[1])))     # indices[1]: query of target 0, 1, ...
+                rec.setdefault("rematch_cost_gap", {})[name] = cost(got) - cost(gold[k])
             n_idx += 1
             continue
         rec["outputs"]["/".join(k.split("/")[1:])] = err(node[parts[0]], gold[k])
@@ -703,8 +713,12 @@ def test_full_size_training_step_bf16_layout_against_reference():
                       "worst_AB_grad_full4": max(rec["grads_full"].values()), "worst_AB_grad_sampled60": rec["grads_sampled_worst"]}
     _record("full_bf16", rec)
     # the assignment: the reference's own autocast forward re-matches `outputs_with_different_matching` of its 6 outputs at this size
-    # (1: near-tied costs under a 3e-2 move of the logits); this build may not flip more than that
-    assert len(rec["outputs_with_different_matching"]) <= int(yard["outputs_with_different_matching"]), rec["outputs_with_different_matching"]
+    # (1).  Which ones CAN flip is a property of the fixture: by the reference's own fp32 cost matrices three of the six outputs (final,
+    # aux2, aux4) have a second-best assignment within 0.010-0.013 of the optimum (total cost ~15: 0.07-0.09 %), the other three are
+    # 0.15-0.27 away.  A re-matching is accepted where the reference's cost matrix rates this build's assignment within
+    # FULL_REMATCH_GAP = 0.05 of its optimum (between the two groups, a factor 4 from either); seen in eight runs: 0 or 1 outputs.
+    assert all(gap <= FULL_REMATCH_GAP for gap in rec.get("rematch_cost_gap", {}).values()), rec["rematch_cost_gap"]
+    assert len(rec["outputs_with_different_matching"]) <= 3, rec["outputs_with_different_matching"]
     sm = rec["summary"]
     # Bars: FULL_BF16_SLACK x the yardstick (masks 2 x: the mask head stays bf16).  Both sides are single samples of a chaotic quantity --
     # the frozen GEMMs' stream-K reductions are not bit-stable, and a 1e-3 move near a tie re-matches a query: five runs of this test on
