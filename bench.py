@@ -1252,8 +1252,9 @@ def parity_gates(dev, args):
             "one image) re-run here in the layout this line times: max-abs error over max|ref| per output class, loss and worst A/B gradient, "
             "outputs (final + 5 auxiliary) whose Hungarian matching differs; bar = the reference's own autocast(bf16) deviation at that size "
             "(x 1.5 on logits / boxes / presence, x 2 on masks: the bars of test_full_size_training_step_bf16_layout_against_reference); a "
-            "re-matched output passes where the reference's own fp32 cost matrix rates this build's assignment within 0.05 of its optimum "
-            "(`rematch_cost_gap`; three of the fixture's six outputs have a second-best assignment 0.010-0.013 away, the others 0.15-0.27)"))
+            "re-matched output passes where the reference's own fp32 cost matrix rates this build's assignment within 0.10 of its optimum "
+            "(`rematch_cost_gap`, of ~15: what a 5e-3 box deviation moves a pair's cost by; three of the fixture's six outputs have five more "
+            "assignments within 0.05, the other three none within 0.15)"))
         torch.cuda.empty_cache()
     except Exception as e:
         gates["full_size_step_vs_reference"] = {"error": f"{type(e).__name__}: {str(e)[:300]}", "pass": False}

@@ -567,7 +567,7 @@ GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 
 
 FULL_BF16_SLACK = 1.5       # see test_full_size_training_step_bf16_layout_against_reference
-FULL_REMATCH_GAP = 0.05     # Hungarian cost units (the full fixture's assignments cost ~15): same test
+FULL_REMATCH_GAP = 0.10     # Hungarian cost units (the full fixture's assignments cost ~15): same test
 
 
 def _full_size_step(layout, islands=None, holes=None, post_layout=None):
@@ -714,9 +714,11 @@ def test_full_size_training_step_bf16_layout_against_reference():
     _record("full_bf16", rec)
     # the assignment: the reference's own autocast forward re-matches `outputs_with_different_matching` of its 6 outputs at this size
     # (1).  Which ones CAN flip is a property of the fixture: by the reference's own fp32 cost matrices three of the six outputs (final,
-    # aux2, aux4) have a second-best assignment within 0.010-0.013 of the optimum (total cost ~15: 0.07-0.09 %), the other three are
-    # 0.15-0.27 away.  A re-matching is accepted where the reference's cost matrix rates this build's assignment within
-    # FULL_REMATCH_GAP = 0.05 of its optimum (between the two groups, a factor 4 from either); seen in eight runs: 0 or 1 outputs.
+    # aux2, aux4) have FIVE further assignments within 0.010-0.05 of the optimum (total cost ~15), the other three outputs none
+    # within 0.15-0.27.  A re-matching is accepted where the reference's cost matrix rates this build's assignment within
+    # FULL_REMATCH_GAP = 0.10 of its optimum: the cost is 5 x L1 over four box coordinates + 2 x class + 2 x GIoU, so a box deviation of
+    # 5e-3 per coordinate -- a tenth of the yardstick's 5.3e-2 maximum -- moves a pair's cost by 0.1; it stays below every gap of the
+    # robust group.  Seen: aux2 re-matched onto an assignment 0.041 away (two runs), otherwise none.
     assert all(gap <= FULL_REMATCH_GAP for gap in rec.get("rematch_cost_gap", {}).values()), rec["rematch_cost_gap"]
     assert len(rec["outputs_with_different_matching"]) <= 3, rec["outputs_with_different_matching"]
     sm = rec["summary"]
