@@ -357,6 +357,38 @@ def _o2m_report(out, gold, batch, margin=0.025):
             "differing": differing}
 
 
+SMALL_REMATCH_GAP = 0.05        # Hungarian cost units; the small fixtures' assignments cost 2-6 per image
+
+
+def _rematch_report(out, gold, batch):
+    """Final and auxiliary outputs whose Hungarian assignment differs from the reference's, each with the amount by which the
+    REFERENCE's own cost matrix (its stored fp32 scores and boxes) rates this build's assignment above its optimum.  Gaps to the
+    second-best assignment in the fixtures (final output): tiny 0.12 / 0.26, wide 0.33 / 0.017, wide_large_r32 0.018 / 0.27,
+    wide_minimal_r4 0.14 / 1.2 -- a bf16 layout can flip the small ones (it has not in a dozen runs); {} = all as the reference."""
+    matcher, _ = _criterion()
+    ft = batch.find_targets[0]
+    tgt, nb = ft.boxes_padded.float().cpu(), [int(v) for v in ft.num_boxes.cpu()]
+    gaps = {}
+    for name, node, pre in [("final", out, "lora/")] + [(f"aux{i}", a, f"lora/aux{i}/") for i, a in enumerate(out["aux_outputs"])]:
+        if pre + "indices" not in gold.files:
+            continue
+        got = torch.stack([node["indices"][0], node["indices"][1]]).cpu().numpy()
+        ref = gold[pre + "indices"]
+        if np.array_equal(got, ref):
+            continue
+        Cr = matcher.cost_matrix(torch.tensor(gold[pre + "pred_logits"]).float().squeeze(-1), torch.tensor(gold[pre + "pred_boxes"]).float(), tgt).numpy()
+
+        def cost(idx):      # entries of an image are listed in target order
+            seen, tot = {}, 0.0
+            for b, q in zip(idx[0], idx[1]):
+                t = seen.get(int(b), 0)
+                seen[int(b)] = t + 1
+                tot += float(Cr[int(b), int(q), t])
+            return tot
+        gaps[name] = cost(got) - cost(ref) if got.shape == ref.shape else float("inf")
+    return gaps
+
+
 def _assert_first_step_loss(m, bound, what):
     """The first step's total against the reference -- unless the final output's one-to-many assignment flipped on a pair the
     fixture leaves undecided (:func:`_o2m_report`): then every term that does not hang on that assignment is held to ``bound``
@@ -407,6 +439,7 @@ def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True)
             got = torch.stack([out["indices"][0], out["indices"][1]]).cpu().numpy()
             m["indices_equal"] = bool(np.array_equal(got, gold["lora/indices"]))
             m["o2m"] = _o2m_report(out, gold, batch)
+            m["rematch_cost_gap"] = _rematch_report(out, gold, batch)
             for k in gold.files:
                 if k.startswith("loss/") and "ce_f1" not in k and "acc" not in k:
                     ref = float(gold[k])
@@ -538,8 +571,10 @@ def test_yaml_configurations_whole_step_matches_reference(case, layout):
     lim = lambda k, mult=1.0: mult * max(yard[k], floor[k])
     assert logit_err <= lim("pred_logits") and box_err <= lim("pred_boxes"), (logit_err, box_err, yard)
     assert m["outputs"]["presence_logit_dec"] <= lim("presence_logit_dec") and m["outputs"]["pred_masks"] <= lim("pred_masks", 2.0), (m["outputs"], yard)
-    _assert_first_step_loss(m, lim("core_loss"), case)
-    assert max(m["loss_curve_rel"][1:]) <= max(lim("core_loss"), 2e-2), (m["losses"], m["loss_curve_rel"])
+    assert all(gap <= SMALL_REMATCH_GAP for gap in m["rematch_cost_gap"].values()), m["rematch_cost_gap"]
+    if not m["rematch_cost_gap"]:           # (a re-matched output's loss terms belong to another assignment: _rematch_report)
+        _assert_first_step_loss(m, lim("core_loss"), case)
+    assert max(m["loss_curve_rel"][1:]) <= (0.05 if m["rematch_cost_gap"] else max(lim("core_loss"), 2e-2)), (m["losses"], m["loss_curve_rel"])
     assert all(np.isfinite(m["losses"]))
 
 
@@ -786,13 +821,21 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
     assert out["pred_masks"].dtype == torch.bfloat16 and out["encoder_hidden_states"].dtype == torch.bfloat16
     # scores and boxes leave in fp32 (matcher cost, box losses)
     assert out["pred_logits"].dtype == out["pred_boxes"].dtype == out["presence_logit_dec"].dtype == torch.float32
-    assert m["indices_equal"]
     logit_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_logits"))
     box_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes"))
     assert logit_err <= yard["pred_logits"], (logit_err, yard)
     assert box_err <= yard["pred_boxes"], (box_err, yard)
     assert m["outputs"]["presence_logit_dec"] <= yard["presence_logit_dec"], (m["outputs"], yard)
     assert m["outputs"]["pred_masks"] <= 2.0 * yard["pred_masks"], (m["outputs"], yard)
+    # the assignment: the reference's, or one the reference's own cost matrix rates within SMALL_REMATCH_GAP of it (_rematch_report;
+    # the wide fixture's second image has a second-best assignment 0.017 away).  With a re-matched output the loss and the gradients
+    # belong to another assignment: what does not depend on it has been checked above, the loss curve from the second step on below.
+    assert all(gap <= SMALL_REMATCH_GAP for gap in m["rematch_cost_gap"].values()), m["rematch_cost_gap"]
+    if m["rematch_cost_gap"]:
+        assert not m["indices_equal"] or "final" not in m["rematch_cost_gap"]
+        assert all(np.isfinite(m["losses"])) and max(m["loss_curve_rel"][1:]) <= 0.05, (m["losses"], m["loss_curve_rel"])
+        return
+    assert m["indices_equal"]
     same_o2m = _assert_first_step_loss(m, max(yard["core_loss"], 1e-3), which)
     assert max(m["loss_curve_rel"][0 if same_o2m else 1:]) <= max(yard["core_loss"], 3e-3), (m["losses"], m["loss_curve_rel"])
     assert len(m["grads"]) >= 6
