@@ -330,7 +330,7 @@ O2M_ALPHA, O2M_THRESHOLD, O2M_TOPK = 0.3, 0.4, 4        # trainer.build_criterio
 def _o2m_report(out, gold, batch, margin=0.025):
     """The final output's one-to-many assignment (``alpha p + (1 - alpha) IoU`` in the per-target top-k AND above 0.4) against the
     reference's, re-derived from the reference's stored fp32 outputs.  It is a THRESHOLD decision: a pair whose reference score
-    lies within ``margin`` of the threshold (or of the top-k cut) is decided by the build's rounding noise -- the fixtures hold such
+    lies within ``margin`` of the larger of the threshold and its target's top-k cut is decided by the build's rounding noise -- the fixtures hold such
     pairs (e2e_wide_minimal_r4: the only match of the final output scores 0.4002; e2e_wide: 0.4033 in an auxiliary output), and when
     one flips, every ``*_o2m`` loss term of that output and with it the first step's total change by tens of percent.
     Returns {"equal", "fragile_flip", "differing": [(b, q, t, reference score)]}; a difference that is not fragile is a failure."""
@@ -351,7 +351,7 @@ def _o2m_report(out, gold, batch, margin=0.025):
     ours = torch.zeros_like(ref)
     ours[bi, si, ti - offs[bi]] = True
     diff = torch.nonzero(ours != ref)
-    near = (C - O2M_THRESHOLD).abs().minimum((C - cut).abs()) <= margin
+    near = (C - cut.clamp(min=O2M_THRESHOLD)).abs() <= margin        # a pair is positive iff its score exceeds BOTH the top-k cut and the threshold
     differing = [(int(b), int(q), int(t), round(float(C[b, q, t]), 4)) for b, q, t in diff]
     return {"equal": len(differing) == 0, "fragile_flip": len(differing) > 0 and all(bool(near[b, q, t]) for b, q, t, _ in differing),
             "differing": differing}
@@ -956,3 +956,35 @@ def test_training_layout_islands_and_holes_on_cpu(gold):
     assert n_hooks == 2 + len(model._sam3_fp32_holes) + 1          # two islands, the holes, the mask head that consumes the queries
     to_training_layout(model, fp32_islands=())
     assert model._sam3_layout_hooks == [] and all(p.dtype == torch.bfloat16 for p in model.parameters() if not p.requires_grad)
+
+
+def test_assignment_reports_on_the_references_own_data():
+    """No GPU: the two reports the bf16-layout tests judge assignments with, fed the reference's stored outputs.  The reference's
+    own Hungarian indices give no re-matched output; moving one target to another query gives that output with a positive cost gap.
+    The one-to-many report re-derives the reference's threshold decisions: equal on them; dropping the minimal-r4 fixture's single
+    match (score 0.4002 against the threshold 0.4) is a fragile flip; adding a pair that scores far below the threshold is not."""
+    batch = make_batch_wide()
+    g = np.load(os.path.join(os.path.dirname(GOLD), "e2e_wide.npz"))
+
+    def node(pre, change=None):
+        idx = g[pre + "indices"].copy()
+        if change:
+            idx[1][change[0]] = change[1]
+        return {"indices": (torch.tensor(idx[0]), torch.tensor(idx[1]))}
+    out = dict(node("lora/"), aux_outputs=[node("lora/aux0/"), node("lora/aux1/")])
+    assert _rematch_report(out, g, batch) == {}
+    out = dict(node("lora/", (2, 5)), aux_outputs=[node("lora/aux0/"), node("lora/aux1/", (0, 3))])
+    rep = _rematch_report(out, g, batch)
+    assert set(rep) == {"final", "aux1"} and all(v > SMALL_REMATCH_GAP for v in rep.values()), rep
+
+    g4 = np.load(os.path.join(os.path.dirname(GOLD), "e2e_wide_minimal_r4.npz"))
+    nb = batch.find_targets[0].num_boxes
+    offs = torch.cat([torch.zeros(1, dtype=torch.long), nb.long().cumsum(-1)[:-1]])
+    as_indices = lambda pairs: tuple(torch.tensor(v, dtype=torch.long) for v in
+                                     ([b for b, _, _ in pairs], [q for _, q, _ in pairs], [t + int(offs[b]) for b, _, t in pairs]))
+    ref_pairs = [(1, 16, 0)]                                  # the reference's only one-to-many match of the final output
+    assert _o2m_report({"indices_o2m": as_indices(ref_pairs)}, g4, batch) == {"equal": True, "fragile_flip": False, "differing": []}
+    rep = _o2m_report({"indices_o2m": as_indices([])}, g4, batch)
+    assert not rep["equal"] and rep["fragile_flip"] and rep["differing"] == [(1, 16, 0, 0.4002)], rep
+    rep = _o2m_report({"indices_o2m": as_indices(ref_pairs + [(0, 3, 1)])}, g4, batch)
+    assert not rep["equal"] and not rep["fragile_flip"], rep
