@@ -287,7 +287,7 @@ unsigned sam3_lora_debug_set_stages(unsigned mask);
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
  * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_WGS,
  * SAM3_LORA_FUSED_HALF, SAM3_LORA_FUSED_EARLY, SAM3_LORA_FUSED_TILE, SAM3_LORA_FUSED_PROBE, SAM3_LORA_HL_MAX_RANK, SAM3_LORA_BWD_V2, SAM3_LORA_BWD_XGX,
- * SAM3_LORA_BWD_FORK, SAM3_LORA_T3W_WGS, SAM3_LORA_XCD_ORDER, SAM3_LORA_GA_IN_T2, SAM3_LORA_T1_BK; INTEGRATION.md section D says what each selects) are read from the
+ * SAM3_LORA_BWD_FORK, SAM3_LORA_T3_RIDE, SAM3_LORA_T3_ONESET, SAM3_LORA_T3W_WGS, SAM3_LORA_XCD_ORDER, SAM3_LORA_GA_IN_T2, SAM3_LORA_T1_BK; INTEGRATION.md section D says what each selects) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);

@@ -613,11 +613,27 @@ struct GaEmit {
     const bf16_t* GTTf;     // gt, fragment-major (k_gt_reduce<HL> / store_t4_hl): [32-row step][hi | lo][64 lanes][8]
     float* part;            // [row blocks][16][N]
 };
-template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false>
+// T3R: the grid's rows [ride.rows, ride.rows + t3.NR) run k_t3's blocks -- gA^T = gt^T . x over the layer's input, the backward's other
+// consumer of gt -- instead of launching them on their own: at in_features = 1024 the two are 22 + 37 us kernels, each a third ramp and
+// tail (t3_body; SAM3_LORA_T3_RIDE).  Their partials are complete only when this launch is: gA's fixed-order sum follows as a launch.
+struct T3Ride {
+    const bf16_t* X;        // the layer's input [M, N]
+    long long ldx;
+    const bf16_t* TTf;      // gt, fragment-major
+    float* Gpart;           // [NR][16][N]
+    long long Mp;
+    int rows_per_wg, NR, xcd_order;
+};
+template <typename XT, int RT, bool GATHER, bool DROP, bool HL, bool ONE>
+__device__ __forceinline__ void t3_body(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
+                                        long long M, long long Mp, int N, int rows_per_wg, const DropKey& dk, unsigned ptile, unsigned nchunks,
+                                        uint4 (*xs)[32 * 16]);
+template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false, bool T3R = false>
 __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
-                                            ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga) {
+                                            ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga, T3Ride t3) {
+    static_assert(!T3R || (ACT == 0 && HL && RT == 2 && !DROP && !Q8 && !GA && sizeof(YT) == 2), "k_t3's blocks ride on the plain hi + lo gx update, r <= 16, no mask");
     static_assert(!GA || (ACT == 2 && HL && RT == 2 && !DROP && sizeof(YT) == 2), "the in-pass gA contraction: GELU' pass of the hi + lo kernels, r <= 16");
     static_assert(!Q8 || ACT != 0, "the fp8 image is the one of the activation-fused passes");
     static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: RT / 2 rank tiles, each as [hi 4 | lo 4] per 4 rank indices");
@@ -635,9 +651,21 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
             reduce_block(e < ride.nblk ? ride.j0 : ride.j1, e % ride.nblk, ride.scale, ride.accumulate, &slab_all[0][0]);
         return;
     }
+    unsigned lead = (unsigned)ride.rows;        // grid rows in front of the body's
+    if (T3R) {
+        if (blockIdx.y < lead + (unsigned)t3.NR) {
+            static_assert(sizeof(slab_all) >= 4 * 32 * 16 * sizeof(uint4), "k_t3's 32 KB of slabs fit this kernel's");
+            unsigned ptile = (blockIdx.y - lead) * gridDim.x + blockIdx.x;
+            if (t3.xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * (unsigned)t3.NR);
+            t3_body<bf16_t, 2, false, false, true, true>(t3.X, t3.ldx, t3.TTf, t3.Gpart, M, t3.Mp, N, t3.rows_per_wg, DropKey{0u, 0u, 0}, ptile, gridDim.x,
+                                                   reinterpret_cast<uint4(*)[32 * 16]>(&slab_all[0][0]));
+            return;
+        }
+        lead += (unsigned)t3.NR;
+    }
     // body tile (bx = column block, by = row block): all column blocks of a row block on one XCD (they share its T rows)
-    unsigned pbody = (blockIdx.y - (unsigned)ride.rows) * gridDim.x + blockIdx.x;
-    if (xcd_order) pbody = xcd_tile_index(pbody, gridDim.x * (gridDim.y - (unsigned)ride.rows));
+    unsigned pbody = (blockIdx.y - lead) * gridDim.x + blockIdx.x;
+    if (xcd_order) pbody = xcd_tile_index(pbody, gridDim.x * (gridDim.y - lead));
     const unsigned bx = pbody % gridDim.x, by = pbody / gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
@@ -840,21 +868,20 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
 
 // HL (RT == 2): the two fragment blocks of a step are the hi and lo parts of the same 16 rank indices and accumulate
 // into ONE rank tile (RTA = 1): G = t_hi^T X + t_lo^T X.
-template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false>
-__global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(const XT* __restrict__ X, long long ldx,
-                                            const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
-                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk, int xcd_order) {
+// The kernel's body as a function of its tile number: k_t3 is the launch of its own, k_t2<T3R> runs the same blocks as leading rows of
+// the gx update's grid (the two passes of a backward call that only share gt: one launch instead of two).
+// `ptile`: tile number (column chunk fastest), `nchunks`: column chunks of N, `xs`: 32 KB of the workgroup's LDS.
+template <typename XT, int RT, bool GATHER, bool DROP, bool HL, bool ONE>
+__device__ __forceinline__ void t3_body(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
+                                        long long M, long long Mp, int N, int rows_per_wg, const DropKey& dk, unsigned ptile, unsigned nchunks,
+                                        uint4 (*xs)[32 * 16]) {
     static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: fragment blocks [hi tiles | lo tiles] per step");
     constexpr int RTA = HL ? RT / 2 : RT;       // rank tiles of the result
     constexpr int RP = RTA * 16, CW = 128, CPR = 16;
-    __shared__ uint4 xs[4][32 * CPR];      // 32 rows x 256 B per wave; reused as the reduction buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    // tile (column chunk, row group): the chunks of a row group on one XCD (they share its t^T fragments)
-    unsigned ptile = blockIdx.y * gridDim.x + blockIdx.x;
-    if (xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * gridDim.y);
-    const int c0 = (int)(ptile % gridDim.x) * CW;
-    const int rg = (int)(ptile / gridDim.x);
+    const int c0 = (int)(ptile % nchunks) * CW;
+    const int rg = (int)(ptile / nchunks);
     // rows of this wave: quarter `wave` of [rg*rows_per_wg, +rows_per_wg), rows_per_wg % 128 == 0
     const long long w_begin = (long long)rg * rows_per_wg + (long long)wave * (rows_per_wg / 4);
     long long w_end = w_begin + rows_per_wg / 4;
@@ -891,7 +918,7 @@ __global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(co
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     uint4* slab = xs[wave];
-    auto stage = [&](int s0, const Regs& r_) {
+    auto put = [&](int s0, const Regs& r_) {          // the step's 32 x 128 tile into the wave's slab
         const long long mb = w_begin + (long long)s0 * 32;
         const unsigned smask = s0 < nst ? cmask : 0u;
 #pragma unroll
@@ -902,6 +929,8 @@ __global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(co
             if (DROP) v = drop8(v, (unsigned long long)m * dk.width + col, dk);
             slab[row * CPR + (lc ^ (t3_h(row) << 1))] = v;
         }
+    };
+    auto eat = [&](const uint4* tf) {                  // acc += t^T (fragments tf) . slab
         wave_sync();
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -935,13 +964,34 @@ __global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(co
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
                 // D[i = rank idx][n = column] += sum_m T[m][i] * X[m][col]
-                acc[rt % RTA][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[rt]), xf,
+                acc[rt % RTA][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, tf[rt]), xf,
                                                                            acc[rt % RTA][ct], 0, 0, 0);    // HL: hi and lo block of a tile -> one accumulator
         }
         wave_sync();
     };
+    auto stage = [&](int s0, const Regs& r_) {
+        put(s0, r_);
+        eat(r_.t);
+    };
 
-    if (nst > 0) {
+    if (ONE) {
+        // ONE register set: the slab is the second buffer.  The step's tile goes to the LDS, the NEXT step's loads are issued into the
+        // same registers, and the MFMAs then run on the slab with those loads in flight -- ~100 registers instead of ~200: four waves
+        // per SIMD instead of two (and the form that fits inside k_t2<T3R>, whose launch keeps four).
+        if (nst > 0) {
+            Regs r;
+            gload(0, r);
+            for (int s = 0; s < nst; ++s) {
+                uint4 tc[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) tc[rt] = r.t[rt];
+                put(s, r);
+                gload(s + 1, r);       // clamped to the last step at the end (harmless re-read)
+                __builtin_amdgcn_sched_barrier(0);
+                eat(tc);
+            }
+        }
+    } else if (nst > 0) {
         Regs rA, rB;               // distance-1 prefetch, two named register sets (see k_t1)
         gload(0, rA);
         for (int s = 0; s < nst2; s += 2) {
@@ -977,6 +1027,17 @@ __global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(co
             }
         }
     }
+}
+
+template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false, bool ONE = false>
+__global__ __launch_bounds__(256, ONE ? 4 : (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(const XT* __restrict__ X, long long ldx,
+                                            const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
+                                            long long M, long long Mp, int N, int rows_per_wg, DropKey dk, int xcd_order) {
+    __shared__ uint4 xs[4][32 * 16];       // 32 rows x 256 B per wave; reused as the reduction buffer
+    // tile (column chunk, row group): the chunks of a row group on one XCD (they share its t^T fragments)
+    unsigned ptile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * gridDim.y);
+    t3_body<XT, RT, GATHER, DROP, HL, ONE>(X, ldx, TTf, Gpart, M, Mp, N, rows_per_wg, dk, ptile, gridDim.x, xs);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1590,6 +1651,16 @@ T3Plan plan_t3w(long long Mp, int N) {
 }
 // version 2 of the bf16 backward (k_t3w, k_xgx): hi + lo kernels, one rank group of <= 16; SAM3_LORA_BWD_V2=0 restores k_t3e
 bool bwd_v2_enabled() { return env_int("SAM3_LORA_BWD_V2", 1) != 0; }
+// k_t3 (gA) as leading blocks of k_t2's launch over gx (k_t2<T3R>): SAM3_LORA_T3_RIDE = 0 off (default), 1 narrow inputs (<= 1024),
+// 2 always.  Built to save one of the two 22-37 us launches of a narrow backward; bit-identical; MEASURED SLOWER on MI355X, M = 41,472,
+// three interleaved rounds (profiles/r05ad_t3_ride_sweep.json): fc1 backward 139.6-141.0 us riding against 132.7-135.9 us as two
+// launches, fc2 backward (in = 4736) 262 against 249 -- inside k_t2's launch the blocks must live with 128 registers (t3_body<ONE>:
+// one register set, the LDS slab as the second buffer), a form that is 3 % slower than the two-set one on its own as well
+// (SAM3_LORA_T3_ONESET=1: k_t3 76-78 us against 74-75 at 4736), and gA's sum becomes a launch of its own.
+bool t3_ride_enabled(int in_features) {
+    const long long m = env_int("SAM3_LORA_T3_RIDE", 0);
+    return m >= 2 || (m == 1 && in_features <= 1024);
+}
 
 int check_common(long long M, int in_f, int out_f, int rank, int layout, int dtype) {
     if (M <= 0 || M >= (1LL << 31)) return fail(SAM3_LORA_EINVAL, "M must be in [1, 2^31) (got %lld)", M);
@@ -1659,7 +1730,8 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_HL_MAX_RANK", false, 0},
                   {"SAM3_LORA_T1_BK", false, 0},
                   {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_BWD_XGX", false, 0},   {"SAM3_LORA_T3W_WGS", false, 0},
-                  {"SAM3_LORA_BWD_FORK", false, 0},    {"SAM3_LORA_FUSED_EARLY", false, 0}};
+                  {"SAM3_LORA_BWD_FORK", false, 0},    {"SAM3_LORA_FUSED_EARLY", false, 0},
+                  {"SAM3_LORA_T3_RIDE", false, 0},      {"SAM3_LORA_T3_ONESET", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1877,9 +1949,10 @@ bool ga_in_t2_enabled() { return env_flag("SAM3_LORA_GA_IN_T2"); }
 template <typename YT>
 void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT, bool hl,
                hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0,
-               const ReduceRide* ride_in = nullptr, const Q8Out* q8_in = nullptr, const GaEmit* ga_in = nullptr) {
+               const ReduceRide* ride_in = nullptr, const Q8Out* q8_in = nullptr, const GaEmit* ga_in = nullptr, const T3Ride* t3_in = nullptr) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
+    const T3Ride t3 = t3_in ? *t3_in : T3Ride{nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
     // 3 tiles per wave measured best on MI355X for both N = 4736 and N = 1024 at M = 41472 (sweep 4..48:
     // 121 / 36 us at 12 vs 125 / 37 us at 32 / 8); fewer per workgroup only when that leaves too few workgroups.
     long long tiles_per_wg = 12;
@@ -1892,13 +1965,18 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
         ride = *ride_in;
         ride.rows = (int)((2LL * ride.nblk + nchunks - 1) / nchunks);
     }
-    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows);
+    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows + (unsigned)t3.NR);
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
     const Q8Out q8 = q8_in ? *q8_in : Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
     const int xcd = xcd_order_for(N);
+    if (t3_in) {    // checked by the caller: bf16, hi + lo, r <= 16, plain update (no activation, no mask, no fp8 image)
+        hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 0, true, false, 0, false, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
+                           (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga, t3);
+        return;
+    }
     if (q8.q && !ga_in) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
 #define T2_Q8(AV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, AV, true, true, FV>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
-                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga, t3)
         if (act == 1) { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(1, SAM3_FP8_E4M3); else T2_Q8(1, SAM3_FP8_E5M2); }
         else { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(2, SAM3_FP8_E4M3); else T2_Q8(2, SAM3_FP8_E5M2); }
 #undef T2_Q8
@@ -1906,7 +1984,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     }
     if (ga_in) {    // checked by the caller: bf16, hi + lo, GELU' pass, no dropout mask
 #define T2_GA(QV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, QV, FV, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
-                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga, t3)
         if (!q8.q) T2_GA(false, 0);
         else if (q8.fmt == SAM3_FP8_E4M3) T2_GA(true, SAM3_FP8_E4M3);
         else T2_GA(true, SAM3_FP8_E5M2);
@@ -1915,7 +1993,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     }
 #define T2_LAUNCH(RTV, DV, AV, HV) \
     hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV, HV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
-                       (YT*)aux, ldaux, ride, q8, xcd, ga)
+                       (YT*)aux, ldaux, ride, q8, xcd, ga, t3)
 #define T2_RT(RTV, HV)                                                                     \
     do {                                                                               \
         if (act == 1) T2_LAUNCH(RTV, false, 1, HV);            /* forward: no mask on y */   \
@@ -1942,7 +2020,10 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
     } else if (hl && RT == 4) {
         if (gather) T3_LAUNCH(4, true, true); else T3_LAUNCH(4, false, true);
     } else if (hl) {
-        if (gather) T3_LAUNCH(2, true, true); else T3_LAUNCH(2, false, true);
+        if (gather) T3_LAUNCH(2, true, true);
+        else if (!dk.thr && env_flag("SAM3_LORA_T3_ONESET"))     // one register set, four waves per SIMD (t3_body<ONE>)
+            hipLaunchKernelGGL((k_t3<XT, 2, false, false, true, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk, xcd);
+        else T3_LAUNCH(2, false, true);
     } else {
         if (gather) T3_LAUNCH(2, true, false); else T3_LAUNCH(2, false, false);
     }
@@ -2410,6 +2491,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     bool one_pass = false, ga_in_pass = false, v2 = false;
     SideStream* side = nullptr;
     std::unique_lock<std::mutex> side_lock;
+    bool t3ride = false;
     if (f32) {
         const float* T32 = (const float*)tT_saved;
         if (!T32) {     // no saved t: recompute t = drop(x) . A_c
@@ -2476,7 +2558,11 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && RG == 16 && !dk.thr && (x == nullptr || ga_in_t2_enabled());
         // (x == NULL with the in-pass form switched off by a partial debug stage mask: nothing can read the input -- skip, the
         // header says a partial mask leaves the outputs meaningless)
-        if (gA_g && s3a && !ga_in_pass && x) {
+        // k_t3's blocks as leading rows of the gx update's launch (k_t2<T3R>): plain hi + lo backward of r <= 16 without a mask.
+        // Not while sam3_lora_prof_start is timing launches (the per-kernel times are those of the separate kernels).
+        t3ride = gA_g && s3a && !ga_in_pass && x && gx_inout && s2 && hl && RG == 16 && RT == 2 && !dk.thr && a2 == 0 && !q8 &&
+                 stage_on(SAM3_LORA_STAGE_REDUCE) && !g_prof.mask && t3_ride_enabled(in_features);
+        if (gA_g && s3a && !ga_in_pass && x && !t3ride) {
             if (gx_inout && s2 && stage_on(SAM3_LORA_STAGE_REDUCE))
                 side = side_stream_for(st, M * (long long)in_features * 2);
             hipStream_t sa = st;
@@ -2506,7 +2592,7 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         ride.accumulate = accumulate;
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
         ride.nblk = (int)(((nb > na ? nb : na) + 63) / 64);
-        if (side) {     // gA was summed on the side stream
+        if (side || t3ride) {     // gA is summed on the side stream / after the launch that produces its partials
             ride.j1 = ReduceJob{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
             ride.nblk = (int)((nb + 63) / 64);
         }
@@ -2515,13 +2601,19 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     // (with the gA partials produced BY that kernel the sum cannot ride on it: it follows as its own launch)
     const bool riding = want_reduce && !f32 && gx_inout && s2 && !ga_in_pass && !env_flag("SAM3_LORA_NO_RIDE");
     const GaEmit ga{(const bf16_t*)(ws + w.gtt), PA};
+    const T3Ride t3{(const bf16_t*)x, ldx, (const bf16_t*)(ws + w.gtt), PA, Mp, (int)w.pA.rows_per_wg, (int)w.pA.NR, xcd_order_for(in_features)};
     if (!f32 && gx_inout && s2)
         launch_t2<bf16_t>(gx_inout, ldgx, (bf16_t*)(ws + w.gt), (const bf16_t*)W2tb, M, in_features, scale, RT, hl, st, dk, a2, hpre,
-                          ldpre, riding ? &ride : nullptr, a2 ? q8 : nullptr, ga_in_pass ? &ga : nullptr);
+                          ldpre, riding ? &ride : nullptr, a2 ? q8 : nullptr, ga_in_pass ? &ga : nullptr, t3ride ? &t3 : nullptr);
     if (want_reduce && !riding) {
         dim3 grid((unsigned)ride.nblk, 2);
         ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
         hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, ride.j0, ride.j1, scale, accumulate);
+    }
+    if (t3ride) {       // gA's partials came out of that launch: their fixed-order sum
+        const ReduceJob ja{PA, gA_g, w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
+        const ReduceJob none{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)(((long long)rank * in_features + 63) / 64), 1), dim3(256), 0, st, ja, none, scale, accumulate);
     }
     if (side) hipStreamWaitEvent(st, side->join, 0);
 }

@@ -726,8 +726,10 @@ def test_backward_versions_agree_with_each_other_and_the_oracle(monkeypatch, M, 
     gx_l, gA_w, gB_w = O.adapter_backward(gy, x, A, B, s, 0, drop_scale_mask=mask, acc_dtype=np.float64)
     dA, dB = _t(A), _t(B)
     outs = {}
-    for name, env in (("v2", {}), ("v1", {"SAM3_LORA_BWD_V2": "0"}), ("v2+xgx", {"SAM3_LORA_BWD_XGX": "1"})):
-        for k in ("SAM3_LORA_BWD_V2", "SAM3_LORA_BWD_XGX"):
+    for name, env in (("v2", {"SAM3_LORA_T3_RIDE": "0"}), ("v1", {"SAM3_LORA_BWD_V2": "0", "SAM3_LORA_T3_RIDE": "0"}),
+                      ("v2+xgx", {"SAM3_LORA_BWD_XGX": "1"}), ("v2+t3ride", {"SAM3_LORA_T3_RIDE": "2"}),
+                      ("v2+t3oneset", {"SAM3_LORA_T3_RIDE": "0", "SAM3_LORA_T3_ONESET": "1"})):
+        for k in ("SAM3_LORA_BWD_V2", "SAM3_LORA_BWD_XGX", "SAM3_LORA_T3_RIDE", "SAM3_LORA_T3_ONESET"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -741,12 +743,17 @@ def test_backward_versions_agree_with_each_other_and_the_oracle(monkeypatch, M, 
         _one_rounding(outs[name][0], gxb + gx_l)
         ea, eb = _relmax(outs[name][1], gA_w), _relmax(outs[name][2], gB_w)
         assert ea < 3e-5 and eb < 3e-5, (name, ea, eb)
-    for k in ("SAM3_LORA_BWD_V2", "SAM3_LORA_BWD_XGX"):
+    for k in ("SAM3_LORA_BWD_V2", "SAM3_LORA_BWD_XGX", "SAM3_LORA_T3_RIDE", "SAM3_LORA_T3_ONESET"):
         monkeypatch.delenv(k, raising=False)
     _reload_knobs()
     # gx does not depend on how gt's partials were laid out (the same fixed-order sum, the same hi + lo split): bit-identical
     assert np.array_equal(outs["v2"][0], outs["v2+xgx"][0])
     assert np.array_equal(outs["v2"][2], outs["v2+xgx"][2])          # gB: the same k_t3w partials through the same sum
+    # k_t3's blocks riding on k_t2's launch (k_t2<T3R>; without a mask): the same blocks, the same sums -- every output bit-identical
+    if not p:
+        for other in ("v2+t3ride", "v2+t3oneset"):      # (one register set: the same MFMAs in the same order)
+            for a, b in zip(outs["v2"], outs[other]):
+                assert np.array_equal(a, b), other
 
 
 def test_riding_reduction_is_bit_identical_to_the_separate_launch(monkeypatch):
