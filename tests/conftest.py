@@ -18,3 +18,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _same_random_inputs_every_run(request):
+    """Tests that draw inputs without seeding (a handful) get the same draws in every run: a test either passes always or never."""
+    import zlib
+
+    import numpy as np
+    import torch
+    seed = zlib.crc32(request.node.nodeid.encode()) % (2 ** 31)
+    torch.manual_seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    yield

@@ -873,7 +873,8 @@ def test_fast_multihead_attention_equals_the_stock_module(batch_first, case, mas
     import torch.nn as nn
     from sam3_lora_amd.sam3_detr import MultiheadAttention
     dev = "cuda:0"
-    torch.manual_seed(hash((batch_first, case, masking)) % 1000)
+    import zlib
+    torch.manual_seed(zlib.crc32(repr((batch_first, case, masking)).encode()) % 1000)      # (str hashes differ from process to process)
     B, H, E, Lq = 3, 4, 64, 10
     Lk = Lq if case in ("self", "q_is_k") else 17
     fast = MultiheadAttention(E, H, batch_first=batch_first).to(dev)
