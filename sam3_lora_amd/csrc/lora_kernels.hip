@@ -2434,7 +2434,7 @@ int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    int state = 0;              // 0 = not tried, 1 = ready, -1 = could not be created
+    std::atomic<int> state{0};  // 0 = not tried, 1 = ready, -1 = could not be created
     std::mutex busy;            // one forked region at a time per device: its events are reused
 };
 static SideStream g_side[64];
@@ -2447,17 +2447,17 @@ static SideStream* side_stream_for(hipStream_t st, long long stream_bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     SideStream* d = &g_side[dev];
-    if (d->state == 0) {
+    if (d->state.load(std::memory_order_acquire) == 0) {
         std::lock_guard<std::mutex> g(g_side_init);
-        if (d->state == 0) {
+        if (d->state.load(std::memory_order_relaxed) == 0) {
             const bool ok = hipStreamCreateWithFlags(&d->s, hipStreamNonBlocking) == hipSuccess &&
                             hipEventCreateWithFlags(&d->fork, hipEventDisableTiming) == hipSuccess &&
                             hipEventCreateWithFlags(&d->join, hipEventDisableTiming) == hipSuccess;
             if (!ok) (void)hipGetLastError();
-            d->state = ok ? 1 : -1;
+            d->state.store(ok ? 1 : -1, std::memory_order_release);
         }
     }
-    return d->state == 1 ? d : nullptr;
+    return d->state.load(std::memory_order_acquire) == 1 ? d : nullptr;
 }
 
 // backward of one rank group (see fwd_group for A_g / B_g); gA_g / gB_g point at the group's slice of the gradients.
