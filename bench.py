@@ -1192,10 +1192,10 @@ def parity_gates(dev, args):
     (1) the adapter C-ABI calls (forward + backward, hi + lo bf16 kernels, the benchmark's rank) on 2048 rows of the fc1 / fc2 shapes
         against the numpy fp64 oracle (oracle/lora_oracle.py, pinned to the reference by tests/golden/adapter_*.npz): y / gx within one
         bf16 rounding, gA / gB within 3e-5 of max;
-    (2) ONE training step at the full model size in exactly the layout the line above times (bf16 frozen tensors, fp32 islands, fused
-        fc1, hi + lo operands) against the REFERENCE's fp32 CPU step of tests/golden/e2e_full.npz (tests/golden/make_e2e_golden.py full):
-        logits / boxes / masks / loss / A-B gradients, the number of outputs whose matching differs, beside the reference's own
-        autocast(bf16) deviation at that size (tests/golden/ref_autocast_bf16.json)."""
+    (2) the training steps at the full model size in exactly the layout the line above times (bf16 frozen tensors, fp32 islands, fused
+        fc1, hi + lo operands) against the REFERENCE's fp32 CPU steps of tests/golden/e2e_full.npz (tests/golden/make_e2e_golden.py full):
+        every discrete decision of the first step identical, loss / curve / A-B gradients at fixed bars, logits / boxes / masks beside the
+        reference's own autocast(bf16) deviation at that size (tests/golden/ref_autocast_bf16.json)."""
     import numpy as np
     gates = {}
     try:
@@ -1237,24 +1237,17 @@ def parity_gates(dev, args):
         import test_sam3_e2e as T
         rec = T._full_size_step("bf16")
         yard = T._yardstick("full")
-        cls = lambda suffix: max(v for k, v in rec["outputs"].items() if k.endswith(suffix))
-        sm = {"pred_logits": cls("pred_logits"), "pred_boxes": cls("pred_boxes"), "presence_logit_dec": cls("presence_logit_dec"),
-              "pred_masks": cls("pred_masks"), "core_loss": rec["loss_terms"]["core_loss"],
-              "worst_AB_grad": max(max(rec["grads_full"].values()), rec["grads_sampled_worst"]),
-              "outputs_with_different_matching": len(rec["outputs_with_different_matching"]), "outputs_matched": 6,
-              "rematch_cost_gap": {k: {kk: round(vv, 5) for kk, vv in v.items()} for k, v in rec.get("rematch_cost_gap", {}).items()}}
-        S = T.FULL_BF16_SLACK        # the test's bars (run-to-run spread of both sides: tests/test_sam3_e2e.py)
-        ok = (sm["pred_logits"] <= S * yard["pred_logits"] and sm["pred_boxes"] <= S * yard["pred_boxes"] and sm["presence_logit_dec"] <= S * yard["presence_logit_dec"]
-              and sm["pred_masks"] <= 2 * yard["pred_masks"] and sm["core_loss"] <= max(yard["core_loss"], 1e-3)
-              and sm["worst_AB_grad"] <= yard["worst_AB_grad"] and T._rematch_explained(sm["rematch_cost_gap"]))
-        gates["full_size_step_vs_reference"] = dict(sm, reference_autocast_bf16_vs_its_fp32=yard, **{"pass": bool(ok)}, what=(
-            "one training step of the reference's fp32 CPU run at the REAL model size (tests/golden/e2e_full.npz: depth 32, 1008^2, 64 adapters, "
-            "one image) re-run here in the layout this line times: max-abs error over max|ref| per output class, loss and worst A/B gradient, "
-            "outputs (final + 5 auxiliary) whose Hungarian matching differs; bar = the reference's own autocast(bf16) deviation at that size "
-            "(x 1.5 on logits / boxes / presence, x 2 on masks: the bars of test_full_size_training_step_bf16_layout_against_reference); a "
-            "re-matched output passes when this run's own cost deviation explains it: the reference's fp32 cost matrix rates this build's "
-            "assignment at most 2 T eps above its optimum, eps = max |C_build - C_reference| (`rematch_cost_gap`: gap, eps, bound; three of "
-            "the fixture's six outputs have five more assignments within 0.05 of the optimum, of ~15)"))
+        sm, checks = T._full_bf16_verdict(rec, yard)        # the bars of test_full_size_training_step_bf16_layout_against_reference
+        sm["losses"] = [round(v, 6) for v in rec["losses"]]
+        yard_short = {k: v for k, v in yard.items() if k != "samples"}
+        gates["full_size_step_vs_reference"] = dict(sm, checks=checks, reference_autocast_bf16_vs_its_fp32=yard_short, **{"pass": bool(all(checks.values()))}, what=(
+            "the reference's fp32 CPU training steps at the REAL model size (tests/golden/e2e_full.npz: depth 32, 1008^2, 64 adapters, one image, "
+            "%d AdamW steps) re-run here in the layout this line times.  Held strictly: the fixture's ground-truth boxes leave each of the first "
+            "step's 12 discrete decisions (Hungarian assignment of the final + 5 auxiliary outputs and of the 5 auxiliary one-to-many twins, the "
+            "final twin's threshold matches) a margin (tests/golden/margins.py, e2e_boxes.json), so `decisions_differing` must be empty; first-step "
+            "total and every step of the loss curve within %g; worst A/B gradient within twice this build's measured deviation; logits / boxes / "
+            "presence (max-abs error over max|ref|) within the reference's own autocast(bf16) deviation at that size (largest of three image "
+            "samples), masks within twice it" % (len(rec["losses"]), T.BF16_CURVE_BAR)))
         torch.cuda.empty_cache()
     except Exception as e:
         gates["full_size_step_vs_reference"] = {"error": f"{type(e).__name__}: {str(e)[:300]}", "pass": False}
@@ -1262,12 +1255,78 @@ def parity_gates(dev, args):
     return gates
 
 
+def exchange_alone_measurement(full):
+    """N = 1: hardware evidence for the side-stream mechanics on the one GPU there is.  A one-rank RCCL communicator is created and
+    the reducer is told to issue its collectives anyway (``LoRAGradReducer.run_alone``: a 1-rank all-reduce is the identity, but it is
+    a real RCCL launch on the side HIP stream, ordered by the same events): where each bucket's all-reduce starts and ends relative to
+    the END of backward on the GPU's clock, how many collectives a step issues, and the step time with and without them (interleaved).
+    No bytes cross xGMI here -- what N > 1 adds is the transfer time inside each all-reduce, not the launch positions."""
+    red = full.reducer
+    made_group = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=full.dev)
+            made_group = True
+
+        def run(n, alone):
+            red.run_alone = alone
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                full.step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        run(1, True)                                    # communicator warm-up (the first collective builds its channels)
+        with_x, without = [], []
+        for _ in range(3):                              # interleaved: box drift does not land on one side
+            without.append(run(2, False))
+            with_x.append(run(2, True))
+        red.run_alone = True
+        red.trace = True
+        full.backward_end_event = torch.cuda.Event(enable_timing=True)
+        full.step()
+        torch.cuda.synchronize()
+        red.trace = False
+        ev = full.backward_end_event
+        full.backward_end_event = None
+        buckets = [{"bucket": b, "origin": o, "bytes": 4 * (red.buckets[b][1] - red.buckets[b][0]),
+                    "start_ms_after_backward_end": round(ev.elapsed_time(e0), 3), "end_ms_after_backward_end": round(ev.elapsed_time(e1), 3)}
+                   for (b, e0, e1, o) in red.launch_events]
+        log = list(red.launch_log)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(red.flat)
+        torch.cuda.synchronize()
+        alone_ms = (time.perf_counter() - t0) / 10 * 1e3
+        med = lambda v: sorted(v)[len(v) // 2]
+        return {"world": 1, "n_gpus_note": "N = 1: one-rank RCCL communicator, collectives issued although there is no peer (launch positions "
+                                           "and stream ordering are real, transfer time is not)",
+                "step_ms_with_exchange": round(med(with_x), 2), "step_ms_without": round(med(without), 2),
+                "step_ms_delta": round(med(with_x) - med(without), 3), "samples_with": [round(v, 2) for v in with_x],
+                "samples_without": [round(v, 2) for v in without], "allreduce_alone_ms": round(alone_ms, 3), "bytes": red.nbytes,
+                "collectives_per_step": len(buckets), "launch_log": log, "buckets_rank0": buckets,
+                "buckets_started_before_backward_end": sum(1 for b in buckets if b["start_ms_after_backward_end"] < 0)}
+    except Exception as e:      # an auxiliary measurement must never cost the bench line
+        return {"world": 1, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+    finally:
+        red.run_alone = False
+        red.trace = False
+        if made_group:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+
+
 def overlap_measurement(full, world):
     """How much of the A/B-gradient exchange hides behind the backward: the step timed with the bucketed side-stream
     all-reduce launched from the gradient hooks (overlapped) against the same step with one blocking all-reduce after
     the backward (exposed), and the exchange on its own.  With one rank there is nothing to exchange: reported as such."""
     if world == 1:
-        return {"world": 1, "note": "single rank: no exchange"}
+        return exchange_alone_measurement(full)
     red = full.reducer
 
     def run(n):

@@ -280,14 +280,14 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
 #define SAM3_LORA_STAGE_GT_REDUCE 64u /* k_gt_reduce : chunk sum of the gt partials k_t3 emitted (r <= 16)  */
 #define SAM3_LORA_STAGE_FUSED 128u  /* k_fused_linear : frozen GEMM + rank-r K step + bias + activation (sam3_lora_linear_fwd) */
 #define SAM3_LORA_STAGE_T3W 256u    /* k_t3w    : backward version 2 over gy -- gB partials + gt (partials, or its images when out <= 1024) */
-#define SAM3_LORA_STAGE_XGX 512u    /* k_xgx    : backward version 2 over x and gx -- gx += s.gt.A_c^T and the gA partials in one pass */
+#define SAM3_LORA_STAGE_XGX 512u    /* retired (round 5's k_xgx, measured slower and removed in round 6): selects nothing; the value stays reserved */
 #define SAM3_LORA_STAGE_ALL 0xffffffffu
 unsigned sam3_lora_debug_set_stages(unsigned mask);
 
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
  * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_WGS,
- * SAM3_LORA_FUSED_HALF, SAM3_LORA_FUSED_EARLY, SAM3_LORA_FUSED_TILE, SAM3_LORA_FUSED_PROBE, SAM3_LORA_HL_MAX_RANK, SAM3_LORA_BWD_V2, SAM3_LORA_BWD_XGX,
- * SAM3_LORA_BWD_FORK, SAM3_LORA_T3_RIDE, SAM3_LORA_T3_ONESET, SAM3_LORA_T3W_WGS, SAM3_LORA_XCD_ORDER, SAM3_LORA_GA_IN_T2, SAM3_LORA_T1_BK; INTEGRATION.md section D says what each selects) are read from the
+ * SAM3_LORA_FUSED_HALF, SAM3_LORA_FUSED_PROBE, SAM3_LORA_HL_MAX_RANK, SAM3_LORA_BWD_V2,
+ * SAM3_LORA_T3W_WGS, SAM3_LORA_XCD_ORDER, SAM3_LORA_GA_IN_T2, SAM3_LORA_T1_BK; INTEGRATION.md section D says what each selects) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);

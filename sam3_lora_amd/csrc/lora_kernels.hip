@@ -613,27 +613,11 @@ struct GaEmit {
     const bf16_t* GTTf;     // gt, fragment-major (k_gt_reduce<HL> / store_t4_hl): [32-row step][hi | lo][64 lanes][8]
     float* part;            // [row blocks][16][N]
 };
-// T3R: the grid's rows [ride.rows, ride.rows + t3.NR) run k_t3's blocks -- gA^T = gt^T . x over the layer's input, the backward's other
-// consumer of gt -- instead of launching them on their own: at in_features = 1024 the two are 22 + 37 us kernels, each a third ramp and
-// tail (t3_body; SAM3_LORA_T3_RIDE).  Their partials are complete only when this launch is: gA's fixed-order sum follows as a launch.
-struct T3Ride {
-    const bf16_t* X;        // the layer's input [M, N]
-    long long ldx;
-    const bf16_t* TTf;      // gt, fragment-major
-    float* Gpart;           // [NR][16][N]
-    long long Mp;
-    int rows_per_wg, NR, xcd_order;
-};
-template <typename XT, int RT, bool GATHER, bool DROP, bool HL, bool ONE>
-__device__ __forceinline__ void t3_body(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
-                                        long long M, long long Mp, int N, int rows_per_wg, const DropKey& dk, unsigned ptile, unsigned nchunks,
-                                        uint4 (*xs)[32 * 16]);
-template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false, bool T3R = false>
+template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false>
 __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
-                                            ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga, T3Ride t3) {
-    static_assert(!T3R || (ACT == 0 && HL && RT == 2 && !DROP && !Q8 && !GA && sizeof(YT) == 2), "k_t3's blocks ride on the plain hi + lo gx update, r <= 16, no mask");
+                                            ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga) {
     static_assert(!GA || (ACT == 2 && HL && RT == 2 && !DROP && sizeof(YT) == 2), "the in-pass gA contraction: GELU' pass of the hi + lo kernels, r <= 16");
     static_assert(!Q8 || ACT != 0, "the fp8 image is the one of the activation-fused passes");
     static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: RT / 2 rank tiles, each as [hi 4 | lo 4] per 4 rank indices");
@@ -651,18 +635,7 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
             reduce_block(e < ride.nblk ? ride.j0 : ride.j1, e % ride.nblk, ride.scale, ride.accumulate, &slab_all[0][0]);
         return;
     }
-    unsigned lead = (unsigned)ride.rows;        // grid rows in front of the body's
-    if (T3R) {
-        if (blockIdx.y < lead + (unsigned)t3.NR) {
-            static_assert(sizeof(slab_all) >= 4 * 32 * 16 * sizeof(uint4), "k_t3's 32 KB of slabs fit this kernel's");
-            unsigned ptile = (blockIdx.y - lead) * gridDim.x + blockIdx.x;
-            if (t3.xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * (unsigned)t3.NR);
-            t3_body<bf16_t, 2, false, false, true, true>(t3.X, t3.ldx, t3.TTf, t3.Gpart, M, t3.Mp, N, t3.rows_per_wg, DropKey{0u, 0u, 0}, ptile, gridDim.x,
-                                                   reinterpret_cast<uint4(*)[32 * 16]>(&slab_all[0][0]));
-            return;
-        }
-        lead += (unsigned)t3.NR;
-    }
+    const unsigned lead = (unsigned)ride.rows;  // grid rows in front of the body's
     // body tile (bx = column block, by = row block): all column blocks of a row block on one XCD (they share its T rows)
     unsigned pbody = (blockIdx.y - lead) * gridDim.x + blockIdx.x;
     if (xcd_order) pbody = xcd_tile_index(pbody, gridDim.x * (gridDim.y - lead));
@@ -868,10 +841,9 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
 
 // HL (RT == 2): the two fragment blocks of a step are the hi and lo parts of the same 16 rank indices and accumulate
 // into ONE rank tile (RTA = 1): G = t_hi^T X + t_lo^T X.
-// The kernel's body as a function of its tile number: k_t3 is the launch of its own, k_t2<T3R> runs the same blocks as leading rows of
-// the gx update's grid (the two passes of a backward call that only share gt: one launch instead of two).
+// The kernel's body as a function of its tile number.
 // `ptile`: tile number (column chunk fastest), `nchunks`: column chunks of N, `xs`: 32 KB of the workgroup's LDS.
-template <typename XT, int RT, bool GATHER, bool DROP, bool HL, bool ONE>
+template <typename XT, int RT, bool GATHER, bool DROP, bool HL>
 __device__ __forceinline__ void t3_body(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
                                         long long M, long long Mp, int N, int rows_per_wg, const DropKey& dk, unsigned ptile, unsigned nchunks,
                                         uint4 (*xs)[32 * 16]) {
@@ -974,24 +946,7 @@ __device__ __forceinline__ void t3_body(const XT* __restrict__ X, long long ldx,
         eat(r_.t);
     };
 
-    if (ONE) {
-        // ONE register set: the slab is the second buffer.  The step's tile goes to the LDS, the NEXT step's loads are issued into the
-        // same registers, and the MFMAs then run on the slab with those loads in flight -- ~100 registers instead of ~200: four waves
-        // per SIMD instead of two (and the form that fits inside k_t2<T3R>, whose launch keeps four).
-        if (nst > 0) {
-            Regs r;
-            gload(0, r);
-            for (int s = 0; s < nst; ++s) {
-                uint4 tc[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) tc[rt] = r.t[rt];
-                put(s, r);
-                gload(s + 1, r);       // clamped to the last step at the end (harmless re-read)
-                __builtin_amdgcn_sched_barrier(0);
-                eat(tc);
-            }
-        }
-    } else if (nst > 0) {
+    if (nst > 0) {
         Regs rA, rB;               // distance-1 prefetch, two named register sets (see k_t1)
         gload(0, rA);
         for (int s = 0; s < nst2; s += 2) {
@@ -1029,15 +984,15 @@ __device__ __forceinline__ void t3_body(const XT* __restrict__ X, long long ldx,
     }
 }
 
-template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false, bool ONE = false>
-__global__ __launch_bounds__(256, ONE ? 4 : (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(const XT* __restrict__ X, long long ldx,
+template <typename XT, int RT, bool GATHER, bool DROP, bool HL = false>
+__global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(const XT* __restrict__ X, long long ldx,
                                             const bf16_t* __restrict__ TTf, float* __restrict__ Gpart,
                                             long long M, long long Mp, int N, int rows_per_wg, DropKey dk, int xcd_order) {
     __shared__ uint4 xs[4][32 * 16];       // 32 rows x 256 B per wave; reused as the reduction buffer
     // tile (column chunk, row group): the chunks of a row group on one XCD (they share its t^T fragments)
     unsigned ptile = blockIdx.y * gridDim.x + blockIdx.x;
     if (xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * gridDim.y);
-    t3_body<XT, RT, GATHER, DROP, HL, ONE>(X, ldx, TTf, Gpart, M, Mp, N, rows_per_wg, dk, ptile, gridDim.x, xs);
+    t3_body<XT, RT, GATHER, DROP, HL>(X, ldx, TTf, Gpart, M, Mp, N, rows_per_wg, dk, ptile, gridDim.x, xs);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1214,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward, version 2 (hi + lo operands, r <= 16): TWO kernels for the whole call instead of four.
+// Backward, version 2 (hi + lo operands, r <= 16): the pass over gy.
 //
 // T3W  k_t3w  the pass over gy.  Like k_t3e it yields the gB partials AND gt = gy . B_c^T from one read of gy, but the
 //             workgroup's 8 waves split its COLUMNS (one 128-column chunk each: 1024 columns per workgroup) and walk the same
@@ -1226,10 +1181,6 @@ __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP
 //             accumulators to memory without the cross-wave pass of k_t3 / k_t3e.  The spill balance:
 //             gt partials 64 M ceil(N / 1024) bytes + gB partials 64 N x row groups, 28 MB at M = 41,472, N = 4736 with one
 //             workgroup per CU, against 58 MB for k_t3e's 256-column pairs.
-// XGX  k_xgx  the pass over x and gx: gx += s (gt A_c^T) (.) mask as k_t2, and IN THE SAME PASS gA = drop(x)^T gt from the x
-//             tile (k_t2<GA>'s contraction with the tile taken from memory instead of recomputed), with gt summed from T3W's
-//             partials per 16-row tile (NP 16-byte loads per lane) and split hi + lo in registers: the gt images never exist,
-//             k_gt_reduce and k_t3 over x are gone, and x / gx share one launch's ramp and tail.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_barrier() {     // workgroup barrier that orders LDS traffic only: global loads in flight stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1382,158 +1333,6 @@ __global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long l
     }
 }
 
-// NP: number of gt partials summed per tile (>= nparts; the surplus loads re-read the last partial and are masked out)
-template <bool DROP, int NP>
-__global__ __launch_bounds__(256, 2) void k_xgx(const bf16_t* __restrict__ X, long long ldx, bf16_t* __restrict__ Y, long long ldy,
-                                                const float* __restrict__ GTP, int nparts, long long Mp,
-                                                const bf16_t* __restrict__ W2t, long long M, int N, float scale, int tiles_per_wg,
-                                                DropKey dk, float* __restrict__ GApart, ReduceRide ride, int xcd_order) {
-    constexpr int RP = 32, CW = 128, LDW = CW + 4;
-    __shared__ __attribute__((aligned(16))) float slab_all[4][16 * LDW];
-    __shared__ uint4 atile_all[4][16 * 16];         // the wave's x tile, bf16 [16 rows][16 chunks of 8], t3_h swizzle
-    __shared__ uint4 gtt_all[4][64];                // gt^T of the tile as the K = 32 A-operand image: [rank 16][hi rows 0..15 | lo rows 0..15]
-    if (blockIdx.y < (unsigned)ride.rows) {         // riding reduction blocks (the gB partials of k_t3w), scheduled first
-        const long long e = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-        if (e < (long long)ride.nblk) reduce_block(ride.j0, e, ride.scale, ride.accumulate, &slab_all[0][0]);
-        return;
-    }
-    unsigned pbody = (blockIdx.y - (unsigned)ride.rows) * gridDim.x + blockIdx.x;
-    if (xcd_order) pbody = xcd_tile_index(pbody, gridDim.x * (gridDim.y - (unsigned)ride.rows));
-    const unsigned bx = pbody % gridDim.x, by = pbody / gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    float* slab = slab_all[wave];
-    uint4* atile = atile_all[wave];
-    uint4* gtt = gtt_all[wave];
-    const int c0 = bx * CW;
-    // A_c fragments (MFMA A-operand: i = output column, k = rank index; interleaved hi | lo image), kept for the whole kernel
-    uint4 wq[8];
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        const int colw = c0 + ct * 16 + n;
-        wq[ct] = colw < N ? *reinterpret_cast<const uint4*>(W2t + (long long)colw * RP + g * 8) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    const long long ntiles = (M + 15) / 16, nfull = M / 16;
-    const long long t_begin = (long long)by * tiles_per_wg + wave;
-    const long long t_end = min((long long)(by + 1) * tiles_per_wg, ntiles);
-    const int col = c0 + (lane & 15) * 8;
-    f32x4 gacc[8];
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) gacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    struct GtP {
-        f32x4 p[NP];
-    };
-    auto load_gt = [&](long long t, GtP& q) {
-#pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            const int cc = c < nparts ? c : nparts - 1;
-            q.p[c] = *reinterpret_cast<const f32x4*>(GTP + ((long long)cc * Mp + t * 16 + n) * 16 + g * 4);
-        }
-    };
-    // the tile's work once its operands are in registers
-    auto tile_body = [&](auto fast_tag, long long t, YTile<bf16_t>& cur, const YTile<bf16_t>& xt, const GtP& q) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        f32x4 s4 = q.p[0];
-#pragma unroll
-        for (int c = 1; c < NP; ++c) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            s4 += c < nparts ? q.p[c] : z;
-        }
-        const unsigned h0 = pack2(s4[0], s4[1]), h1 = pack2(s4[2], s4[3]);
-        const unsigned l0 = pack2(s4[0] - bf_lo(h0), s4[1] - bf_hi(h0)), l1 = pack2(s4[2] - bf_lo(h1), s4[3] - bf_hi(h1));
-        // delta^T: (w_hi, w_lo) . (t_hi, t_hi) + (w_hi, w_lo) . (t_lo, 0), as k_t2's hi + lo form
-        const uint4 tb = make_uint4(h0, h1, h0, h1), tc = make_uint4(l0, l1, 0u, 0u);
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[ct]), __builtin_bit_cast(bf16x8, tb), d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[ct]), __builtin_bit_cast(bf16x8, tc), d, 0, 0, 0);
-            *reinterpret_cast<f32x4*>(slab + n * LDW + ct * 16 + g * 4) = d;
-        }
-        wave_sync();
-        cur.template add_store<FAST, DROP, 0>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, nullptr, 0, cur);
-        // the x tile (masked as the forward masked it) and gt^T in the K = 32 operand image: slot n = hi of row n, slot 16 + n = lo
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int rl = p * 4 + (lane >> 4);
-            uint4 v = xt.v[p];
-            if (DROP) v = drop8(v, (unsigned long long)(t * 16 + rl) * dk.width + col, dk);
-            atile[rl * 16 + ((lane & 15) ^ (t3_h(rl) << 1))] = v;
-        }
-        {
-            bf16_t* gb = reinterpret_cast<bf16_t*>(gtt) + (g * 4) * 32 + n;
-            gb[0] = (bf16_t)(h0 & 0xffffu);  gb[32] = (bf16_t)(h0 >> 16);  gb[64] = (bf16_t)(h1 & 0xffffu);  gb[96] = (bf16_t)(h1 >> 16);
-            gb[16] = (bf16_t)(l0 & 0xffffu); gb[48] = (bf16_t)(l0 >> 16);  gb[80] = (bf16_t)(l1 & 0xffffu);  gb[112] = (bf16_t)(l1 >> 16);
-        }
-        wave_sync();
-        const uint4 gf = gtt[n * 4 + g];
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const char* base = reinterpret_cast<const char*>(atile);
-        const int rowA = (g & 1) * 8 + (n >> 2), rowB = rowA + 4;
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
-            const char* pa = base + ((rowA * 16 + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
-            const char* pb = base + ((rowB * 16 + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
-            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            // D[i = rank idx][n = column] += sum_row (gt_hi + gt_lo)[row][i] * drop(x)[row][col]
-            gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf), __builtin_bit_cast(bf16x8, both), gacc[ct], 0, 0, 0);
-        }
-        wave_sync();
-    };
-    const bool colfull = c0 + CW <= N;
-    const long long t_fast_end = colfull ? min(t_end, nfull) : t_begin;
-    long long t = t_begin;
-    if (t < t_fast_end) {       // branch-free stream, one tile ahead (k_t2's discipline): gt partials first, they are needed first
-        YTile<bf16_t> cur, nxt, xc, xn;
-        GtP qc, qn;
-        load_gt(t, qn);
-        nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
-        xn.template load<true, true>(X, ldx, t * 16, col, lane, M, N);
-        for (; t < t_fast_end; t += 4) {
-            cur = nxt;
-            xc = xn;
-            qc = qn;
-            const long long tn = t + 4 < t_fast_end ? t + 4 : t;
-            load_gt(tn, qn);
-            nxt.template load<true>(Y, ldy, tn * 16, col, lane, M, N);
-            xn.template load<true, true>(X, ldx, tn * 16, col, lane, M, N);
-            tile_body(std::true_type{}, t, cur, xc, qc);
-        }
-    }
-    for (; t < t_end; t += 4) {     // ragged tiles: predicated path (loads beyond M / N come back as zeros)
-        YTile<bf16_t> cur, xc;
-        GtP qc;
-        load_gt(t, qc);
-        cur.template load<false>(Y, ldy, t * 16, col, lane, M, N);
-        xc.template load<false, true>(X, ldx, t * 16, col, lane, M, N);
-        tile_body(std::false_type{}, t, cur, xc, qc);
-    }
-    // fixed-order cross-wave sum ((w0 + w1) + w2) + w3 through LDS (as k_t2<GA>); wave w writes column tiles 2w, 2w + 1
-    float* red = &slab_all[0][0];
-    float* out = GApart + (long long)by * 16 * N;
-    __syncthreads();
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) *reinterpret_cast<f32x4*>(red + ((wave * 8 + ct) * 64 + lane) * 4) = gacc[ct];
-    __syncthreads();
-#pragma unroll
-    for (int jc = 0; jc < 2; ++jc) {
-        const int ct = wave * 2 + jc;
-        f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ((0 * 8 + ct) * 64 + lane) * 4);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 8 + ct) * 64 + lane) * 4);
-        const int ocol = c0 + ct * 16 + n;
-        if (ocol < N) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = s4[jj];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // merge: Wm[o][i] = W[o][i] + scaling * sum_r A_c[i][r] * B_c[r][o]     (fp32, one-off)
 // ------------------------------------------------------------------------------------------
@@ -1649,18 +1448,8 @@ T3Plan plan_t3w(long long Mp, int N) {
     p.NR = (int)((steps + spw - 1) / spw);
     return p;
 }
-// version 2 of the bf16 backward (k_t3w, k_xgx): hi + lo kernels, one rank group of <= 16; SAM3_LORA_BWD_V2=0 restores k_t3e
+// version 2 of the bf16 backward (k_t3w): hi + lo kernels, one rank group of <= 16; SAM3_LORA_BWD_V2=0 restores k_t3e
 bool bwd_v2_enabled() { return env_int("SAM3_LORA_BWD_V2", 1) != 0; }
-// k_t3 (gA) as leading blocks of k_t2's launch over gx (k_t2<T3R>): SAM3_LORA_T3_RIDE = 0 off (default), 1 narrow inputs (<= 1024),
-// 2 always.  Built to save one of the two 22-37 us launches of a narrow backward; bit-identical; MEASURED SLOWER on MI355X, M = 41,472,
-// three interleaved rounds (profiles/r05ad_t3_ride_sweep.json): fc1 backward 139.6-141.0 us riding against 132.7-135.9 us as two
-// launches, fc2 backward (in = 4736) 262 against 249 -- inside k_t2's launch the blocks must live with 128 registers (t3_body<ONE>:
-// one register set, the LDS slab as the second buffer), a form that is 3 % slower than the two-set one on its own as well
-// (SAM3_LORA_T3_ONESET=1: k_t3 76-78 us against 74-75 at 4736), and gA's sum becomes a launch of its own.
-bool t3_ride_enabled(int in_features) {
-    const long long m = env_int("SAM3_LORA_T3_RIDE", 0);
-    return m >= 2 || (m == 1 && in_features <= 1024);
-}
 
 int check_common(long long M, int in_f, int out_f, int rank, int layout, int dtype) {
     if (M <= 0 || M >= (1LL << 31)) return fail(SAM3_LORA_EINVAL, "M must be in [1, 2^31) (got %lld)", M);
@@ -1726,12 +1515,10 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_T1_LDS_PAD", false, 0},   {"SAM3_LORA_T2_TPW", false, 0},    {"SAM3_LORA_T3_GATHER", false, 0},
                   {"SAM3_LORA_TWO_PASS_GY", false, 0},  {"SAM3_LORA_SINGLE_ROUND", false, 0}, {"SAM3_LORA_NO_RIDE", false, 0},
                   {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
-                  {"SAM3_LORA_FUSED_HALF", false, 0},  {"SAM3_LORA_FUSED_TILE", false, 0},  {"SAM3_LORA_FUSED_PROBE", false, 0},
+                  {"SAM3_LORA_FUSED_HALF", false, 0},  {"SAM3_LORA_FUSED_PROBE", false, 0},
                   {"SAM3_LORA_HL_MAX_RANK", false, 0},
                   {"SAM3_LORA_T1_BK", false, 0},
-                  {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_BWD_XGX", false, 0},   {"SAM3_LORA_T3W_WGS", false, 0},
-                  {"SAM3_LORA_BWD_FORK", false, 0},    {"SAM3_LORA_FUSED_EARLY", false, 0},
-                  {"SAM3_LORA_T3_RIDE", false, 0},      {"SAM3_LORA_T3_ONESET", false, 0}};
+                  {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_T3W_WGS", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
     for (Knob& k : g_knobs) {
@@ -1949,10 +1736,9 @@ bool ga_in_t2_enabled() { return env_flag("SAM3_LORA_GA_IN_T2"); }
 template <typename YT>
 void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long long M, int N, float scale, int RT, bool hl,
                hipStream_t st, DropKey dk = DropKey{0u, 0u, 0}, int act = 0, void* aux = nullptr, long long ldaux = 0,
-               const ReduceRide* ride_in = nullptr, const Q8Out* q8_in = nullptr, const GaEmit* ga_in = nullptr, const T3Ride* t3_in = nullptr) {
+               const ReduceRide* ride_in = nullptr, const Q8Out* q8_in = nullptr, const GaEmit* ga_in = nullptr) {
     const long long ntiles = (M + 15) / 16;
     const int nchunks = (N + 127) / 128;
-    const T3Ride t3 = t3_in ? *t3_in : T3Ride{nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
     // 3 tiles per wave measured best on MI355X for both N = 4736 and N = 1024 at M = 41472 (sweep 4..48:
     // 121 / 36 us at 12 vs 125 / 37 us at 32 / 8); fewer per workgroup only when that leaves too few workgroups.
     long long tiles_per_wg = 12;
@@ -1965,18 +1751,13 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
         ride = *ride_in;
         ride.rows = (int)((2LL * ride.nblk + nchunks - 1) / nchunks);
     }
-    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows + (unsigned)t3.NR);
+    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows);
     ProfScope ps(SAM3_LORA_STAGE_T2, N, st);
     const Q8Out q8 = q8_in ? *q8_in : Q8Out{nullptr, 0, nullptr, nullptr, nullptr, 0};
     const int xcd = xcd_order_for(N);
-    if (t3_in) {    // checked by the caller: bf16, hi + lo, r <= 16, plain update (no activation, no mask, no fp8 image)
-        hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 0, true, false, 0, false, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, scale,
-                           (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga, t3);
-        return;
-    }
     if (q8.q && !ga_in) {     // fp8 image beside the bf16 output: activation-fused passes of the hi + lo kernels, no dropout mask (checked by the caller)
 #define T2_Q8(AV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, AV, true, true, FV>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
-                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga, t3)
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
         if (act == 1) { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(1, SAM3_FP8_E4M3); else T2_Q8(1, SAM3_FP8_E5M2); }
         else { if (q8.fmt == SAM3_FP8_E4M3) T2_Q8(2, SAM3_FP8_E4M3); else T2_Q8(2, SAM3_FP8_E5M2); }
 #undef T2_Q8
@@ -1984,7 +1765,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     }
     if (ga_in) {    // checked by the caller: bf16, hi + lo, GELU' pass, no dropout mask
 #define T2_GA(QV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, QV, FV, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
-                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga, t3)
+                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
         if (!q8.q) T2_GA(false, 0);
         else if (q8.fmt == SAM3_FP8_E4M3) T2_GA(true, SAM3_FP8_E4M3);
         else T2_GA(true, SAM3_FP8_E5M2);
@@ -1993,7 +1774,7 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
     }
 #define T2_LAUNCH(RTV, DV, AV, HV) \
     hipLaunchKernelGGL((k_t2<YT, RTV, DV, AV, HV>), grid, dim3(256), 0, st, (YT*)Y, ldy, T, W2t, M, N, scale, (int)tiles_per_wg, dk, \
-                       (YT*)aux, ldaux, ride, q8, xcd, ga, t3)
+                       (YT*)aux, ldaux, ride, q8, xcd, ga)
 #define T2_RT(RTV, HV)                                                                     \
     do {                                                                               \
         if (act == 1) T2_LAUNCH(RTV, false, 1, HV);            /* forward: no mask on y */   \
@@ -2020,10 +1801,7 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
     } else if (hl && RT == 4) {
         if (gather) T3_LAUNCH(4, true, true); else T3_LAUNCH(4, false, true);
     } else if (hl) {
-        if (gather) T3_LAUNCH(2, true, true);
-        else if (!dk.thr && env_flag("SAM3_LORA_T3_ONESET"))     // one register set, four waves per SIMD (t3_body<ONE>)
-            hipLaunchKernelGGL((k_t3<XT, 2, false, false, true, true>), grid, dim3(256), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk, xcd);
-        else T3_LAUNCH(2, false, true);
+        if (gather) T3_LAUNCH(2, true, true); else T3_LAUNCH(2, false, true);
     } else {
         if (gather) T3_LAUNCH(2, true, false); else T3_LAUNCH(2, false, false);
     }
@@ -2059,28 +1837,6 @@ void launch_t3w(const void* X, long long ldx, const bf16_t* TT, float* part, lon
         hipLaunchKernelGGL((k_t3w<XT, true>), grid, dim3(512), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg / 32, W1b, GTP, GT, GTT, xcd);
     else
         hipLaunchKernelGGL((k_t3w<XT, false>), grid, dim3(512), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg / 32, W1b, GTP, GT, GTT, xcd);
-}
-constexpr int XGX_MAX_PARTS = 5;      // (8 partials in flight spill k_xgx's 256 registers)
-// version 2: the pass over x and gx (k_xgx); `ride`: the reduction of k_t3w's gB partials (j0 only)
-void launch_xgx(const void* X, long long ldx, void* GX, long long ldgx, const float* GTP, int nparts, long long Mp, const bf16_t* W2t,
-                long long M, int N, float scale, DropKey dk, float* GApart, const ReduceRide* ride_in, hipStream_t st) {
-    const long long ntiles = (M + 15) / 16;
-    const int nchunks = (N + 127) / 128;
-    const int tiles_per_wg = GA_TILES_PER_WG;
-    ReduceRide ride{};
-    if (ride_in) {
-        ride = *ride_in;
-        ride.rows = (int)(((long long)ride.nblk + nchunks - 1) / nchunks);
-    }
-    dim3 grid((unsigned)nchunks, (unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg) + (unsigned)ride.rows);
-    const int xcd = xcd_order_for(N);
-    ProfScope ps(SAM3_LORA_STAGE_XGX, N, st);
-#define XGX_LAUNCH(DV, NPV) hipLaunchKernelGGL((k_xgx<DV, NPV>), grid, dim3(256), 0, st, (const bf16_t*)X, ldx, (bf16_t*)GX, ldgx, GTP, nparts, \
-                                               Mp, W2t, M, N, scale, tiles_per_wg, dk, GApart, ride, xcd)
-#define XGX_NP(NPV) do { if (dk.thr) XGX_LAUNCH(true, NPV); else XGX_LAUNCH(false, NPV); } while (0)
-    if (nparts <= 1 && !dk.thr) XGX_NP(1); else if (nparts <= 2) XGX_NP(2); else XGX_NP(5);
-#undef XGX_NP
-#undef XGX_LAUNCH
 }
 
 // ---- exact-fp32 launchers (lora_f32_kernels.inc) ----------------------------------------------------
@@ -2421,45 +2177,6 @@ int sam3_lora_fwd_act(const void* x, const void* A, const void* B, void* y_inout
                     offset, dtype, workspace, workspace_bytes, stream, act, act_out, ldact);
 }
 
-// ---- the two independent passes of a backward call on two streams (built, measured, OFF) ----------------------------------------
-// Once gt exists, `gA = x^T gt` (k_t3 over x) and `gx += gt A^T` (k_t2 over gx) touch disjoint outputs, and at in_features = 1024
-// each is a 20-37 us launch at 0.40-0.59 of the HBM peak.  SAM3_LORA_BWD_FORK=1 (passes of >= 32 MB) / 2 (always) forks the call
-// inside itself: an event on the caller's stream, k_t3 and the sum of ITS partials on a library-owned stream of the same device,
-// and the caller's stream waits for that stream's event before the call hands control back -- the caller sees one stream.  Bits
-// are unchanged (test_forked_backward_is_bit_identical_to_the_one_stream_form).  MEASURED on MI355X, M = 41,472, same process,
-// three interleaved rounds (profiles/r05t_backward_fork_rejected.json): fc1 backward 150 us forked against 134 us on one stream,
-// fc2 backward 271 against 245 -- the two cross-queue dependencies (barrier packets resolved by the command processor) cost
-// more than the overlap of two short kernels returns.  Default 0.
-// Never while the caller's stream is being captured into a graph, nor while sam3_lora_prof_start is timing launches.
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    std::atomic<int> state{0};  // 0 = not tried, 1 = ready, -1 = could not be created
-    std::mutex busy;            // one forked region at a time per device: its events are reused
-};
-static SideStream g_side[64];
-static std::mutex g_side_init;
-static SideStream* side_stream_for(hipStream_t st, long long stream_bytes) {
-    const long long mode = env_int("SAM3_LORA_BWD_FORK", 0);
-    if (mode == 0 || (mode == 1 && stream_bytes < (32LL << 20)) || g_prof.mask) return nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    SideStream* d = &g_side[dev];
-    if (d->state.load(std::memory_order_acquire) == 0) {
-        std::lock_guard<std::mutex> g(g_side_init);
-        if (d->state.load(std::memory_order_relaxed) == 0) {
-            const bool ok = hipStreamCreateWithFlags(&d->s, hipStreamNonBlocking) == hipSuccess &&
-                            hipEventCreateWithFlags(&d->fork, hipEventDisableTiming) == hipSuccess &&
-                            hipEventCreateWithFlags(&d->join, hipEventDisableTiming) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-            d->state.store(ok ? 1 : -1, std::memory_order_release);
-        }
-    }
-    return d->state.load(std::memory_order_acquire) == 1 ? d : nullptr;
-}
-
 // backward of one rank group (see fwd_group for A_g / B_g); gA_g / gB_g point at the group's slice of the gradients.
 // `act2` (GELU' on gx) must only be requested for the last group: gx is complete then.
 static void bwd_group(const void* gy, const void* x, const void* tT_saved, const void* A_g, const void* B_g, bool pre,
@@ -2489,9 +2206,6 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
     const bool s1 = stage_on(SAM3_LORA_STAGE_T1), s2 = stage_on(SAM3_LORA_STAGE_T2);
     const bool s3b = stage_on(SAM3_LORA_STAGE_T3_GB), s3a = stage_on(SAM3_LORA_STAGE_T3_GA);
     bool one_pass = false, ga_in_pass = false, v2 = false;
-    SideStream* side = nullptr;
-    std::unique_lock<std::mutex> side_lock;
-    bool t3ride = false;
     if (f32) {
         const float* T32 = (const float*)tT_saved;
         if (!T32) {     // no saved t: recompute t = drop(x) . A_c
@@ -2518,31 +2232,11 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         // r <= 16 with weight gradients wanted: gy is read ONCE -- k_t3e emits the gt partials beside the gB partials
         one_pass = RG == 16 && gB_g && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
         float* GTP = (float*)(ws + w.gtp);
-        // version 2 (hi + lo): k_t3w over gy; when the plain backward wants gx, gA and gB, k_xgx finishes the call
+        // version 2 (hi + lo): k_t3w over gy
         v2 = one_pass && hl && bwd_v2_enabled() && M < (1LL << 31) && ldgy < (1LL << 31);
-        const bool xgx = v2 && gA_g && s3a && s2 && gx_inout && a2 == 0 && x && !q8 && w.pW.nchunks <= XGX_MAX_PARTS &&
-                         stage_on(SAM3_LORA_STAGE_REDUCE) && env_int("SAM3_LORA_BWD_XGX", 0) != 0;
         if (v2) {
-            const bool final_images = !xgx && w.pW.nchunks == 1;
+            const bool final_images = w.pW.nchunks == 1;
             launch_t3w<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pW, (const bf16_t*)W1b, GTP, GT, GTT, final_images, st);
-            if (xgx) {
-                ReduceRide rd{};
-                rd.j0 = ReduceJob{PB, gB_g, w.pW.NR, RG, out_features, rank, s.b_sr, s.b_so};
-                rd.scale = scale;
-                rd.accumulate = accumulate;
-                rd.nblk = (int)(((long long)rank * out_features + 63) / 64);
-                const bool ride_ok = !env_flag("SAM3_LORA_NO_RIDE");
-                launch_xgx(x, ldx, gx_inout, ldgx, GTP, w.pW.nchunks, Mp, (const bf16_t*)W2tb, M, in_features, scale, dk, PA,
-                           ride_ok ? &rd : nullptr, st);
-                // gA's partials come out of that kernel: their fixed-order sum (3.5 MB at M = 41,472) follows as its own small launch
-                const ReduceJob ja{PA, gA_g, ga_row_blocks(M), RG, in_features, rank, s.a_sr, s.a_si};
-                const ReduceJob none{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
-                const int nblk_a = (int)(((long long)rank * in_features + 63) / 64);
-                ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + (ride_ok ? 0 : out_features), st);
-                if (ride_ok) hipLaunchKernelGGL(k_reduce, dim3((unsigned)nblk_a, 1), dim3(256), 0, st, ja, none, scale, accumulate);
-                else hipLaunchKernelGGL(k_reduce, dim3((unsigned)(nblk_a > rd.nblk ? nblk_a : rd.nblk), 2), dim3(256), 0, st, ja, rd.j0, scale, accumulate);
-                return;
-            }
             if (!final_images) {
                 ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, out_features, st);
                 hipLaunchKernelGGL(k_gt_reduce<true>, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, w.pW.nchunks, GT, GTT, Mp);
@@ -2558,29 +2252,8 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && RG == 16 && !dk.thr && (x == nullptr || ga_in_t2_enabled());
         // (x == NULL with the in-pass form switched off by a partial debug stage mask: nothing can read the input -- skip, the
         // header says a partial mask leaves the outputs meaningless)
-        // k_t3's blocks as leading rows of the gx update's launch (k_t2<T3R>): plain hi + lo backward of r <= 16 without a mask.
-        // Not while sam3_lora_prof_start is timing launches (the per-kernel times are those of the separate kernels).
-        t3ride = gA_g && s3a && !ga_in_pass && x && gx_inout && s2 && hl && RG == 16 && RT == 2 && !dk.thr && a2 == 0 && !q8 &&
-                 stage_on(SAM3_LORA_STAGE_REDUCE) && !g_prof.mask && t3_ride_enabled(in_features);
-        if (gA_g && s3a && !ga_in_pass && x && !t3ride) {
-            if (gx_inout && s2 && stage_on(SAM3_LORA_STAGE_REDUCE))
-                side = side_stream_for(st, M * (long long)in_features * 2);
-            hipStream_t sa = st;
-            if (side) {
-                side_lock = std::unique_lock<std::mutex>(side->busy);
-                hipEventRecord(side->fork, st);
-                hipStreamWaitEvent(side->s, side->fork, 0);
-                sa = side->s;
-            }
-            launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, sa, dk);      // gA^T = gt^T . x
-            if (side) {     // gA's fixed-order sum follows its partials on that stream; gB's rides on k_t2 below
-                const ReduceJob ja{PA, gA_g, w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
-                const ReduceJob none{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
-                hipLaunchKernelGGL(k_reduce, dim3((unsigned)(((long long)rank * in_features + 63) / 64), 1), dim3(256), 0, sa, ja, none,
-                                   scale, accumulate);
-                hipEventRecord(side->join, sa);
-            }
-        }
+        if (gA_g && s3a && !ga_in_pass && x)
+            launch_t3<bf16_t>(x, ldx, GTT, PA, M, Mp, in_features, w.pA, RT, hl, SAM3_LORA_STAGE_T3_GA, st, dk);      // gA^T = gt^T . x
     }
     // partial layouts: PB[rs][r][out] -> gB_c[r][out] ; PA[rs][r][in] -> gA_c[in][r]
     const bool want_reduce = (gA_g || gB_g) && stage_on(SAM3_LORA_STAGE_REDUCE);
@@ -2592,30 +2265,19 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
         ride.accumulate = accumulate;
         const long long nb = (long long)rank * out_features, na = (long long)rank * in_features;
         ride.nblk = (int)(((nb > na ? nb : na) + 63) / 64);
-        if (side || t3ride) {     // gA is summed on the side stream / after the launch that produces its partials
-            ride.j1 = ReduceJob{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
-            ride.nblk = (int)((nb + 63) / 64);
-        }
     }
     // the reduction rides on the bf16 rank-r update of gx (the last kernel of the call) when there is one
     // (with the gA partials produced BY that kernel the sum cannot ride on it: it follows as its own launch)
     const bool riding = want_reduce && !f32 && gx_inout && s2 && !ga_in_pass && !env_flag("SAM3_LORA_NO_RIDE");
     const GaEmit ga{(const bf16_t*)(ws + w.gtt), PA};
-    const T3Ride t3{(const bf16_t*)x, ldx, (const bf16_t*)(ws + w.gtt), PA, Mp, (int)w.pA.rows_per_wg, (int)w.pA.NR, xcd_order_for(in_features)};
     if (!f32 && gx_inout && s2)
         launch_t2<bf16_t>(gx_inout, ldgx, (bf16_t*)(ws + w.gt), (const bf16_t*)W2tb, M, in_features, scale, RT, hl, st, dk, a2, hpre,
-                          ldpre, riding ? &ride : nullptr, a2 ? q8 : nullptr, ga_in_pass ? &ga : nullptr, t3ride ? &t3 : nullptr);
+                          ldpre, riding ? &ride : nullptr, a2 ? q8 : nullptr, ga_in_pass ? &ga : nullptr);
     if (want_reduce && !riding) {
         dim3 grid((unsigned)ride.nblk, 2);
         ProfScope ps(SAM3_LORA_STAGE_REDUCE, in_features + out_features, st);
         hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, st, ride.j0, ride.j1, scale, accumulate);
     }
-    if (t3ride) {       // gA's partials came out of that launch: their fixed-order sum
-        const ReduceJob ja{PA, gA_g, w.pA.NR, RG, in_features, rank, s.a_sr, s.a_si};
-        const ReduceJob none{nullptr, nullptr, 0, RG, 0, 0, 0, 0};
-        hipLaunchKernelGGL(k_reduce, dim3((unsigned)(((long long)rank * in_features + 63) / 64), 1), dim3(256), 0, st, ja, none, scale, accumulate);
-    }
-    if (side) hipStreamWaitEvent(st, side->join, 0);
 }
 
 static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const void* A, const void* B, void* gx_inout,
@@ -2722,25 +2384,32 @@ int sam3_lora_bwd_act_q8(const void* gy, const void* x, const void* tT_saved, co
 
 // ---- the adapter inside the frozen GEMM (fused_linear.inc)
 // per-device facts the persistent kernel needs: CU count (grid size) and whether a workgroup may hold all 160 KB of LDS (gfx950).
-// Cached per device ordinal of the CURRENT device at each call: a process may drive several devices.
+// Cached per device ordinal.  A launch asks for the device its STREAM belongs to (a process may drive several devices and the
+// current device need not be the tensors'); the shape query, which has no stream, asks for the current device.  `cus` is published
+// last with release ordering and read with acquire: a thread that sees it non-zero also sees `lds_ok`.
 struct FusedDevInfo {
     std::atomic<int> cus{0}, lds_ok{-1};
 };
 static FusedDevInfo g_fused_dev[64];
-static FusedDevInfo* fused_dev_info() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+static FusedDevInfo* fused_dev_info(void* stream = nullptr, bool have_stream = false) {
+    int dev = -1;
+    if (have_stream && stream != nullptr) {
+        hipDevice_t sd = 0;
+        if (hipStreamGetDevice((hipStream_t)stream, &sd) == hipSuccess) dev = (int)sd;
+    }
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= 64) dev = 0;
     FusedDevInfo* d = &g_fused_dev[dev];
-    if (d->cus.load(std::memory_order_relaxed) == 0) {
+    if (d->cus.load(std::memory_order_acquire) == 0) {
         int cus = 0, lds = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         const bool known = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess;
         d->lds_ok.store((!known || lds >= (int)fl::TileGeo<fl::CfgBig>::LDS_BYTES) ? 1 : 0, std::memory_order_relaxed);
-        d->cus.store(cus, std::memory_order_relaxed);
+        d->cus.store(cus, std::memory_order_release);
     }
     return d;
 }
-static int fused_cu_count() { return fused_dev_info()->cus.load(std::memory_order_relaxed); }
+static int fused_cu_count(void* stream) { return fused_dev_info(stream, true)->cus.load(std::memory_order_acquire); }
 
 int sam3_lora_linear_fwd_supported(int in_features, int out_features, int rank, int dtype) {
     if (!(dtype == SAM3_LORA_BF16 && rank >= 1 && rank <= 32 && n_groups(rank, dtype) == 1 && in_features > 0 && out_features > 0 &&
@@ -2864,27 +2533,22 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
             fa.sx = f8->scale_x; fa.sw = f8->scale_w;
             fa.q8 = f8->q8;
         }
-        // tile configuration: 1 = fl::CfgPair (256 x 128 x 32, two workgroups per CU), 0 = fl::CfgBig (256 x 256 x 64, one)
-        // tile configuration: 0 = fl::CfgBig, 1 = fl::CfgPair, 2 = fl::CfgRing (256 x 256 x 32, four-stage ring)
-        const int tile_cfg = (f8 || mirror) ? 0 : (int)env_int("SAM3_LORA_FUSED_TILE", 0);
-        const int pair = tile_cfg == 1, ring = tile_cfg == 2;
-        const int bm = pair ? fl::CfgPair::BM : fl::CfgBig::BM, bn = pair ? fl::CfgPair::BN : fl::CfgBig::BN;
+        const int bm = fl::CfgBig::BM, bn = fl::CfgBig::BN;
         fa.tiles_m = (int)((M + bm - 1) / bm);
         {   // a last column of tiles at most half a tile wide runs as "half tiles" (fl::TileSeq); SAM3_LORA_FUSED_HALF=0: as full ones
             const int rem = out_features % bn;
             fa.half_col = (rem > 0 && rem <= bn / 2 && env_int("SAM3_LORA_FUSED_HALF", 1) != 0) ? 1 : 0;
             fa.ncf = fa.half_col ? out_features / bn : (out_features + bn - 1) / bn;
         }
-        fa.early = env_int("SAM3_LORA_FUSED_EARLY", 0) != 0 ? 1 : 0;      // measured slower (fused_linear.inc, EARLY): off
         const long long ntiles = (long long)fa.tiles_m * (fa.ncf + fa.half_col);
-        long long grid = env_int("SAM3_LORA_FUSED_WGS", (long long)fused_cu_count() * (pair ? fl::CfgPair::WGS_PER_CU : 1));
+        long long grid = env_int("SAM3_LORA_FUSED_WGS", (long long)fused_cu_count(stream));
         if (grid > ntiles) grid = ntiles;
         if (grid < 1) grid = 1;
         const int trow = RP * 2;
         ProfScope ps(SAM3_LORA_STAGE_FUSED, out_features, st);
 #define SAM3_FL_LAUNCH(CFG_, ACT_, TROW_) \
         hipLaunchKernelGGL((fl::k_fused_linear<fl::CFG_, ACT_, TROW_>), dim3((unsigned)grid), dim3(fl::TileGeo<fl::CFG_>::NTHREADS), 0, st, fa)
-#define SAM3_FL_CFG(ACT_, TROW_) do { if (pair) SAM3_FL_LAUNCH(CfgPair, ACT_, TROW_); else if (ring) SAM3_FL_LAUNCH(CfgRing, ACT_, TROW_); else SAM3_FL_LAUNCH(CfgBig, ACT_, TROW_); } while (0)
+#define SAM3_FL_CFG(ACT_, TROW_) SAM3_FL_LAUNCH(CfgBig, ACT_, TROW_)
         const int probe = (int)env_int("SAM3_LORA_FUSED_PROBE", 0);
         if (mirror) {
 #define SAM3_FL_MIRROR(TROW_) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 2, TROW_>), dim3((unsigned)grid), dim3(512), 0, st, fa)
@@ -2895,10 +2559,7 @@ static int linear_fwd_impl(const void* x, const void* W, const void* bias, const
             if (act) { if (trow == 128) SAM3_FL_F8(1, 128); else if (trow == 64) SAM3_FL_F8(1, 64); else SAM3_FL_F8(1, 32); }
             else { if (trow == 128) SAM3_FL_F8(0, 128); else if (trow == 64) SAM3_FL_F8(0, 64); else SAM3_FL_F8(0, 32); }
 #undef SAM3_FL_F8
-        } else if (probe && ring && trow == 64 && !act && probe <= 2) {      // the same two probes on the four-stage ring
-            if (probe == 1) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgRing, 0, 64, 1>), dim3((unsigned)grid), dim3(512), 0, st, fa);
-            else hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgRing, 0, 64, 2>), dim3((unsigned)grid), dim3(512), 0, st, fa);
-        } else if (probe && !pair && !ring && trow == 64) {      // measurement aid (fl::k_fused_linear's PROBE): fill alone / matrix pipe alone
+        } else if (probe && trow == 64) {      // measurement aid (fl::k_fused_linear's PROBE): fill alone / matrix pipe alone
 #define SAM3_FL_PROBE(P_) do { if (act) hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 1, 64, P_>), dim3((unsigned)grid), dim3(512), 0, st, fa); \
                                else hipLaunchKernelGGL((fl::k_fused_linear<fl::CfgBig, 0, 64, P_>), dim3((unsigned)grid), dim3(512), 0, st, fa); } while (0)
             if (probe == 1) SAM3_FL_PROBE(1); else if (probe == 2) SAM3_FL_PROBE(2); else if (probe == 3) SAM3_FL_PROBE(3);

@@ -143,6 +143,7 @@ class LoRAGradReducer:
         self.launch_log = []
         self.launch_events = []
         self._works = []
+        self._flags_back_event = None      # (a step whose `skip_unused` was toggled between launch and finish() leaves none behind)
         self._armed = True
 
     def notify(self, param: torch.nn.Parameter):

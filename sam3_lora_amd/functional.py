@@ -782,8 +782,12 @@ class _LoRAMlpFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[i] for i in (3, 4, 8, 9))
         fused1 = (fused_linear_enabled() and not q8_ok and not fp8.eligible(x2, W1) and _fused_layout_ok(x2, W1, b1)
                   and linear_fwd_supported(W1.shape[1], W1.shape[0], _rank_of(_master(A1), layout), cdt))
+        # (the layout predicate comes BEFORE anything with side effects: fp8.producer_slots below flips the delayed-scaling buffers of
+        # W2's input role, so the fused call must be certain to be accepted once it has run)
+        xq_given = x_q8 is not None and x_q8[2] == id(W1) and x_q8[0].shape == x2.shape
         fused1_q8 = (fused_linear_enabled() and fused_linear_fp8_enabled() and q8_ok and fp8.eligible(x2, W1) and x2.dtype == torch.bfloat16
-                     and W1.shape[1] % 128 == 0
+                     and W1.shape[1] % 128 == 0 and _fused_layout_ok(x2, W1, b1)
+                     and (not xq_given or (x_q8[0].stride(1) == 1 and x_q8[0].stride(0) % 16 == 0 and x_q8[0].data_ptr() % 16 == 0))
                      and linear_fwd_supported(W1.shape[1], W1.shape[0], _rank_of(_master(A1), layout), cdt))
         if fused1:
             # frozen GEMM + rank-r K step + bias + GELU in ONE kernel -- h and a are written once, never re-read
@@ -794,7 +798,7 @@ class _LoRAMlpFn(torch.autograd.Function):
             # the same in the fp8 frozen-W mode: e4m3 x (the LayerNorm's image when it made one for this weight) and W on the
             # scaled fp8 MFMA, the LoRA branch as a bf16 K step, and GELU(h) also as the e4m3 input of fc2's GEMM
             st = fp8.state_for(W1)
-            if x_q8 is not None and x_q8[2] == id(W1) and x_q8[0].shape == x2.shape:
+            if xq_given:
                 xq, sx = x_q8[0], x_q8[1]
             else:
                 xq, sx = st.qx(x2)
@@ -826,7 +830,10 @@ class _LoRAMlpFn(torch.autograd.Function):
         ctx.wt = (Wt1, Wt2)
         # a = GELU(h) is fc2's input; the backward needs it for gA2 only, and where the kernels can they recompute it from h
         # inside the pass that applies GELU'(h) (sam3_lora_bwd_act with x == NULL): not saved then (393 MB per block at batch 8)
-        ctx.mirror = bool(_knob("SAM3_LORA_MIRROR") and drop_p == 0.0 and h.dtype == torch.bfloat16 and not q8_ok and not fp8.eligible(a, W2)
+        # (the mirror only ever runs for an input gradient, on layouts the kernel addresses -- otherwise `a` would be kept for nothing)
+        ctx.mirror = bool(_knob("SAM3_LORA_MIRROR") and ctx.needs_input_grad[0] and drop_p == 0.0 and h.dtype == torch.bfloat16 and not q8_ok
+                          and not fp8.eligible(a, W2) and _fused_layout_ok(h, W2, None)
+                          and (Wt2 is None or (Wt2.stride(1) == 1 and Wt2.data_ptr() % 16 == 0 and (Wt2.stride(0) * Wt2.element_size()) % 16 == 0))
                           and linear_fwd_supported(W2.shape[0], W2.shape[1], _rank_of(_master(A2), layout), cdt))
         ctx.recompute_a = bool(need_w and t2 is not None and not ctx.mirror
                                and bwd_act_recomputes_input(_rank_of(_master(A2), layout), h.dtype, drop_p))
@@ -852,7 +859,7 @@ class _LoRAMlpFn(torch.autograd.Function):
         else:
             gA1, gB1, gA2, gB2 = ((torch.empty_like(t) if need_w else None) for t in (A1m, B1m, A2m, B2m))
         from . import fp8
-        if ctx.mirror and need_x and gy2.shape[0] > 0:
+        if ctx.mirror and need_x and gy2.shape[0] > 0 and gy2.stride(1) == 1 and gy2.data_ptr() % 16 == 0 and (gy2.stride(0) * gy2.element_size()) % 16 == 0:
             # SURVEY 8f-1's backward mirror behind SAM3_LORA_MIRROR=1 (an A/B knob): gh as ONE MFMA kernel, the weight
             # gradients from the adapter backward without gx (it then reads the stored activation for gA)
             Wt2 = ctx.wt[1] if (ctx.wt[1] is not None and ctx.wt[1].dtype == gy2.dtype and ctx.wt[1].shape == (W2.shape[1], W2.shape[0])

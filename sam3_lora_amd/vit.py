@@ -637,15 +637,21 @@ def _cast_inputs_hook(dtype, skip=()):
     """Forward pre-hook casting floating-point tensor arguments to ``dtype``; arguments named in ``skip`` are left alone whether they
     arrive by keyword or by position (bound through the module's forward signature: a positional ``memory`` would otherwise get an fp32
     copy of all 5184 x batch memory tokens at the decoder's entry)."""
+    positional = {}          # type(module) -> positional parameter names of its forward, resolved once (not per call: this hook runs
+                             # on every forward of every boundary module of a launch-bound step)
+
     def hook(module, args, kwargs):
         skip_pos = ()
         if skip and args:
-            import inspect
-            try:
-                names = [n for n in inspect.signature(module.forward).parameters][:len(args)]
-                skip_pos = tuple(i for i, n in enumerate(names) if n in skip)
-            except (TypeError, ValueError):
-                skip_pos = ()
+            names = positional.get(type(module))
+            if names is None:
+                import inspect
+                try:
+                    names = tuple(inspect.signature(module.forward).parameters)
+                except (TypeError, ValueError):
+                    names = ()
+                positional[type(module)] = names
+            skip_pos = tuple(i for i, n in enumerate(names[:len(args)]) if n in skip)
         new_args = tuple(a if i in skip_pos else _tree_cast(a, dtype) for i, a in enumerate(args))
         return new_args, {k: (v if k in skip else _tree_cast(v, dtype)) for k, v in kwargs.items()}
     return hook

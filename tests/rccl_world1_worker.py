@@ -63,6 +63,35 @@ def main():
     out["grads_equal"] = bool(torch.equal(red.flat[red._grad0:], want[red._grad0:]))
     out["flags"] = red.flat[:len(red.params)].tolist()
     out["launch_log"] = red.launch_log
+    # where the buckets' all-reduces sit relative to the END of backward on the GPU's clock: a deeper stack on
+    # enough rows that the backward takes a few milliseconds; the hooks launch a bucket as soon as its last gradient is final, so every
+    # bucket but the last one must START while later layers' backward kernels are still queued behind it
+    deep = torch.nn.Sequential(*[torch.nn.Linear(512, 512) for _ in range(12)]).to(dev)
+    for i in range(len(deep)):
+        deep[i] = L.LoRALinear(deep[i], rank=16, alpha=32)
+    for m in deep.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.weight.requires_grad_(False), m.bias.requires_grad_(False)
+    with torch.no_grad():
+        for m in deep.modules():
+            if isinstance(m, L.LoRALayer):
+                m.lora_B.normal_(0, 0.05)
+    dparams = [p for p in deep.parameters() if p.requires_grad]
+    dred = LoRAGradReducer(dparams, bucket_bytes=128 << 10, run_collectives_alone=True)
+    xd = torch.randn(40000, 512, device=dev)
+    for it in range(3):                 # the first pass warms the communicator and the allocator
+        dred.zero_grad()
+        dred.trace = it == 2
+        loss = deep(xd).pow(2).mean()
+        loss.backward()
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(torch.cuda.current_stream(dev))
+        dred.finish()
+        torch.cuda.synchronize()
+    out["deep_buckets"] = len(dred.buckets)
+    out["deep_launch_log"] = dred.launch_log
+    out["deep_bucket_start_ms_after_backward_end"] = [round(end.elapsed_time(e0), 3) for (_, e0, _, _) in dred.launch_events]
+    out["deep_bucket_end_ms_after_backward_end"] = [round(end.elapsed_time(e1), 3) for (_, _, e1, _) in dred.launch_events]
     nb = allreduce_scalar_sum(torch.tensor([5.0], device=dev))
     out["scalar"] = nb.item()
     dist.barrier()

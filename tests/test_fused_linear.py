@@ -37,7 +37,7 @@ def _reload():
 def _knobs_back():
     yield
     if torch.cuda.is_available():
-        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_FUSED_EARLY", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_HL_MAX_RANK"):
+        for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_HL_MAX_RANK"):
             os.environ.pop(k, None)
         _reload()
         Fn.set_fused_linear(None)
@@ -68,10 +68,7 @@ SHAPES = [(1000, 128, 520, 16, 0), (1000, 128, 520, 16, 1), (37, 64, 8, 4, 0), (
 @pytest.mark.parametrize("M,fin,fout,rank,layout", SHAPES)
 @pytest.mark.parametrize("gelu", [False, True])
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("tile", ["0", "1"])
-def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, layout, gelu, packed, tile):
-    os.environ["SAM3_LORA_FUSED_TILE"] = tile       # 0: 256 x 256 x 64, one workgroup per CU; 1: 256 x 128 x 32, two per CU
-    _reload()
+def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, layout, gelu, packed):
     x, W, b, A, B = _case(M, fin, fout, rank, layout, seed=M + rank)
     s = 1.7
     want = O.lora_linear_forward(x, W, b, A, B, s, layout, acc_dtype=np.float64)
@@ -88,12 +85,9 @@ def test_fused_linear_is_the_fp64_oracle_to_one_rounding(M, fin, fout, rank, lay
     assert torch.equal(tT, tT2)
 
 
-@pytest.mark.parametrize("tile", ["0", "1"])
-def test_no_bias_rank_32_and_single_rounded_images(tile):
+def test_no_bias_rank_32_and_single_rounded_images():
     """Ranks 17..32: the rank-r term is 128 K slots (two more K steps) of hi + lo images -- one rounding, as r <= 16; with
     SAM3_LORA_HL_MAX_RANK=16 / SAM3_LORA_SINGLE_ROUND=1 the plain [M][32] / [M][16] row images (1e-2)."""
-    os.environ["SAM3_LORA_FUSED_TILE"] = tile
-    _reload()
     M, fin, fout = 700, 128, 520
     for rank in (32, 24, 17):
         x, W, _, A, B = _case(M, fin, fout, rank, 0, seed=rank, bias=False)
@@ -129,18 +123,15 @@ def test_dropout_on_the_branch_input_only():
 
 
 def test_persistent_tile_walk_is_bit_identical_for_any_grid():
-    """12 (24) tiles + a last column of tiles 8 columns wide on 1 / 3 / 5 / 512 workgroups, that column run as half tiles (waves
-    re-arranged 4 x 2, dealt to the workgroups with one full tile fewer) or as full ones, both tile configurations, repeated: the
-    same bits."""
+    """12 tiles + a last column of tiles 8 columns wide on 1 / 3 / 5 / 512 workgroups, that column run as half tiles (waves
+    re-arranged 4 x 2, dealt to the workgroups with one full tile fewer) or as full ones, repeated: the same bits."""
     M, fin, fout, rank = 1000, 192, 776, 16
     x, W, b, A, B = _case(M, fin, fout, rank, 0, seed=3)
     args = (_t(x, torch.bfloat16), _t(W, torch.bfloat16), _t(b, torch.bfloat16), _t(A), _t(B), 2.0, 0)
     outs = []
-    for wgs, order, tile, early in [(w, o, t, e) for w in ("1", "3", "5", "512") for o in ("0", "1") for t in ("0", "1", "2") for e in ("1", "0")]:
-        if tile == "0" or early == "1":        # grid size, half-tile scheduling (placement only), tile configuration (same K order per output
-            # element) and, for the default configuration, the tile switch with / without the next tile's two K steps issued ahead of the stores
-            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_HALF"], os.environ["SAM3_LORA_FUSED_TILE"] = wgs, order, tile
-            os.environ["SAM3_LORA_FUSED_EARLY"] = early
+    for wgs, order in [(w, o) for w in ("1", "3", "5", "512") for o in ("0", "1")]:
+        if True:        # grid size and half-tile scheduling change placement only
+            os.environ["SAM3_LORA_FUSED_WGS"], os.environ["SAM3_LORA_FUSED_HALF"] = wgs, order
             _reload()
             for _ in range(3):              # repeated: a race between DMA and read would show as run-to-run differences
                 y, a, _ = Fn.lora_linear_fwd_(*args, gelu=True)
@@ -151,10 +142,7 @@ def test_persistent_tile_walk_is_bit_identical_for_any_grid():
     _one_rounding(outs[0][0].float().cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2"])
-def test_fused_linear_at_configs1_fc1_shape(tile):
-    os.environ["SAM3_LORA_FUSED_TILE"] = tile
-    _reload()
+def test_fused_linear_at_configs1_fc1_shape():
     _configs1_fc1_shape()
 
 
@@ -300,10 +288,9 @@ def test_mlp_node_with_the_mirror_knob_gives_the_default_paths_gradients():
 
 
 @pytest.mark.parametrize("gelu", [True, False])
-def test_early_tile_switch_is_bit_identical_at_the_benchmark_shape(gelu):
-    """The tile switch that issues the next tile's first two K steps BEFORE the epilogue's stores and waits with counted vmcnt
-    (SAM3_LORA_FUSED_EARLY=1; measured slower, not the default) against the drained form (=0) at M = 41,472, 1024 -> 4736, r = 16: 12 tiles per workgroup,
-    half tiles in the mix, four launches each -- a DMA read too early would show as differing bits."""
+def test_repeated_launches_are_bit_identical_at_the_benchmark_shape(gelu):
+    """M = 41,472, 1024 -> 4736, r = 16: 12 tiles per workgroup, half tiles in the mix, five launches -- a DMA stage read before it
+    has landed (or overwritten while a wave still reads it) would show as differing bits."""
     M, fin, fout, rank = 41472, 1024, 4736, 16
     g = torch.Generator(device=DEV).manual_seed(21)
     x = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
@@ -312,9 +299,7 @@ def test_early_tile_switch_is_bit_identical_at_the_benchmark_shape(gelu):
     A = (torch.rand(fin, rank, device=DEV, generator=g) - 0.5) / 2
     B = torch.randn(rank, fout, device=DEV, generator=g) * 0.05
     ref = None
-    for early in ("0", "1", "1", "1", "1"):
-        os.environ["SAM3_LORA_FUSED_EARLY"] = early
-        _reload()
+    for _ in range(5):
         y, a, _ = Fn.lora_linear_fwd_(x, W, b, A, B, 2.0, 0, gelu=gelu)
         if ref is None:
             ref = (y.clone(), a.clone() if gelu else None)

@@ -27,3 +27,9 @@ def test_reducer_runs_on_rccl_with_world_size_1():
     assert r["flags"] and all(f == 1.0 for f in r["flags"])
     assert r["elements_reduced"] == r["flat_elements"]
     assert r["grads_equal"] and r["scalar"] == 5.0
+    # launch positions on the GPU's clock: every bucket is launched from a hook, in index order, and all but the last START before the
+    # backward has ended (negative = earlier than the end-of-backward event) -- the exchange rides behind the remaining backward
+    assert r["deep_buckets"] >= 3 and r["deep_launch_log"] == [[b, "hook"] for b in range(r["deep_buckets"])]
+    starts = r["deep_bucket_start_ms_after_backward_end"]
+    assert len(starts) == r["deep_buckets"] and all(s < 0 for s in starts[:-1]), starts
+    assert starts == sorted(starts), starts

@@ -43,10 +43,12 @@ def build_wide(gold_wide, device="cpu", **kw):
     return model
 
 
-def make_batch_wide():
+def make_batch_wide(case="wide"):
+    """The collated batch of a wide-model fixture: images by seed, texts of e2e_case_defs.SAMPLES, the ground-truth boxes chosen for
+    THIS fixture's decisions (e2e_case_defs.samples_for: tests/golden/e2e_boxes.json)."""
     res = D.WIDE_RES
     dps = []
-    for i, ((text, boxes), img) in enumerate(zip(D.SAMPLES, D.make_images_res(res))):
+    for i, ((text, boxes), img) in enumerate(zip(D.samples_for(case), D.make_images_res(res))):
         objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask_res(b, res))
                 for j, b in enumerate(boxes)]
         q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
@@ -80,7 +82,7 @@ def build(gold, device="cpu", **kw):
 
 def make_batch():
     dps = []
-    for i, ((text, boxes), img) in enumerate(zip(D.SAMPLES, D.make_images())):
+    for i, ((text, boxes), img) in enumerate(zip(D.samples_for("tiny"), D.make_images())):
         objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask(b))
                 for j, b in enumerate(boxes)]
         q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
@@ -324,97 +326,49 @@ def test_training_step_through_hip_adapters_matches_reference(gold, ckpt):
     assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
 
 
-O2M_ALPHA, O2M_THRESHOLD, O2M_TOPK = 0.3, 0.4, 4        # trainer.build_criterion's BinaryOneToManyMatcher (the reference's values)
-
-
-def _o2m_report(out, gold, batch, margin=0.025):
-    """The final output's one-to-many assignment (``alpha p + (1 - alpha) IoU`` in the per-target top-k AND above 0.4) against the
-    reference's, re-derived from the reference's stored fp32 outputs.  It is a THRESHOLD decision: a pair whose reference score
-    lies within ``margin`` of the larger of the threshold and its target's top-k cut is decided by the build's rounding noise -- the fixtures hold such
-    pairs (e2e_wide_minimal_r4: the only match of the final output scores 0.4002; e2e_wide: 0.4033 in an auxiliary output), and when
-    one flips, every ``*_o2m`` loss term of that output and with it the first step's total change by tens of percent.
-    Returns {"equal", "fragile_flip", "differing": [(b, q, t, reference score)]}; a difference that is not fragile is a failure."""
-    from sam3_lora_amd.losses import box_cxcywh_to_xyxy, box_iou
-    if "lora/pred_logits_o2m" not in gold.files or out.get("indices_o2m") is None:
-        return {"equal": True, "fragile_flip": False, "differing": []}
-    ft = batch.find_targets[0]
-    tgt, nb = ft.boxes_padded.float().cpu(), ft.num_boxes.cpu()
-    prob = torch.tensor(gold["lora/pred_logits_o2m"]).float().sigmoid().squeeze(-1)
-    iou, _ = box_iou(box_cxcywh_to_xyxy(torch.tensor(gold["lora/pred_boxes_o2m"]).float()), box_cxcywh_to_xyxy(tgt))
-    C = O2M_ALPHA * prob.unsqueeze(-1) + (1 - O2M_ALPHA) * iou
-    nq, nt = C.shape[1], C.shape[2]
-    cut = torch.quantile(C, 1 - O2M_TOPK / nq, dim=1, keepdim=True)
-    valid = (torch.arange(nt)[None] < nb[:, None]).unsqueeze(1)
-    ref = (C > cut) & (C > O2M_THRESHOLD) & valid
-    bi, si, ti = (t.cpu() for t in out["indices_o2m"])
-    offs = torch.cat([torch.zeros(1, dtype=torch.long), nb.long().cumsum(-1)[:-1]])
-    ours = torch.zeros_like(ref)
-    ours[bi, si, ti - offs[bi]] = True
-    diff = torch.nonzero(ours != ref)
-    near = (C - cut.clamp(min=O2M_THRESHOLD)).abs() <= margin        # a pair is positive iff its score exceeds BOTH the top-k cut and the threshold
-    differing = [(int(b), int(q), int(t), round(float(C[b, q, t]), 4)) for b, q, t in diff]
-    return {"equal": len(differing) == 0, "fragile_flip": len(differing) > 0 and all(bool(near[b, q, t]) for b, q, t, _ in differing),
-            "differing": differing}
-
-
-def _rematch_explained(gaps):
-    """A re-matched output is the Hungarian solver doing its job on slightly different costs -- not a defect -- exactly when the
-    reference's cost matrix rates this build's assignment no further above its own optimum than the two cost matrices differ:
-    with eps = max |C_build - C_reference| over all (query, target) pairs and T targets, optimality of each assignment under its own
-    costs gives  C_ref(ours) - C_ref(ref) <= 2 T eps.  A larger gap means the assignment is NOT the optimum of the build's own costs
-    (a matcher defect); how large eps may be is bounded by the output checks (scores and boxes against the yardstick).  A fixed bar
-    does not work: 0.10 failed on a run whose boxes deviated 5.3e-2 (the yardstick's own figure) with a gap of 0.114."""
-    return all(v["gap"] <= v["bound"] + 1e-4 for v in gaps.values())
-
-
-def _rematch_report(out, gold, batch):
-    """Final and auxiliary outputs whose Hungarian assignment differs from the reference's: {name: {"gap", "eps", "bound"}} with
-    gap = the amount by which the REFERENCE's own cost matrix (its stored fp32 scores and boxes) rates this build's assignment above
-    its optimum, eps = the largest difference between this build's cost matrix and the reference's, bound = 2 T eps
-    (:func:`_rematch_explained`).  Gaps to the second-best assignment in the fixtures (final output): tiny 0.12 / 0.26, wide
-    0.33 / 0.017, wide_large_r32 0.018 / 0.27, wide_minimal_r4 0.14 / 1.2; {} = every output matched as the reference's."""
-    matcher, _ = _criterion()
-    ft = batch.find_targets[0]
-    tgt, nb = ft.boxes_padded.float().cpu(), [int(v) for v in ft.num_boxes.cpu()]
-    gaps = {}
+def _decisions(out, gold):
+    """Every discrete decision of the first step against the reference's, bit for bit: the Hungarian indices of the final and the
+    auxiliary outputs, of each auxiliary one-to-many twin, and the final twin's threshold matches (``lora/**/indices``,
+    ``lora/**/indices_o2m`` of the fixture).  The fixtures' boxes were chosen so that each of these is taken with a margin
+    (tests/golden/margins.py; test_fixture_decisions_have_margins), so NO layout of this build may move one: returns the list of
+    decisions that differ (empty = all equal) and how many were compared."""
+    differing, n = [], 0
     for name, node, pre in [("final", out, "lora/")] + [(f"aux{i}", a, f"lora/aux{i}/") for i, a in enumerate(out["aux_outputs"])]:
-        if pre + "indices" not in gold.files:
-            continue
-        got = torch.stack([node["indices"][0], node["indices"][1]]).cpu().numpy()
-        ref = gold[pre + "indices"]
-        if np.array_equal(got, ref):
-            continue
-        Cr = matcher.cost_matrix(torch.tensor(gold[pre + "pred_logits"]).float().squeeze(-1), torch.tensor(gold[pre + "pred_boxes"]).float(), tgt).numpy()
-
-        def cost(idx):      # entries of an image are listed in target order
-            seen, tot = {}, 0.0
-            for b, q in zip(idx[0], idx[1]):
-                t = seen.get(int(b), 0)
-                seen[int(b)] = t + 1
-                tot += float(Cr[int(b), int(q), t])
-            return tot
-        eps = float("inf")
-        if "pred_logits" in node and "pred_boxes" in node:
-            Co = matcher.cost_matrix(node["pred_logits"].detach().float().cpu().squeeze(-1), node["pred_boxes"].detach().float().cpu(), tgt).numpy()
-            eps = max(float(np.abs(Co[b, :, :n] - Cr[b, :, :n]).max()) for b, n in enumerate(nb) if n > 0)
-        gap = cost(got) - cost(ref) if got.shape == ref.shape else float("inf")
-        gaps[name] = {"gap": gap, "eps": eps, "bound": 2.0 * sum(nb) * eps}
-    return gaps
+        if pre + "indices" in gold.files:
+            got = torch.stack([node["indices"][0], node["indices"][1]]).cpu().numpy()
+            n += 1
+            if not np.array_equal(got, gold[pre + "indices"]):
+                differing.append(name)
+        if pre + "indices_o2m" in gold.files and node.get("indices_o2m") is not None:
+            ref = gold[pre + "indices_o2m"]
+            got = torch.stack([t for t in node["indices_o2m"][:ref.shape[0]]]).cpu().numpy()
+            n += 1
+            if not np.array_equal(got, ref):
+                differing.append(name + "_o2m")
+    return differing, n
 
 
-def _assert_first_step_loss(m, bound, what):
-    """The first step's total against the reference -- unless the final output's one-to-many assignment flipped on a pair the
-    fixture leaves undecided (:func:`_o2m_report`): then every term that does not hang on that assignment is held to ``bound``
-    (floored at 5 %: single terms are smaller numbers than the total) and the total itself is not compared."""
-    o = m.get("o2m", {"equal": True})
-    assert o["equal"] or o["fragile_flip"], ("the one-to-many assignment differs on a pair that is NOT near its threshold", o)
-    if o["equal"]:
-        assert m["loss_terms"]["core_loss"] <= bound, (what, m["loss_terms"]["core_loss"], bound)
-        return True
-    final_o2m = {k for k in m["loss_terms"] if k.endswith("_o2m") and "_aux_" not in k}
-    worst = max(v for k, v in m["loss_terms"].items() if k not in final_o2m and k != "core_loss")
-    assert worst <= max(bound, 0.05), (what, o, m["loss_terms"])
-    return False
+# The bf16 layout (what bench.py times), held strictly since round 6: the fixtures' ground-truth boxes were chosen so that every
+# discrete decision of the step has a margin (Hungarian gaps >= 0.3, one-to-many scores >= 0.05 from their threshold:
+# tests/golden/margins.py), so a mixed-precision build must take EVERY decision as the reference's fp32 run does, and then its loss and
+# gradients are comparable numbers: first step's total and every step of the curve within BF16_CURVE_BAR, A/B gradients within twice
+# what this build measured on the fixture (BF16_GRAD_MEASURED, profiles/r06*_parity_*), output tensors within the reference's own
+# autocast(bf16) deviation (ref_autocast_bf16.json: the largest of three image samples; masks 2x -- the mask head stays bf16).
+BF16_CURVE_BAR = 1e-2
+BF16_GRAD_MEASURED = {"tiny": 0.155, "wide": 0.146, "wide_large_r32": 0.15, "wide_minimal_r4": 0.15, "full": 0.12}
+
+
+def _assert_bf16_layout_step(m, yard, case, floor=None):
+    lim = lambda k, mult=1.0: mult * max(yard[k], floor[k] if floor else 0.0)
+    logit_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_logits"))
+    box_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes"))
+    assert logit_err <= lim("pred_logits") and box_err <= lim("pred_boxes"), (case, logit_err, box_err, yard)
+    assert m["outputs"]["presence_logit_dec"] <= lim("presence_logit_dec") and m["outputs"]["pred_masks"] <= lim("pred_masks", 2.0), (case, m["outputs"], yard)
+    assert m["decisions_compared"] >= 4 and not m["decisions_differing"], (case, "decisions that differ from the reference's", m["decisions_differing"])
+    assert all(np.isfinite(m["losses"]))
+    assert m["loss_terms"]["core_loss"] <= BF16_CURVE_BAR, (case, m["loss_terms"])
+    assert max(m["loss_curve_rel"]) <= BF16_CURVE_BAR, (case, m["losses"], m["loss_curve_rel"])
+    assert max(m["grads"].values()) <= 2.0 * BF16_GRAD_MEASURED[case], (case, m["grads"])
 
 
 def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True):
@@ -449,10 +403,8 @@ def run_training_steps(model, layers, gold, batch, steps, lr, wd, prefetch=True)
                 for k in ("pred_logits", "pred_boxes"):
                     ref = gold[f"lora/aux{i}/{k}"]
                     m["outputs"][f"aux{i}/{k}"] = float(np.abs(aux[k].detach().float().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12))
-            got = torch.stack([out["indices"][0], out["indices"][1]]).cpu().numpy()
-            m["indices_equal"] = bool(np.array_equal(got, gold["lora/indices"]))
-            m["o2m"] = _o2m_report(out, gold, batch)
-            m["rematch_cost_gap"] = _rematch_report(out, gold, batch)
+            m["decisions_differing"], m["decisions_compared"] = _decisions(out, gold)
+            m["indices_equal"] = not m["decisions_differing"]
             for k in gold.files:
                 if k.startswith("loss/") and "ce_f1" not in k and "acc" not in k:
                     ref = float(gold[k])
@@ -565,7 +517,7 @@ def test_yaml_configurations_whole_step_matches_reference(case, layout):
     if layout == "bf16":
         from sam3_lora_amd.vit import to_training_layout
         to_training_layout(model)
-    m = run_training_steps(model, layers, gold, move_to_device(make_batch_wide(), dev), D.STEPS, D.CONFIGS[case][3], D.WD)
+    m = run_training_steps(model, layers, gold, move_to_device(make_batch_wide(case), dev), D.STEPS, D.CONFIGS[case][3], D.WD)
     _record(f"{case}_{layout}", m)
     assert "libsam3_lora_amd.so" in open("/proc/self/maps").read()
     assert len(m["grads"]) >= (6 if case == "wide_large_r32" else 4)
@@ -576,19 +528,7 @@ def test_yaml_configurations_whole_step_matches_reference(case, layout):
         assert max(m["grads"].values()) <= 5e-3, m["grads"]
         assert max(m["loss_curve_rel"]) <= 1e-3, (m["losses"], m["loss_curve_rel"])
         return
-    yard = _yardstick(case)
-    logit_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_logits"))
-    box_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes"))
-    # (this configuration's yardstick, floored at the wide fixture's: two of its entries are this small by luck of one run)
-    floor = _yardstick("wide")
-    lim = lambda k, mult=1.0: mult * max(yard[k], floor[k])
-    assert logit_err <= lim("pred_logits") and box_err <= lim("pred_boxes"), (logit_err, box_err, yard)
-    assert m["outputs"]["presence_logit_dec"] <= lim("presence_logit_dec") and m["outputs"]["pred_masks"] <= lim("pred_masks", 2.0), (m["outputs"], yard)
-    assert _rematch_explained(m["rematch_cost_gap"]), m["rematch_cost_gap"]
-    if not m["rematch_cost_gap"]:           # (a re-matched output's loss terms belong to another assignment: _rematch_report)
-        _assert_first_step_loss(m, lim("core_loss"), case)
-    assert max(m["loss_curve_rel"][1:]) <= (0.05 if m["rematch_cost_gap"] else max(lim("core_loss"), 2e-2)), (m["losses"], m["loss_curve_rel"])
-    assert all(np.isfinite(m["losses"]))
+    _assert_bf16_layout_step(m, _yardstick(case), case, floor=_yardstick("wide"))
 
 
 @pytest.mark.parametrize("case", sorted(D.YAML_CASES))
@@ -614,10 +554,7 @@ def test_yaml_configurations_inject_the_references_modules(case):
 GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_full.npz")
 
 
-FULL_BF16_SLACK = 1.5       # see test_full_size_training_step_bf16_layout_against_reference
-
-
-def _full_size_step(layout, islands=None, holes=None, post_layout=None):
+def _full_size_step(layout, islands=None, holes=None, post_layout=None, steps=None):
     """One training step at the REAL model size through this library on the GPU, `layout` = "fp32" (exact-fp32 adapters) or "bf16"
     (vit.to_training_layout: exactly what bench.py runs -- bf16 frozen tensors and activations, fp32 A/B, the default fp32
     islands, fused fc1, hi + lo operands); returns the error record against e2e_full.npz.  The REAL model size (e2e_case_defs.FULL = sam3/model_builder.py:69-187,486-495: 1008^2 input, 72 x 72 tokens, depth-32
@@ -652,7 +589,7 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None):
             post_layout(model)
     # the batch: the first sample at 1008^2 (the generator's first draw), 2 boxes + rectangular masks
     res = D.FULL_RES
-    (text, boxes), img = D.FULL_SAMPLES[0], D.make_images_res(res)[0]
+    (text, boxes), img = D.samples_for("full")[0], D.make_images_res(res)[0]
     objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask_res(b, res))
             for j, b in enumerate(boxes)]
     q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
@@ -668,13 +605,10 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None):
     batch = move_to_device(batch, dev)
     matcher, wrapper = _criterion()
     model.set_prefetch_matcher(wrapper)
-    outputs = model(batch)
-    targets = [model.back_convert(t) for t in batch.find_targets]
-    match_all_steps(wrapper, outputs.output, targets)
-    loss_dict = wrapper(outputs, targets)
-    loss_dict["core_loss"].backward()
-    out = outputs.output[0][0]
-    rec = {"outputs": {}, "loss_terms": {}, "grads_full": {}, "grads_sampled_worst": 0.0}
+    # the loop of train_sam3_lora_native.py:887-943: D.STEPS_FULL AdamW steps (the fixture's loss curve); everything else is judged on
+    # the first step
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.CONFIGS["full"][3], weight_decay=D.WD)
+    rec = {"outputs": {}, "loss_terms": {}, "grads_full": {}, "grads_sampled_worst": 0.0, "losses": []}
 
     def err(a, ref):
         a = a.detach().float().cpu().numpy()
@@ -684,49 +618,45 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None):
             a = a[::8]          # encoder states: every 8th token
         assert a.shape == ref.shape, (a.shape, ref.shape)
         return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12))
-    n_idx = 0
-    for k in gold.files:
-        if not k.startswith("lora/"):
-            continue
-        parts = k.split("/")[1:]
-        node = out
-        if parts[0].startswith("aux"):
-            node, parts = out["aux_outputs"][int(parts[0][3:])], parts[1:]
-        if parts[0] == "indices":
-            got = torch.stack([node["indices"][0], node["indices"][1]]).cpu().numpy()
-            same = bool(np.array_equal(got, gold[k]))
-            rec["indices_equal"] = rec.get("indices_equal", True) and same
-            name = "/".join(k.split("/")[1:-1]) or "final"
-            rec.setdefault("outputs_with_different_matching", []).extend([] if same else [name])
-            if not same:
-                # how much worse the REFERENCE's own cost matrix (its stored fp32 scores and boxes) rates this build's assignment
-                # than its optimum: a re-matching onto a near-tied assignment is rounding noise, onto any other one a defect
-                pre = "lora/" + ("" if name == "final" else name + "/")
-                Cr = matcher.cost_matrix(torch.tensor(gold[pre + "pred_logits"]).float().squeeze(-1), torch.tensor(gold[pre + "pred_boxes"]).float(),
-                                         torch.tensor(gold["batch/find_target/boxes_padded"]).float())[0].numpy()
-                cost = lambda idx: float(sum(Cr[q, t] for t, q in enumerate(idx[1])))     # indices[1]: query of target 0, 1, ...
-                Co = matcher.cost_matrix(node["pred_logits"].detach().float().cpu().squeeze(-1), node["pred_boxes"].detach().float().cpu(),
-                                         torch.tensor(gold["batch/find_target/boxes_padded"]).float())[0].numpy()
-                eps = float(np.abs(Co - Cr).max())
-                rec.setdefault("rematch_cost_gap", {})[name] = {"gap": cost(got) - cost(gold[k]), "eps": eps, "bound": 2.0 * Cr.shape[1] * eps}
-            n_idx += 1
-            continue
-        rec["outputs"]["/".join(k.split("/")[1:])] = err(node[parts[0]], gold[k])
-    assert n_idx == 6
-    for k in gold.files:
-        if k.startswith("loss/") and "ce_f1" not in k and "acc" not in k:
-            ref = float(gold[k])
-            rec["loss_terms"][k[5:]] = abs(float(loss_dict[k[5:]]) - ref) / max(abs(ref), 1e-3)
-    for n_, mod in layers.items():
-        if f"gA/{n_}" in gold.files:
-            rec["grads_full"][n_] = max(_rel(mod.lora_A.grad, gold[f"gA/{n_}"]), _rel(mod.lora_B.grad, gold[f"gB/{n_}"]))
-        else:
-            for g_, key in ((mod.lora_A.grad, "gA"), (mod.lora_B.grad, "gB")):
-                got = g_.detach().float().flatten()[::D.FULL_GRAD_SAMPLE].cpu().numpy()
-                e = float(np.abs(got - gold[f"{key}s/{n_}"]).max() / max(float(gold[f"{key}max/{n_}"]), 1e-30))
-                rec["grads_sampled_worst"] = max(rec["grads_sampled_worst"], e)
+    for step in range(steps if steps is not None else D.STEPS_FULL):
+        outputs = model(batch)
+        targets = [model.back_convert(t) for t in batch.find_targets]
+        match_all_steps(wrapper, outputs.output, targets)
+        loss_dict = wrapper(outputs, targets)
+        opt.zero_grad()
+        loss_dict["core_loss"].backward()
+        rec["losses"].append(float(loss_dict["core_loss"]))
+        if step == 0:
+            out = outputs.output[0][0]
+            rec["decisions_differing"], rec["decisions_compared"] = _decisions(out, gold)
+            rec["indices_equal"] = not rec["decisions_differing"]
+            for k in gold.files:
+                if not k.startswith("lora/") or k.endswith(("indices", "indices_o2m")):
+                    continue
+                parts = k.split("/")[1:]
+                node = out
+                if parts[0].startswith("aux"):
+                    node, parts = out["aux_outputs"][int(parts[0][3:])], parts[1:]
+                rec["outputs"]["/".join(k.split("/")[1:])] = err(node[parts[0]], gold[k])
+            for k in gold.files:
+                if k.startswith("loss/") and "ce_f1" not in k and "acc" not in k:
+                    ref = float(gold[k])
+                    rec["loss_terms"][k[5:]] = abs(float(loss_dict[k[5:]]) - ref) / max(abs(ref), 1e-3)
+            for n_, mod in layers.items():
+                if f"gA/{n_}" in gold.files:
+                    rec["grads_full"][n_] = max(_rel(mod.lora_A.grad, gold[f"gA/{n_}"]), _rel(mod.lora_B.grad, gold[f"gB/{n_}"]))
+                else:
+                    for g_, key in ((mod.lora_A.grad, "gA"), (mod.lora_B.grad, "gB")):
+                        got = g_.detach().float().flatten()[::D.FULL_GRAD_SAMPLE].cpu().numpy()
+                        e = float(np.abs(got - gold[f"{key}s/{n_}"]).max() / max(float(gold[f"{key}max/{n_}"]), 1e-30))
+                        rec["grads_sampled_worst"] = max(rec["grads_sampled_worst"], e)
+            del out
+        del outputs, loss_dict
+        opt.step()
+    ref_curve = gold["losses"][:len(rec["losses"])]
+    rec["loss_curve_rel"] = [float(v) for v in np.abs(np.array(rec["losses"]) - ref_curve) / np.abs(ref_curve)]
     rec["peak_mem_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
-    assert len(rec["grads_full"]) == 4 and len(rec["outputs"]) >= 40
+    assert rec["decisions_compared"] == 12 and len(rec["grads_full"]) == 4 and len(rec["outputs"]) >= 40
     return rec
 
 
@@ -734,69 +664,60 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None):
 @pytest.mark.timeout(1500)
 def test_full_size_training_step_fp32_matches_reference():
     """e2e_full.npz through the exact-fp32 HIP adapters: north_star's 1e-3 on every output's logits / boxes / masks, every loss
-    term, matcher indices of the final and the five auxiliary outputs bit-exact, the A/B gradients of all 64 adapters."""
+    term, all 12 decisions of the first step (Hungarian indices of the final + 5 auxiliary outputs and of the 5 auxiliary twins, the
+    final twin's threshold matches) bit-exact, the A/B gradients of all 64 adapters, and the loss curve over D.STEPS_FULL AdamW steps
+    (train_sam3_lora_native.py:887-943 at depth 32 / 1008^2) within 1e-3."""
     rec = _full_size_step("fp32")
     _record("full_fp32", rec)
-    assert rec["indices_equal"]
+    assert rec["indices_equal"], rec["decisions_differing"]
     assert max(rec["outputs"].values()) <= 1e-3, rec["outputs"]
     assert max(rec["loss_terms"].values()) <= 1e-3, rec["loss_terms"]
     assert max(rec["grads_full"].values()) <= 5e-3 and rec["grads_sampled_worst"] <= 5e-3, (rec["grads_full"], rec["grads_sampled_worst"])
+    assert len(rec["losses"]) == D.STEPS_FULL and max(rec["loss_curve_rel"]) <= 1e-3, (rec["losses"], rec["loss_curve_rel"])
+
+
+def _full_bf16_verdict(rec, yard):
+    """The bars of the benchmarked layout at the benchmarked size (shared with bench.py's parity gate): every one of the 12 decisions
+    as the reference's fp32 run takes it; first-step total and every step of the loss curve within BF16_CURVE_BAR; worst A/B gradient
+    (4 adapters in full, 60 sampled) within twice this build's measured figure; logits / boxes / presence within the reference's own
+    autocast(bf16) deviation at this size (the largest of three image samples), masks within twice it (the mask head stays bf16)."""
+    cls = lambda suffix: max(v for k, v in rec["outputs"].items() if k.endswith(suffix))
+    sm = {"pred_logits": cls("pred_logits"), "pred_boxes": cls("pred_boxes"), "presence_logit_dec": cls("presence_logit_dec"),
+          "pred_masks": cls("pred_masks"), "core_loss": rec["loss_terms"]["core_loss"],
+          "worst_AB_grad": max(max(rec["grads_full"].values()), rec["grads_sampled_worst"]),
+          "decisions_differing": list(rec["decisions_differing"]), "decisions_compared": rec["decisions_compared"],
+          "loss_curve_rel": list(rec["loss_curve_rel"])}
+    checks = {"decisions": not sm["decisions_differing"],
+              "pred_logits": sm["pred_logits"] <= yard["pred_logits"], "pred_boxes": sm["pred_boxes"] <= yard["pred_boxes"],
+              "presence_logit_dec": sm["presence_logit_dec"] <= yard["presence_logit_dec"], "pred_masks": sm["pred_masks"] <= 2.0 * yard["pred_masks"],
+              "core_loss": sm["core_loss"] <= BF16_CURVE_BAR, "loss_curve": max(sm["loss_curve_rel"]) <= BF16_CURVE_BAR,
+              "AB_grad": sm["worst_AB_grad"] <= 2.0 * BF16_GRAD_MEASURED["full"]}
+    return sm, checks
 
 
 @pytest.mark.gpu
 @pytest.mark.timeout(1500)
 def test_full_size_training_step_bf16_layout_against_reference():
     """The configuration bench.py TIMES (depth 32, 1024 wide, 1008^2; bf16 layout + fp32 islands + fused fc1 + hi / lo operands)
-    against the reference's fp32 CPU step at that size (e2e_full.npz).  The bar is the reference's OWN mixed-precision mode at
-    the same size -- its model under torch.autocast(bf16), ``sam3_lora/train/native_trainer.py:992``, against its fp32 run:
-    ref_autocast_bf16.json["full"], written by ``make_e2e_golden.py full --yardstick`` (logits 3.5e-2, boxes 5.3e-2, presence
-    1.6e-2, masks 2.8e-2, loss 1.5e-2, A/B gradients worst 0.26 / median 0.13 over the 64 adapters; and its matching
-    differs from its own fp32 forward's in 1 of the 6 outputs).  The loss, the worst A/B gradient and the number of re-matched outputs
-    within 1.0x of that yardstick, logits / boxes / presence within 1.5x (run-to-run spread of both sides, below), masks 2x; the
-    exact-fp32 layout (the test above) is the one that is bit-exact and meets north_star's 1e-3."""
+    against the reference's fp32 CPU steps at that size (e2e_full.npz), held strictly (_full_bf16_verdict): the fixture's boxes leave
+    every decision a margin (Hungarian gap >= 0.99, one-to-many 0.13: e2e_boxes.json), so all 12 decisions must be the reference's, and
+    then loss, curve and gradients are numbers of the SAME assignment.  The output tensors themselves are bf16 quantities: their bar is
+    the reference's own mixed-precision mode at this size (its model under torch.autocast(bf16), native_trainer.py:992, against its
+    fp32 run on three images: ref_autocast_bf16.json["full"]).  north_star's 1e-3 on the logits is the exact-fp32 layout's (above)."""
     rec = _full_size_step("bf16")
     yard = _yardstick("full")
     rec["reference_autocast_bf16_vs_its_fp32"] = yard
-    cls = lambda suffix: max(v for k, v in rec["outputs"].items() if k.endswith(suffix))
-    rec["summary"] = {"pred_logits": cls("pred_logits"), "pred_boxes": cls("pred_boxes"), "presence_logit_dec": cls("presence_logit_dec"),
-                      "pred_masks": cls("pred_masks"), "core_loss": rec["loss_terms"]["core_loss"],
-                      "worst_AB_grad_full4": max(rec["grads_full"].values()), "worst_AB_grad_sampled60": rec["grads_sampled_worst"]}
+    rec["summary"], checks = _full_bf16_verdict(rec, yard)
     _record("full_bf16", rec)
-    # the assignment: the reference's own autocast forward re-matches `outputs_with_different_matching` of its 6 outputs at this size
-    # (1).  Which ones CAN flip is a property of the fixture: by the reference's own fp32 cost matrices three of the six outputs (final,
-    # aux2, aux4) have FIVE further assignments within 0.010-0.05 of the optimum (total cost ~15), the other three outputs none
-    # within 0.15-0.27.  A re-matched output is accepted when this run's own cost deviation explains it (_rematch_explained: the
-    # reference's cost matrix rates this build's assignment at most 2 T eps above its optimum); seen: aux2 with gaps 0.041 (twice)
-    # and 0.114 (boxes 5.3e-2 off in that run), otherwise none.
-    assert _rematch_explained(rec.get("rematch_cost_gap", {})), rec["rematch_cost_gap"]
-    sm = rec["summary"]
-    # Bars: FULL_BF16_SLACK x the yardstick (masks 2 x: the mask head stays bf16).  Both sides are single samples of a chaotic quantity --
-    # the frozen GEMMs' stream-K reductions are not bit-stable, and a 1e-3 move near a tie re-matches a query: five runs of this test on
-    # MI355X gave logits 3.07 / 3.36 / 3.38 / 3.39 / 3.64e-2 (yardstick 3.50e-2), boxes 3.9 - 5.0e-2 (5.27e-2), presence
-    # 1.04 / 1.19 / 1.69 / 1.77 / 1.91e-2 (1.59e-2), masks 3.3 - 3.4e-2 (2.82e-2), loss 2e-5 - 4.5e-3 (1.5e-2), worst A/B gradient
-    # 0.107 - 0.120 (0.265), 0 - 1 re-matched outputs (1): profiles/r05*_parity_full_bf16*.json.
-    S = FULL_BF16_SLACK
-    assert sm["pred_logits"] <= S * yard["pred_logits"], (sm, yard)
-    assert sm["pred_boxes"] <= S * yard["pred_boxes"], (sm, yard)
-    assert sm["presence_logit_dec"] <= S * yard["presence_logit_dec"], (sm, yard)
-    assert sm["pred_masks"] <= 2.0 * yard["pred_masks"], (sm, yard)
-    assert sm["core_loss"] <= max(yard["core_loss"], 1e-3), (sm, yard)
-    assert max(sm["worst_AB_grad_full4"], sm["worst_AB_grad_sampled60"]) <= yard["worst_AB_grad"], (sm, yard)
+    assert all(checks.values()), (checks, rec["summary"], yard)
 
 
 # bf16 layout (frozen tensors and activations bf16, A/B fp32; the DETR decoder + scoring head stay fp32 -- vit.DEFAULT_FP32_ISLANDS;
-# what bench.py runs) against the reference's fp32 CPU run.  The bar is the reference's OWN mixed-precision mode: its model under
-# torch.autocast(bf16) against its fp32 run (tests/golden/ref_autocast_bf16.json, written by make_e2e_golden.py --yardstick:
-# tiny / wide logits 8.8e-3 / 1.8e-2, boxes 8.2e-4 / 8.3e-3, presence logit 1.7e-2 / 8.4e-3, masks 2.1e-2 / 2.5e-2, loss 1.4e-4 /
-# 4.4e-2, worst A/B gradient 0.175 / 0.54).  Every asserted quantity must be within 1.0x of that yardstick (masks 2x: the mask
-# head stays bf16 -- in fp32 it would cost more than the whole adapter path; gradients 1.25x on `tiny`, where this build sits at
-# 0.9x and the frozen GEMMs' stream-K reductions move it by a few per cent run to run).  Measured on MI355X
-# (profiles/r04e_bf16_islands.json): logits 6.5e-3 / 8.6e-3, boxes 2.4e-4 / 1.8e-3, presence 5.6e-3 / 2.3e-3, masks 3.1e-2 / 2.3e-2,
-# loss 7e-6 / 2.1e-3, gradients 0.156 / 0.085; with everything in bf16 (round 3): 1.6e-2 / 1.5e-2, 1.1e-3 / 1.2e-2, 5.5e-2 / 2.3e-2.
-# The A/B gradients are far more sensitive than the outputs in EVERY implementation (the reference's own autocast: 17 % / 54 %):
-# the loss is non-smooth (L1 sign, ReLU gates, GIoU branches, the assignment itself), so a 1e-3 move of a box flips gradient
-# components.  north_star's 1e-3 on the logits is met by the fp32 layout (measured 9e-7,
-# test_wide_training_step_fp32_matches_reference).
+# what bench.py runs) against the reference's fp32 CPU run: _assert_bf16_layout_step above.  The output tensors' bar is the reference's
+# OWN mixed-precision mode -- its model under torch.autocast(bf16) against its fp32 run on three images
+# (tests/golden/ref_autocast_bf16.json, written by make_e2e_golden.py <case> --yardstick; each key = the largest of the samples) --
+# because a bf16 forward cannot be closer to an fp32 one than bf16 arithmetic allows; decisions, loss, curve and gradients are held to
+# fixed bars.  north_star's 1e-3 on the logits is met by the fp32 layout (test_wide_training_step_fp32_matches_reference).
 def _yardstick(which):
     import json
     return json.load(open(os.path.join(os.path.dirname(GOLD), "ref_autocast_bf16.json")))[which]
@@ -805,9 +726,9 @@ def _yardstick(which):
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["tiny", "wide"])
 def test_bf16_training_layout_against_reference(which, gold, gold_wide):
-    """The benchmark's layout: pred_logits / pred_boxes of the final and auxiliary outputs, the presence logit, the masks, the
-    loss, the loss curve AND the A/B gradients against the reference's fp32 run, each bounded by the reference's own
-    autocast(bf16) deviation; matcher indices of the first step identical."""
+    """The benchmark's layout: pred_logits / pred_boxes of the final and auxiliary outputs, the presence logit and the masks within the
+    reference's own autocast(bf16) deviation; every decision of the first step (Hungarian and one-to-many) identical to the reference's;
+    first-step loss and the four-step curve within 1e-2; A/B gradients within twice this build's measured deviation."""
     from sam3_lora_amd.trainer import move_to_device
     from sam3_lora_amd.vit import DEFAULT_FP32_ISLANDS, to_training_layout
     dev = torch.device("cuda")
@@ -834,28 +755,8 @@ def test_bf16_training_layout_against_reference(which, gold, gold_wide):
     assert out["pred_masks"].dtype == torch.bfloat16 and out["encoder_hidden_states"].dtype == torch.bfloat16
     # scores and boxes leave in fp32 (matcher cost, box losses)
     assert out["pred_logits"].dtype == out["pred_boxes"].dtype == out["presence_logit_dec"].dtype == torch.float32
-    logit_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_logits"))
-    box_err = max(v for k, v in m["outputs"].items() if k.endswith("pred_boxes"))
-    assert logit_err <= yard["pred_logits"], (logit_err, yard)
-    assert box_err <= yard["pred_boxes"], (box_err, yard)
-    assert m["outputs"]["presence_logit_dec"] <= yard["presence_logit_dec"], (m["outputs"], yard)
-    assert m["outputs"]["pred_masks"] <= 2.0 * yard["pred_masks"], (m["outputs"], yard)
-    # the assignment: the reference's, or one that this run's own cost deviation explains (_rematch_explained; the wide fixture's
-    # second image has a second-best assignment 0.017 away).  With a re-matched output the loss and the gradients
-    # belong to another assignment: what does not depend on it has been checked above, the loss curve from the second step on below.
-    assert _rematch_explained(m["rematch_cost_gap"]), m["rematch_cost_gap"]
-    if m["rematch_cost_gap"]:
-        assert not m["indices_equal"] or "final" not in m["rematch_cost_gap"]
-        assert all(np.isfinite(m["losses"])) and max(m["loss_curve_rel"][1:]) <= 0.05, (m["losses"], m["loss_curve_rel"])
-        return
-    assert m["indices_equal"]
-    same_o2m = _assert_first_step_loss(m, max(yard["core_loss"], 1e-3), which)
-    assert max(m["loss_curve_rel"][0 if same_o2m else 1:]) <= max(yard["core_loss"], 3e-3), (m["losses"], m["loss_curve_rel"])
     assert len(m["grads"]) >= 6
-    # A/B gradients: never beyond the reference's own autocast deviation, and within twice what this build has measured on the
-    # fixture (worst adapter 0.155 tiny / 0.146 wide, profiles/r05s_parity_bf16_*.json; the wide yardstick alone -- 0.54 -- would
-    # let a real regression pass)
-    assert max(m["grads"].values()) <= min(1.25 * yard["worst_AB_grad"], 0.30), (m["grads"], yard)
+    _assert_bf16_layout_step(m, yard, which)
 
 
 @pytest.mark.gpu
@@ -972,38 +873,57 @@ def test_training_layout_islands_and_holes_on_cpu(gold):
     assert model._sam3_layout_hooks == [] and all(p.dtype == torch.bfloat16 for p in model.parameters() if not p.requires_grad)
 
 
-def test_assignment_reports_on_the_references_own_data():
-    """No GPU: the two reports the bf16-layout tests judge assignments with, fed the reference's stored outputs.  The reference's
-    own Hungarian indices give no re-matched output; moving one target to another query gives that output with a positive cost gap.
-    The one-to-many report re-derives the reference's threshold decisions: equal on them; dropping the minimal-r4 fixture's single
-    match (score 0.4002 against the threshold 0.4) is a fragile flip; adding a pair that scores far below the threshold is not."""
-    batch = make_batch_wide()
-    g = np.load(os.path.join(os.path.dirname(GOLD), "e2e_wide.npz"))
+@pytest.mark.parametrize("case", ["tiny", "wide", "wide_large_r32", "wide_minimal_r4", "full"])
+def test_fixture_decisions_have_margins(case):
+    """No GPU: every committed whole-step fixture takes each of its discrete decisions with a margin, re-derived here from the
+    reference's STORED fp32 outputs with this library's cost expressions (matcher.cost_matrix; the one-to-many score
+    ``alpha p + (1 - alpha) IoU``): every Hungarian optimum (final, auxiliary outputs, auxiliary twins) beats the best assignment
+    that differs from it by >= margins.HUNGARIAN_MARGIN, no one-to-many score of the final twin lies within margins.O2M_MARGIN of the
+    decision it hangs on, and at least one fixture pair is a one-to-many positive (so the *_o2m terms are exercised).  The numbers
+    agree with the ones the generator computed on the reference's own cost matrices (``margins`` row 0)."""
+    import margins as MG
+    from sam3_lora_amd.losses import box_cxcywh_to_xyxy, box_iou
+    g = np.load(os.path.join(os.path.dirname(GOLD), f"e2e_{case}.npz"))
+    matcher, wrapper = _criterion()
+    tgt = torch.tensor(g["batch/find_target/boxes_padded"]).float()
+    nb = [int(v) for v in g["batch/find_target/num_boxes"]]
+    hung = float("inf")
+    n_dec = 0
+    for pre in ["lora/"] + [f"lora/aux{i}/" for i in range(8) if f"lora/aux{i}/pred_logits" in g.files]:
+        for tw in ("", "_o2m"):
+            if pre == "lora/" and tw:
+                continue
+            C = matcher.cost_matrix(torch.tensor(g[pre + "pred_logits" + tw]).float().squeeze(-1), torch.tensor(g[pre + "pred_boxes" + tw]).float(), tgt).numpy()
+            for b, n in enumerate(nb):
+                if n:
+                    hung = min(hung, MG.lsap_gap(C[b, :, :n])[1])
+            n_dec += 1
+    om = wrapper.o2m_matcher
+    prob = torch.tensor(g["lora/pred_logits_o2m"]).float().sigmoid().squeeze(-1)
+    iou, _ = box_iou(box_cxcywh_to_xyxy(torch.tensor(g["lora/pred_boxes_o2m"]).float()), box_cxcywh_to_xyxy(tgt))
+    score = (om.alpha * prob.unsqueeze(-1) + (1 - om.alpha) * iou).numpy()
+    o2m, positives = MG.o2m_margin(score, nb, om.threshold, om.topk)
+    assert n_dec == 2 * len([k for k in g.files if k.endswith("/pred_logits") and k.startswith("lora/aux")]) + 1
+    assert hung >= MG.HUNGARIAN_MARGIN and o2m >= MG.O2M_MARGIN and positives >= 1, (case, hung, o2m, positives)
+    stored = g["margins"]
+    assert abs(stored[0][0] - hung) <= 1e-3 * max(1.0, hung) and abs(stored[0][1] - o2m) <= 1e-4 and int(stored[0][2]) == positives, (stored[0], hung, o2m, positives)
+    # the later steps of the curve stay clear of ties as well (half the first step's bar; asserted by the generator, stored per step)
+    assert (stored[:, 0] >= 0.5 * MG.HUNGARIAN_MARGIN).all() and (stored[:, 1] >= 0.5 * MG.O2M_MARGIN).all(), stored
+    # the stored one-to-many matches are the positives counted here
+    assert g["lora/indices_o2m"].shape == (3, positives)
 
-    def node(pre, change=None):
-        idx = g[pre + "indices"].copy()
-        if change:
-            idx[1][change[0]] = change[1]
-        return {"indices": (torch.tensor(idx[0]), torch.tensor(idx[1]))}
-    out = dict(node("lora/"), aux_outputs=[node("lora/aux0/"), node("lora/aux1/")])
-    assert _rematch_report(out, g, batch) == {}
-    out = dict(node("lora/", (2, 5)), aux_outputs=[node("lora/aux0/"), node("lora/aux1/", (0, 3))])
-    rep = _rematch_report(out, g, batch)          # (no outputs of a build in `out`: eps is unknown, nothing explains the difference)
-    assert set(rep) == {"final", "aux1"} and all(v["gap"] > 1.0 for v in rep.values()) and not _rematch_explained({"final": dict(rep["final"], bound=0.5)}), rep
-    # with the reference's own outputs as "the build's" there is no cost deviation: any difference is unexplained
-    as_out = lambda pre, nd: dict(nd, pred_logits=torch.tensor(g[pre + "pred_logits"]), pred_boxes=torch.tensor(g[pre + "pred_boxes"]))
-    out = dict(as_out("lora/", node("lora/", (2, 5))), aux_outputs=[as_out("lora/aux0/", node("lora/aux0/")), as_out("lora/aux1/", node("lora/aux1/"))])
-    rep = _rematch_report(out, g, batch)
-    assert set(rep) == {"final"} and rep["final"]["eps"] == 0.0 and not _rematch_explained(rep), rep
 
-    g4 = np.load(os.path.join(os.path.dirname(GOLD), "e2e_wide_minimal_r4.npz"))
-    nb = batch.find_targets[0].num_boxes
-    offs = torch.cat([torch.zeros(1, dtype=torch.long), nb.long().cumsum(-1)[:-1]])
-    as_indices = lambda pairs: tuple(torch.tensor(v, dtype=torch.long) for v in
-                                     ([b for b, _, _ in pairs], [q for _, q, _ in pairs], [t + int(offs[b]) for b, _, t in pairs]))
-    ref_pairs = [(1, 16, 0)]                                  # the reference's only one-to-many match of the final output
-    assert _o2m_report({"indices_o2m": as_indices(ref_pairs)}, g4, batch) == {"equal": True, "fragile_flip": False, "differing": []}
-    rep = _o2m_report({"indices_o2m": as_indices([])}, g4, batch)
-    assert not rep["equal"] and rep["fragile_flip"] and rep["differing"] == [(1, 16, 0, 0.4002)], rep
-    rep = _o2m_report({"indices_o2m": as_indices(ref_pairs + [(0, 3, 1)])}, g4, batch)
-    assert not rep["equal"] and not rep["fragile_flip"], rep
+def test_margin_arithmetic():
+    """tests/golden/margins.py on hand-made cases: the gap to the second-best assignment, and the one-to-many margin's two parts."""
+    import margins as MG
+    cost = np.array([[1.0, 5.0], [2.0, 1.5], [9.0, 9.0]])
+    best, gap = MG.lsap_gap(cost)                # optimum rows (0, 1) = 2.5; second best (1, 0)... = 2 + 5 = 7 or (0 -> col 0, 2 -> col 1) = 10
+    assert best == 2.5 and abs(gap - 4.5) < 1e-12
+    assert MG.lsap_gap(np.zeros((3, 0)))[1] == float("inf")
+    score = np.zeros((1, 6, 1))
+    score[0, :, 0] = [0.9, 0.8, 0.7, 0.6, 0.55, 0.1]
+    m, pos = MG.o2m_margin(score, [1], 0.4, 4)   # top-4 all above the threshold; the 5th (0.55) is above it too: its distance to the 4th counts
+    assert pos == 4 and abs(m - 0.05) < 1e-12
+    score[0, 4, 0] = 0.2
+    m, pos = MG.o2m_margin(score, [1], 0.4, 4)   # now only distances to the threshold count: 0.6 - 0.4
+    assert pos == 4 and abs(m - 0.2) < 1e-12

@@ -60,31 +60,23 @@ def main():
     torch.cuda.synchronize()
     rounds = {}
     variants = [("two_pass", two_pass, {}), ("gemm_only", gemm_only, {}),
-                ("fused_big", fused, {"SAM3_LORA_FUSED_TILE": "0"}), ("fused_pair", fused, {"SAM3_LORA_FUSED_TILE": "1"}),
-                ("fused_noact_big", fused_noact, {"SAM3_LORA_FUSED_TILE": "0"}),
-                ("fused_big_drained_tile_switch", fused, {"SAM3_LORA_FUSED_TILE": "0", "SAM3_LORA_FUSED_EARLY": "0"}),
-                ("fused_noact_big_drained_tile_switch", fused_noact, {"SAM3_LORA_FUSED_TILE": "0", "SAM3_LORA_FUSED_EARLY": "0"}),
-                ("fused_ring", fused, {"SAM3_LORA_FUSED_TILE": "2"}), ("fused_noact_ring", fused_noact, {"SAM3_LORA_FUSED_TILE": "2"}),
-                ("fused_big_last_column_as_full_tiles", fused, {"SAM3_LORA_FUSED_TILE": "0", "SAM3_LORA_FUSED_HALF": "0"}),
+                ("fused_big", fused, {}), ("fused_noact_big", fused_noact, {}),
+                ("fused_big_last_column_as_full_tiles", fused, {"SAM3_LORA_FUSED_HALF": "0"}),
                 # what bounds the kernel (fl::k_fused_linear's PROBE; outputs are garbage in these two):
                 ("PROBE_fill_only_gelu", fused, {"SAM3_LORA_FUSED_PROBE": "1"}), ("PROBE_fill_only_noact", fused_noact, {"SAM3_LORA_FUSED_PROBE": "1"}),
                 ("PROBE_mfma_only_gelu", fused, {"SAM3_LORA_FUSED_PROBE": "2"}), ("PROBE_mfma_only_noact", fused_noact, {"SAM3_LORA_FUSED_PROBE": "2"}),
                 ("PROBE_no_global_stores_gelu", fused, {"SAM3_LORA_FUSED_PROBE": "3"}), ("PROBE_no_global_stores_noact", fused_noact, {"SAM3_LORA_FUSED_PROBE": "3"}),
-                ("PROBE_no_gelu_arithmetic", fused, {"SAM3_LORA_FUSED_PROBE": "4"}),
-                ("PROBE_fill_only_noact_ring", fused_noact, {"SAM3_LORA_FUSED_PROBE": "1", "SAM3_LORA_FUSED_TILE": "2"}),
-                ("PROBE_mfma_only_noact_ring", fused_noact, {"SAM3_LORA_FUSED_PROBE": "2", "SAM3_LORA_FUSED_TILE": "2"})]
+                ("PROBE_no_gelu_arithmetic", fused, {"SAM3_LORA_FUSED_PROBE": "4"})]
     for r in range(5):
         for name, f, env in variants:
-            for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_FUSED_PROBE", "SAM3_LORA_FUSED_EARLY"):
+            for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_PROBE"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             lib.sam3_lora_debug_reload_knobs()
             f()
             rounds.setdefault(name, []).append(timed(f, 10))
-    for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_TILE", "SAM3_LORA_FUSED_PROBE", "SAM3_LORA_FUSED_EARLY"):
+    for k in ("SAM3_LORA_FUSED_WGS", "SAM3_LORA_FUSED_HALF", "SAM3_LORA_FUSED_PROBE"):
         os.environ.pop(k, None)
-    if os.environ.get("PROBE_TILE"):
-        os.environ["SAM3_LORA_FUSED_TILE"] = os.environ["PROBE_TILE"]
     lib.sam3_lora_debug_reload_knobs()
     out["us"] = {k: {"median": float(np.median(v)), "min": float(np.min(v)), "all": [round(t, 1) for t in v]} for k, v in rounds.items()}
     # in-situ split of the fused call and of the two-pass adapter call
