@@ -1306,6 +1306,9 @@ __global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long l
     // bytes per row -- one line per row, L2 hits): no divergent control flow around the loads, so that the waits stay counted.
     // The next step's loads are issued BEFORE the current step is consumed (sched_barrier pins that order: hipcc otherwise hoists
     // the first consumer above them and waits for the whole queue first).
+    // (Two steps ahead -- three register sets at one workgroup per CU, 128 KB per CU under way instead of 64 -- measured equal on MI355X,
+    // round 6: 73.2-73.4 us against 73.2-73.6 at N = 4736, 27.6-29.1 against 26.7-29.3 at N = 1024 (profiles/r06c_sweep_t3w_depth.json):
+    // this pass is not short of outstanding loads.)
     Regs rA, rB;
     gload(0, rA);
     for (int s = 0; s < nst; s += 2) {

@@ -76,6 +76,7 @@ def main():
         for m in deep.modules():
             if isinstance(m, L.LoRALayer):
                 m.lora_B.normal_(0, 0.05)
+    deep.to(dev)                        # (the adapters are created on the CPU by the wrapper)
     dparams = [p for p in deep.parameters() if p.requires_grad]
     dred = LoRAGradReducer(dparams, bucket_bytes=128 << 10, run_collectives_alone=True)
     xd = torch.randn(40000, 512, device=dev)
