@@ -1087,6 +1087,7 @@ def main():
         if (not args.no_literal and args.rank == 16 and args.dropout == 0.0 and not args.fp8_frozen and args.act_dtype == "bf16"
                 and args.model == "sam3"):
             # the reference's SHIPPED default (configs/full_lora_config.yaml:12-14: rank 32, alpha 64, dropout 0.1) on the same workload
+            torch.cuda.reset_peak_memory_stats(dev)         # (its own peak, not the maximum over the sub-measurements before it)
             lit = FullStep(dev, args.batch, 32, world, rank, dropout=0.1, act_checkpoint=args.act_checkpoint,
                            match_once=not args.match_twice, bf16=True, kind=args.model)
             for _ in range(2):
@@ -1100,14 +1101,16 @@ def main():
                     "rank": 32, "alpha": 64, "dropout": 0.1, "vs_r16_line": round(v / out["value"], 4),
                     "finite": bool(torch.isfinite(lit.last_loss).item()), "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                     "what": "the same whole training step at configs/full_lora_config.yaml's literal adapter settings (r = 32, alpha = 64, "
-                            "LoRA dropout 0.1 generated inside the kernels): hi + lo operand images as at r = 16 (64-wide), two-pass "
-                            "backward, fc1 + GELU through sam3_lora_linear_fwd"}
+                            "LoRA dropout 0.1 generated inside the kernels): hi + lo operand images as at r = 16 (64-wide), one pass over gy "
+                            "(k_t3w with two rank tiles), fc2's input recomputed -- and masked -- inside the GELU' pass (not kept), fc1 + GELU "
+                            "through sam3_lora_linear_fwd"}
             del lit
             torch.cuda.empty_cache()
         if (not args.no_fp32_layout and not args.fp8_frozen and args.act_dtype == "bf16" and args.model == "sam3" and world == 1):
             # the layout that MEETS north_star's 1e-3 on the logits (fp32 frozen tensors and activations, exact-fp32 adapter kernels:
             # tests/test_sam3_e2e.py::test_full_size_training_step_fp32_matches_reference, 1.3e-5 at full size), timed beside the bf16 one
             try:
+                torch.cuda.reset_peak_memory_stats(dev)
                 f32 = FullStep(dev, args.batch, args.rank, world, rank, dropout=args.dropout, act_checkpoint=args.act_checkpoint,
                                match_once=not args.match_twice, bf16=False, kind=args.model)
                 f32.step()

@@ -155,8 +155,9 @@ int sam3_lora_bwd(const void* gy, const void* x, const void* tT_saved, const voi
  * sam3_lora_bwd_act with x == NULL: "this layer's input IS act(pre_act)" (what sam3_lora_fwd_act wrote as act_out).  The pass
  * that applies act'(pre_act) then also recomputes act(pre_act) tile by tile and contracts it with gt for gA -- the second full
  * read of the stored activation (e * M * in bytes) disappears and the caller need not keep the activation for the backward.
- * Needs tT_saved, gx_inout, and sam3_lora_bwd_act_recomputes_input(rank, dtype, drop_p) != 0 (bf16 hi + lo kernels: rank <= 16,
- * no dropout; also in sam3_lora_bwd_act_q8); gA then differs from the x-given form only in summation order (fp32, <= 1e-6 relative).
+ * Needs tT_saved, gx_inout, and sam3_lora_bwd_act_recomputes_input(rank, dtype, drop_p) != 0 (bf16 hi + lo kernels, one rank group:
+ * rank <= 32, with or without dropout -- the recomputed tile is masked with the keep bits the pass draws for gx anyway; in
+ * sam3_lora_bwd_act_q8: rank <= 16 without dropout); gA then differs from the x-given form only in summation order (fp32, <= 1e-6 relative).
  */
 int sam3_lora_bwd_act_recomputes_input(int rank, int dtype, float drop_p);
 #define SAM3_LORA_ACT_NONE 0

@@ -539,7 +539,15 @@ struct YTile<bf16_t> {
             o.w = pack2(bf_lo(v[p].w) + scale * b[2], bf_hi(v[p].w) + scale * b[3]);
             const bool ok = FAST || (m < M && col < N);
             if (ACT == 2) o = act8(o, haux.v[p], 2);
-            if (ACT == 2 && GA) atile[rl * 16 + ((lane & 15) ^ (t3_h(rl) << 1))] = act8(haux.v[p], haux.v[p], 1);   // (zeros beyond M / N: h loads as 0)
+            if (ACT == 2 && GA) {       // (zeros beyond M / N: h loads as 0); under dropout the layer's input was drop(act(h)): the same keep bits
+                uint4 av = act8(haux.v[p], haux.v[p], 1);
+                if (DROP) {
+                    const unsigned kb = keep8((unsigned long long)m * dk.width + col, dk);
+                    auto km = [&](int j) { return ((kb >> (2 * j)) & 1u ? 0xffffu : 0u) | ((kb >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u); };
+                    av = make_uint4(av.x & km(0), av.y & km(1), av.z & km(2), av.w & km(3));
+                }
+                atile[rl * 16 + ((lane & 15) ^ (t3_h(rl) << 1))] = av;
+            }
             if (ok) stg16(Y + m * ldy + col, o);
             uint4 a8 = o;
             if (ACT == 1) {
@@ -614,11 +622,12 @@ struct GaEmit {
     float* part;            // [row blocks][16][N]
 };
 template <typename YT, int RT, bool DROP, int ACT = 0, bool HL = false, bool Q8 = false, int QF = 0, bool GA = false>
-__global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && !DROP) ? (ACT == 2 ? (GA ? 2 : 3) : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
+__global__ __launch_bounds__(256, GA ? 2 : (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && !DROP) ? (ACT == 2 ? 3 : 4) : 1) void k_t2(YT* __restrict__ Y, long long ldy, const bf16_t* __restrict__ T,
                                             const bf16_t* __restrict__ W2t, long long M, int N, float scale,
                                             int tiles_per_wg, DropKey dk, YT* __restrict__ AUX, long long ldaux,
                                             ReduceRide ride, Q8Out q8, int xcd_order, GaEmit ga) {
-    static_assert(!GA || (ACT == 2 && HL && RT == 2 && !DROP && sizeof(YT) == 2), "the in-pass gA contraction: GELU' pass of the hi + lo kernels, r <= 16");
+    static_assert(!GA || (ACT == 2 && HL && (RT == 2 || RT == 4) && sizeof(YT) == 2), "the in-pass gA contraction: GELU' pass of the hi + lo kernels, r <= 32");
+    static_assert(!(GA && Q8) || (RT == 2 && !DROP), "the fp8 image rides on the r <= 16 form without a mask");
     static_assert(!Q8 || ACT != 0, "the fp8 image is the one of the activation-fused passes");
     static_assert(!HL || RT == 2 || RT == 4, "hi + lo operands: RT / 2 rank tiles, each as [hi 4 | lo 4] per 4 rank indices");
     constexpr int RH = HL ? RT / 2 : 1;         // hi + lo: rank tiles (r <= 16: 1, r <= 32: 2)
@@ -735,15 +744,23 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
     // GA: gt fragment of a 16-row tile as the K = 32 A-operand [hi rows 0..15 | lo rows 0..15] (lane (n, g): K slots 8 g .. 8 g + 7),
     // gathered from the 32-row-step image; the B-operand [act(h) rows 0..15 twice] comes from `atile` by transpose reads
     uint4* atile = atile_all[GA ? wave : 0];
-    f32x4 gacc[GA ? 8 : 1];
+    f32x4 gacc[GA ? RH : 1][GA ? 8 : 1];
     if (GA) {
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) gacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < RH; ++tt)
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) gacc[tt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    auto load_gt = [&](long long t) -> uint4 {
-        return *reinterpret_cast<const uint4*>(ga.GTTf + ((((t >> 1) * 2 + (g >> 1)) * 4 + (int)(t & 1) * 2 + (g & 1)) * 16 + n) * 8);
+    struct GtFrag { uint4 v[GA ? RH : 1]; };
+    // fragment-major image of gt (store_t4_hl<RH>): per 32-row step 2 RH blocks [hi tiles 0..RH-1 | lo tiles 0..RH-1] of 4 x 16 x 8
+    auto load_gt = [&](long long t) -> GtFrag {
+        GtFrag f;
+#pragma unroll
+        for (int tt = 0; tt < (GA ? RH : 1); ++tt)
+            f.v[tt] = *reinterpret_cast<const uint4*>(ga.GTTf + ((((t >> 1) * (2 * RH) + (g >> 1) * RH + tt) * 4 + (int)(t & 1) * 2 + (g & 1)) * 16 + n) * 8);
+        return f;
     };
-    auto ga_accumulate = [&](const uint4& gf) {
+    auto ga_accumulate = [&](const GtFrag& gf) {
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         const char* base = reinterpret_cast<const char*>(atile);
@@ -757,8 +774,10 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
             const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             // D[i = rank idx][n = column] += sum_row (gt_hi + gt_lo)[row][i] * act(h)[row][col]
-            gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf), __builtin_bit_cast(bf16x8, both),
-                                                              gacc[ct], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < (GA ? RH : 1); ++tt)
+                gacc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf.v[tt]), __builtin_bit_cast(bf16x8, both),
+                                                                      gacc[tt][ct], 0, 0, 0);
         }
     };
     const bool colfull = c0 + CW <= N;
@@ -770,7 +789,7 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
         // at N = 4736, profiles/r03j_adapter_sweep.json: this stream is not short of outstanding loads.)
         YTile<YT> cur, nxt, hcur, hnxt;      // hcur/hnxt: the pre-activation tile (ACT == 2 only)
         uint2 tlo, thi, nlo, nhi;
-        uint4 gfc = make_uint4(0u, 0u, 0u, 0u), gfn = gfc;
+        GtFrag gfc{}, gfn{};
         load_t(t, nlo, nhi);
         if (GA) gfn = load_gt(t);
         nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
@@ -810,21 +829,24 @@ __global__ __launch_bounds__(256, (HL && RT == 4) ? (ACT == 1 ? 2 : 3) : (HL && 
     if (Q8) q8_end_wave(q8, q8_seen16_to_float(seen), q8_id, qs.have);
     if (GA) {   // fixed-order cross-wave sum ((w0 + w1) + w2) + w3 through LDS, as k_t3; wave w writes column tiles 2w, 2w + 1
         float* red = &slab_all[0][0];           // [4 waves][8 col tiles][64 lanes][4] floats = 32 KB of the 33 KB slab area
-        float* out = ga.part + (long long)by * 16 * N;
-        __syncthreads();
+        float* out = ga.part + (long long)by * (16 * RH) * N;       // one rank tile at a time through the same area
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) *reinterpret_cast<f32x4*>(red + ((wave * 8 + ct) * 64 + lane) * 4) = gacc[ct];
-        __syncthreads();
+        for (int tt = 0; tt < RH; ++tt) {
+            __syncthreads();
 #pragma unroll
-        for (int jc = 0; jc < 2; ++jc) {
-            const int ct = wave * 2 + jc;
-            f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ((0 * 8 + ct) * 64 + lane) * 4);
+            for (int ct = 0; ct < 8; ++ct) *reinterpret_cast<f32x4*>(red + ((wave * 8 + ct) * 64 + lane) * 4) = gacc[tt][ct];
+            __syncthreads();
 #pragma unroll
-            for (int w = 1; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 8 + ct) * 64 + lane) * 4);
-            const int ocol = c0 + ct * 16 + n;
-            if (ocol < N) {
+            for (int jc = 0; jc < 2; ++jc) {
+                const int ct = wave * 2 + jc;
+                f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ((0 * 8 + ct) * 64 + lane) * 4);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = s4[jj];
+                for (int w = 1; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(red + ((w * 8 + ct) * 64 + lane) * 4);
+                const int ocol = c0 + ct * 16 + n;
+                if (ocol < N) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) out[(long long)(tt * 16 + g * 4 + jj) * N + ocol] = s4[jj];
+                }
             }
         }
     }
@@ -1154,17 +1176,18 @@ __global__ __launch_bounds__(256) void k_t3e(const XT* __restrict__ X, long long
 // gt = sum over column pairs (fixed order) of the fp32 partials k_t3e wrote -> bf16 T[Mp, 16] row-major
 // (k_t2's operand) and TTf fragment-major (k_t3's operand), exactly the two images k_t1 would have produced.
 // ------------------------------------------------------------------------------------------
-template <bool HL>
+template <bool HL, int RH = 1>
 __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP, int nchunks, bf16_t* __restrict__ T,
                                                    bf16_t* __restrict__ TTf, long long Mp) {
+    static_assert(RH == 1 || HL, "two rank tiles: the hi + lo images of r <= 32 (k_t3w<RH = 2>)");
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 4 consecutive rank entries
-    if (idx >= Mp * 4) return;
-    const long long m = idx >> 2;
-    const int r0 = (int)(idx & 3) * 4;
+    if (idx >= Mp * 4 * RH) return;
+    const long long m = idx / (4 * RH);
+    const int r0 = (int)(idx % (4 * RH)) * 4;
     f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < nchunks; ++c)
-        s4 += __builtin_bit_cast(f32x4, ldg16(GTP + ((long long)c * Mp + m) * 16 + r0));
-    if (HL) store_t4_hl<1>(T, TTf, m, 0, r0, s4);
+        s4 += __builtin_bit_cast(f32x4, ldg16(GTP + ((long long)c * Mp + m) * (16 * RH) + r0));
+    if (HL) store_t4_hl<RH>(T, TTf, m, r0 >> 4, r0 & 15, s4);
     else store_t4<1>(T, TTf, m, 0, r0, pack2(s4[0], s4[1]), pack2(s4[2], s4[3]));
 }
 
@@ -1186,14 +1209,18 @@ __device__ __forceinline__ void lds_barrier() {     // workgroup barrier that or
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename XT, bool FINAL>
-__global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf,
+// RH: rank tiles of the group (1: r <= 16, 2: r <= 32 -- round 6: the reference's default rank took two passes over gy before, k_t1<RT = 4>
+// for gt and k_t3<RT = 4> for gB).  Operand images as everywhere: W1b = [hi rows 0 .. 16 RH - 1 | lo rows] x N; TTf = per 32-row step
+// 2 RH blocks [hi tiles | lo tiles]; gt leaves with 16 RH entries per row.  RH = 2 needs 128 KB of LDS and ~250 registers: one workgroup
+// per CU, which is what the plan launches anyway.
+template <typename XT, bool FINAL, int RH = 1>
+__global__ __launch_bounds__(512, RH == 1 ? 2 : 1) void k_t3w(const XT* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf,
                                                 float* __restrict__ Gpart, long long M, long long Mp, int N, int steps_per_wg,
                                                 const bf16_t* __restrict__ W1b, float* __restrict__ GTP,
                                                 bf16_t* __restrict__ T_out, bf16_t* __restrict__ TTf_out, int xcd_order) {
-    constexpr int CPR = 16;
+    constexpr int CPR = 16, RW = 16 * RH;                                        // RW: rank entries per row of gt
     __shared__ uint4 xs[8][32 * CPR];                                           // 8 KB per wave: its 32 x 128 tile
-    __shared__ __attribute__((aligned(16))) float gtx[2][8][32 * 16];           // [step parity][wave][row][rank]: gt contributions
+    __shared__ __attribute__((aligned(16))) float gtx[2][8][32 * RW];           // [step parity][wave][row][rank]: gt contributions
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -1212,18 +1239,20 @@ __global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long l
     const int colc = (active && col < N) ? col : (N - 8);
     const unsigned cmask = (active && col < N) ? 0xffffffffu : 0u;
 
-    // B operand of the gt contraction: B_c[r = n][c0 + ks*32 + g*8 .. +8], hi and lo rows of the image
-    uint4 bw[2][4];
+    // B operand of the gt contraction: B_c[r = tt*16 + n][c0 + ks*32 + g*8 .. +8], hi and lo rows of the image
+    uint4 bw[RH][2][4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int tt = 0; tt < RH; ++tt)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cb = c0 + ks * 32 + g * 8;
-            const bool okc = active && cb < N;
-            bw[h][ks] = and4(*reinterpret_cast<const uint4*>(W1b + (long long)(h * 16 + n) * N + (okc ? cb : N - 8)), okc ? 0xffffffffu : 0u);
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cb = c0 + ks * 32 + g * 8;
+                const bool okc = active && cb < N;
+                bw[tt][h][ks] = and4(*reinterpret_cast<const uint4*>(W1b + (long long)(h * RW + tt * 16 + n) * N + (okc ? cb : N - 8)), okc ? 0xffffffffu : 0u);
+            }
     struct Regs {
-        uint4 t[2];
+        uint4 t[2 * RH];
         Raw8<XT> x[8];
     };
     // row indices and the row pitch as 32-bit values (the launcher checks M and ldx < 2^31): one v_min_u32 + one v_mad_u64_u32 per
@@ -1234,18 +1263,21 @@ __global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long l
     auto gload = [&](int s0, Regs& r_) {
         const unsigned s = (unsigned)(s_begin + (s0 < nst ? s0 : nst - 1));
 #pragma unroll
-        for (int h = 0; h < 2; ++h) r_.t[h] = *reinterpret_cast<const uint4*>(TTl + (unsigned long long)(s * 2u + h) * 512u);
+        for (int b = 0; b < 2 * RH; ++b) r_.t[b] = *reinterpret_cast<const uint4*>(TTl + (unsigned long long)(s * (2u * RH) + b) * 512u);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const unsigned m = min(s * 32u + (unsigned)(lr + 4 * q), m_last);
             r_.x[q].load(Xc + (unsigned long long)m * ldx32);
         }
     };
-    f32x4 acc[8];
+    f32x4 acc[RH][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < RH; ++tt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[tt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     uint4* slab = xs[wave];
-    auto stage = [&](int s0, const Regs& r_) {
+    struct TFrag { uint4 t[2 * RH]; };
+    auto put = [&](int s0, const Regs& r_) {        // the step's tile into the wave's slab
         const long long mb = (long long)(s_begin + s0) * 32;
         const unsigned smask = s0 < nst ? cmask : 0u;
 #pragma unroll
@@ -1254,20 +1286,28 @@ __global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long l
             slab[row * CPR + (lc ^ (t3_h(row) << 1))] = and4(r_.x[q].packed(), mb + row < M ? smask : 0u);
         }
         wave_sync();
+    };
+    auto eat = [&](int s0, const TFrag& tf) {       // both contractions on the slab
         float* gout = &gtx[s0 & 1][wave][0];
 #pragma unroll
         for (int rtile = 0; rtile < 2; ++rtile) {
-            f32x4 ga = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 ga[RH];
+#pragma unroll
+            for (int tt = 0; tt < RH; ++tt) ga[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int row = rtile * 16 + n;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const uint4 xa = slab[row * CPR + ((ks * 4 + g) ^ (t3_h(row) << 1))];
                 // D[i = rank idx][n = row] += sum_col B_c[rank idx][col] * gy[row][col]   (k_t3e's transposed product)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    ga = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[h][ks]), __builtin_bit_cast(bf16x8, xa), ga, 0, 0, 0);
+                for (int tt = 0; tt < RH; ++tt)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        ga[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[tt][h][ks]), __builtin_bit_cast(bf16x8, xa), ga[tt], 0, 0, 0);
             }
-            *reinterpret_cast<f32x4*>(gout + (rtile * 16 + n) * 16 + g * 4) = ga;      // lane (n, g): gt[row n][ranks 4g .. 4g+3]
+#pragma unroll
+            for (int tt = 0; tt < RH; ++tt)      // lane (n, g): gt[row n][ranks tt*16 + 4g .. + 3]
+                *reinterpret_cast<f32x4*>(gout + (rtile * 16 + n) * RW + tt * 16 + g * 4) = ga[tt];
         }
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -1282,25 +1322,35 @@ __global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long l
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
             const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r_.t[h]), __builtin_bit_cast(bf16x8, both), acc[ct], 0, 0, 0);
+            for (int tt = 0; tt < RH; ++tt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, tf.t[h * RH + tt]), __builtin_bit_cast(bf16x8, both), acc[tt][ct], 0, 0, 0);
         }
         wave_sync();
     };
-    // after the step's barrier: two waves (rotating with the step) add the eight contributions in the fixed order 0 .. 7 and emit
+    auto stage = [&](int s0, const Regs& r_) {
+        TFrag tf;
+#pragma unroll
+        for (int b = 0; b < 2 * RH; ++b) tf.t[b] = r_.t[b];
+        put(s0, r_);
+        eat(s0, tf);
+    };
+    // after the step's barrier: 2 RH waves (rotating with the step) add the eight contributions in the fixed order 0 .. 7 and emit
     // 4 consecutive rank entries per lane
     auto emit = [&](int s0) {
-        const int rw = (s0 & 3) * 2;
-        if (wave != rw && wave != rw + 1) return;
-        const int l2 = (wave - rw) * 64 + lane;         // 128 lanes x 4 entries = the step's 32 rows x 16 ranks
-        const int row = l2 >> 2, r0 = (l2 & 3) * 4;
-        const float* gin = &gtx[s0 & 1][0][row * 16 + r0];
+        constexpr int EW = 2 * RH;                      // emitting waves: 64 EW lanes x 4 entries = the step's 32 rows x RW ranks
+        const int rw = (s0 % (8 / EW)) * EW;
+        if (wave < rw || wave >= rw + EW) return;
+        const int l2 = (wave - rw) * 64 + lane;
+        const int row = l2 / (4 * RH), r0 = (l2 % (4 * RH)) * 4;
+        const float* gin = &gtx[s0 & 1][0][row * RW + r0];
         f32x4 s4 = *reinterpret_cast<const f32x4*>(gin);
 #pragma unroll
-        for (int w = 1; w < 8; ++w) s4 += *reinterpret_cast<const f32x4*>(gin + w * 512);
+        for (int w = 1; w < 8; ++w) s4 += *reinterpret_cast<const f32x4*>(gin + w * (32 * RW));
         const long long m = (long long)(s_begin + s0) * 32 + row;
-        if (FINAL) store_t4_hl<1>(T_out, TTf_out, m, 0, r0, s4);
-        else *reinterpret_cast<f32x4*>(GTP + ((long long)cg * Mp + m) * 16 + r0) = s4;
+        if (FINAL) store_t4_hl<RH>(T_out, TTf_out, m, r0 >> 4, r0 & 15, s4);
+        else *reinterpret_cast<f32x4*>(GTP + ((long long)cg * Mp + m) * RW + r0) = s4;
     };
     // One code path for every wave (an idle wave of the last column group streams masked duplicates of the group's last 16
     // bytes per row -- one line per row, L2 hits): no divergent control flow around the loads, so that the waits stay counted.
@@ -1309,31 +1359,52 @@ __global__ __launch_bounds__(512, 2) void k_t3w(const XT* __restrict__ X, long l
     // (Two steps ahead -- three register sets at one workgroup per CU, 128 KB per CU under way instead of 64 -- measured equal on MI355X,
     // round 6: 73.2-73.4 us against 73.2-73.6 at N = 4736, 27.6-29.1 against 26.7-29.3 at N = 1024 (profiles/r06c_sweep_t3w_depth.json):
     // this pass is not short of outstanding loads.)
-    Regs rA, rB;
-    gload(0, rA);
-    for (int s = 0; s < nst; s += 2) {
-        gload(s + 1, rB);
-        __builtin_amdgcn_sched_barrier(0);
-        stage(s, rA);
-        lds_barrier();
-        emit(s);
-        gload(s + 2, rA);
-        __builtin_amdgcn_sched_barrier(0);
-        stage(s + 1, rB);           // the padding step of an odd count stages zeros
-        lds_barrier();
-        if (s + 1 < nst) emit(s + 1);
-    }
-    if (!active) return;
-    // the wave's accumulators ARE the row group's partial for its columns: lane (n, g) holds G[rank 4g + jj][col ct*16 + n]
-    float* out = Gpart + (long long)rg * 16 * N;
+    if constexpr (RH == 2) {
+        // ONE register set (two would not fit beside 64 accumulators and 64 operand registers: 68-104 bytes of scratch per lane): the
+        // slab is the second buffer -- the step's tile goes to the LDS, the NEXT step's loads are issued into the same registers and are
+        // in flight while both contractions run on the slab
+        Regs r;
+        gload(0, r);
+        for (int s = 0; s < nst; ++s) {
+            TFrag tf;
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        const int ocol = c0 + ct * 16 + n;
-        if (ocol < N) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = acc[ct][jj];
+            for (int b = 0; b < 2 * RH; ++b) tf.t[b] = r.t[b];
+            put(s, r);
+            gload(s + 1, r);            // clamped to the last step at the end (harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            eat(s, tf);
+            lds_barrier();
+            emit(s);
+        }
+    } else {
+        Regs rA, rB;
+        gload(0, rA);
+        for (int s = 0; s < nst; s += 2) {
+            gload(s + 1, rB);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(s, rA);
+            lds_barrier();
+            emit(s);
+            gload(s + 2, rA);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(s + 1, rB);           // the padding step of an odd count stages zeros
+            lds_barrier();
+            if (s + 1 < nst) emit(s + 1);
         }
     }
+    if (!active) return;
+    // the wave's accumulators ARE the row group's partial for its columns: lane (n, g) holds G[rank tt*16 + 4g + jj][col ct*16 + n]
+    float* out = Gpart + (long long)rg * RW * N;
+#pragma unroll
+    for (int tt = 0; tt < RH; ++tt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int ocol = c0 + ct * 16 + n;
+            if (ocol < N) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) out[(long long)(tt * 16 + g * 4 + jj) * N + ocol] = acc[tt][ct][jj];
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1732,7 +1803,10 @@ int ga_row_blocks(long long M) { return (int)(((M + 15) / 16 + GA_TILES_PER_WG -
 // hi + lo kernels (bf16, one rank group of <= 16), no dropout mask on the branch input; combines with the fp8 image.  SAM3_LORA_GA_IN_T2=1 takes the same
 // route when x IS given (A/B of the two forms; the caller then vouches that x == act(pre_act)).
 bool ga_in_pass_supported(int rank, int dtype, float drop_p) {
-    return dtype == SAM3_LORA_BF16 && rank <= 16 && geo_of(rank, dtype).hl && drop_p == 0.f;
+    // one rank group of the hi + lo kernels (r <= 32), with or without the dropout mask (round 6: r <= 16 without a mask before -- the
+    // reference's default configuration, r = 32 / dropout 0.1, kept fc2's input for a k_t3 pass over [M, 4736] of its own)
+    (void)drop_p;
+    return dtype == SAM3_LORA_BF16 && rank <= 32 && geo_of(rank, dtype).hl;
 }
 bool ga_in_t2_enabled() { return env_flag("SAM3_LORA_GA_IN_T2"); }
 
@@ -1766,12 +1840,14 @@ void launch_t2(void* Y, long long ldy, const bf16_t* T, const bf16_t* W2t, long 
 #undef T2_Q8
         return;
     }
-    if (ga_in) {    // checked by the caller: bf16, hi + lo, GELU' pass, no dropout mask
-#define T2_GA(QV, FV) hipLaunchKernelGGL((k_t2<bf16_t, 2, false, 2, true, QV, FV, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
-                                         scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
-        if (!q8.q) T2_GA(false, 0);
-        else if (q8.fmt == SAM3_FP8_E4M3) T2_GA(true, SAM3_FP8_E4M3);
-        else T2_GA(true, SAM3_FP8_E5M2);
+    if (ga_in) {    // checked by the caller: bf16, hi + lo, GELU' pass; the fp8 image only at r <= 16 without a mask
+#define T2_GA(RTV, DV, QV, FV) hipLaunchKernelGGL((k_t2<bf16_t, RTV, DV, 2, true, QV, FV, true>), grid, dim3(256), 0, st, (bf16_t*)Y, ldy, T, W2t, M, N, \
+                                                  scale, (int)tiles_per_wg, dk, (bf16_t*)aux, ldaux, ride, q8, xcd, ga)
+        if (RT == 4) { if (dk.thr) T2_GA(4, true, false, 0); else T2_GA(4, false, false, 0); }
+        else if (dk.thr) T2_GA(2, true, false, 0);
+        else if (!q8.q) T2_GA(2, false, false, 0);
+        else if (q8.fmt == SAM3_FP8_E4M3) T2_GA(2, false, true, SAM3_FP8_E4M3);
+        else T2_GA(2, false, true, SAM3_FP8_E5M2);
 #undef T2_GA
         return;
     }
@@ -1832,14 +1908,15 @@ void launch_t3_emit(const void* X, long long ldx, const bf16_t* TT, float* part,
 // complete inside the kernel; otherwise p.nchunks fp32 partials go to GTP.
 template <typename XT>
 void launch_t3w(const void* X, long long ldx, const bf16_t* TT, float* part, long long M, long long Mp, int N, const T3Plan& p,
-                const bf16_t* W1b, float* GTP, bf16_t* GT, bf16_t* GTT, bool final_images, hipStream_t st) {
+                const bf16_t* W1b, float* GTP, bf16_t* GT, bf16_t* GTT, bool final_images, hipStream_t st, int RH = 1) {
     dim3 grid((unsigned)p.nchunks, (unsigned)p.NR);
     const int xcd = p.nchunks > 1 ? 1 : 0;      // the column groups of a row range share its t^T fragments and write neighbouring gt partial rows
     ProfScope ps(SAM3_LORA_STAGE_T3W, N, st);
-    if (final_images)
-        hipLaunchKernelGGL((k_t3w<XT, true>), grid, dim3(512), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg / 32, W1b, GTP, GT, GTT, xcd);
-    else
-        hipLaunchKernelGGL((k_t3w<XT, false>), grid, dim3(512), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg / 32, W1b, GTP, GT, GTT, xcd);
+#define T3W_LAUNCH(FV, RV) hipLaunchKernelGGL((k_t3w<XT, FV, RV>), grid, dim3(512), 0, st, (const XT*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg / 32, W1b, GTP, GT, GTT, xcd)
+    if (RH == 2) { if (final_images) T3W_LAUNCH(true, 2); else T3W_LAUNCH(false, 2); }
+    else if (final_images) T3W_LAUNCH(true, 1);
+    else T3W_LAUNCH(false, 1);
+#undef T3W_LAUNCH
 }
 
 // ---- exact-fp32 launchers (lora_f32_kernels.inc) ----------------------------------------------------
@@ -1931,7 +2008,7 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
     w.tt = off; off += al256((size_t)RP * Mp * e);
     {
         int nrb = w.pB.NR > w.pE.NR ? w.pB.NR : w.pE.NR;
-        if (dtype != SAM3_LORA_F32 && RG == 16 && w.pW.NR > nrb) nrb = w.pW.NR;
+        if (dtype != SAM3_LORA_F32 && (RG == 16 || RG == 32) && w.pW.NR > nrb) nrb = w.pW.NR;
         w.pb = off; off += al256((size_t)nrb * RG * out_f * 4);
     }
     {
@@ -1939,7 +2016,8 @@ BwdWs bwd_ws(long long M, int in_f, int out_f, int rank, int dtype) {
         w.pa = off; off += al256((size_t)(w.pA.NR > nra ? w.pA.NR : nra) * RG * in_f * 4);
     }
     {   // gt partials of k_t3e (bf16, r <= 16); the same region serves k_t1's split-K partials at small M
-        const size_t a = (dtype != SAM3_LORA_F32 && RG == 16) ? (size_t)w.pE.nchunks * Mp * 16 * 4 : 0;
+        const size_t a = dtype == SAM3_LORA_F32 ? 0 : RG == 16 ? (size_t)w.pE.nchunks * Mp * 16 * 4        // k_t3e's (19 at N = 4736); k_t3w's fit inside
+                         : RG == 32 ? (size_t)w.pW.nchunks * Mp * 32 * 4 : 0;                                 // k_t3w<RH = 2>'s gt partials
         const size_t b = t1_part_bytes(Mp, RG, dtype);
         w.gtp = off; off += al256(a > b ? a : b);
     }
@@ -2232,17 +2310,19 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
             launch_t1<bf16_t>(x, ldx, (const bf16_t*)W1a, (bf16_t*)(ws + w.t), TTs, M, Mp, in_features, RT, hl, st, dk, t1p);
             TT = TTs;
         }
-        // r <= 16 with weight gradients wanted: gy is read ONCE -- k_t3e emits the gt partials beside the gB partials
-        one_pass = RG == 16 && gB_g && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
+        // weight gradients wanted: gy is read ONCE.  Version 2 (hi + lo, one rank group of <= 32: k_t3w) emits gt beside the gB partials;
+        // r <= 16 single-rounded (or SAM3_LORA_BWD_V2=0): k_t3e
+        const bool once = gB_g && s1 && s3b && !env_flag("SAM3_LORA_TWO_PASS_GY");
+        v2 = once && hl && (RG == 16 || RG == 32) && bwd_v2_enabled() && M < (1LL << 31) && ldgy < (1LL << 31);
+        one_pass = v2 || (once && RG == 16);
         float* GTP = (float*)(ws + w.gtp);
-        // version 2 (hi + lo): k_t3w over gy
-        v2 = one_pass && hl && bwd_v2_enabled() && M < (1LL << 31) && ldgy < (1LL << 31);
         if (v2) {
             const bool final_images = w.pW.nchunks == 1;
-            launch_t3w<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pW, (const bf16_t*)W1b, GTP, GT, GTT, final_images, st);
+            launch_t3w<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pW, (const bf16_t*)W1b, GTP, GT, GTT, final_images, st, RG / 16);
             if (!final_images) {
                 ProfScope ps(SAM3_LORA_STAGE_GT_REDUCE, out_features, st);
-                hipLaunchKernelGGL(k_gt_reduce<true>, dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, w.pW.nchunks, GT, GTT, Mp);
+                if (RG == 32) hipLaunchKernelGGL((k_gt_reduce<true, 2>), dim3((unsigned)((Mp * 8 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, w.pW.nchunks, GT, GTT, Mp);
+                else hipLaunchKernelGGL((k_gt_reduce<true, 1>), dim3((unsigned)((Mp * 4 + 255) / 256)), dim3(256), 0, st, (const float*)GTP, w.pW.nchunks, GT, GTT, Mp);
             }
         } else if (one_pass) {
             launch_t3_emit<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pE, hl, (const bf16_t*)W1b, GTP, GT, GTT, st);
@@ -2252,7 +2332,8 @@ static void bwd_group(const void* gy, const void* x, const void* tT_saved, const
             if (gB_g && s3b) launch_t3<bf16_t>(gy, ldgy, TT, PB, M, Mp, out_features, w.pB, RT, hl, SAM3_LORA_STAGE_T3_GB, st);   // gB = t^T . gy
         }
         // GELU'-fused backward of the hi + lo kernels: gA from act(h) INSIDE the pass over gx (k_t2<GA>), no second read of x
-        ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && RG == 16 && !dk.thr && (x == nullptr || ga_in_t2_enabled());
+        ga_in_pass = gA_g && s3a && s2 && gx_inout && a2 == 2 && hpre && hl && (RG == 16 || RG == 32) && (!q8 || (RG == 16 && !dk.thr)) &&
+                     (x == nullptr || ga_in_t2_enabled());
         // (x == NULL with the in-pass form switched off by a partial debug stage mask: nothing can read the input -- skip, the
         // header says a partial mask leaves the outputs meaningless)
         if (gA_g && s3a && !ga_in_pass && x)
@@ -2304,8 +2385,8 @@ static int bwd_impl(const void* gy, const void* x, const void* tT_saved, const v
         if (act != SAM3_LORA_ACT_GELU || !pre_act || !gx_inout || !tT_saved)
             return fail(SAM3_LORA_EINVAL, "x may be NULL only in sam3_lora_bwd_act with pre_act, gx_inout and the saved t^T given");
         if (!ga_in_pass_supported(rank, dtype, drop_p))
-            return fail(SAM3_LORA_ENOTSUP, "x == NULL (input recomputed from pre_act) needs bf16, rank <= 16 with hi + lo operands and "
-                                           "no dropout (sam3_lora_bwd_act_recomputes_input)");
+            return fail(SAM3_LORA_ENOTSUP, "x == NULL (input recomputed from pre_act) needs bf16 and one rank group (rank <= 32) of the hi + lo "
+                                           "kernels (sam3_lora_bwd_act_recomputes_input)");
     }
     if (gx_inout && (rc = check_act(gx_inout, ldgx, in_features, dtype, "gx_inout"))) return rc;
     if (!A || (!B && !pre)) return fail(SAM3_LORA_EINVAL, "A or B is NULL");

@@ -258,7 +258,8 @@ def _hl_q8_ok(lora) -> bool:
     """The activation-fused adapter passes can carry an fp8 image: hi + lo kernels (rank <= 16, not single-rounded).  The LIBRARY
     is asked (its knob table is latched at first launch; re-reading the environment here could disagree with it, and the q8 entry
     points would then return ENOTSUP after the delayed-scaling state had already been flipped)."""
-    return bool(_ffi.load().sam3_lora_bwd_act_recomputes_input(int(getattr(lora, "rank", 99)), DT_BF16, 0.0))
+    rank = int(getattr(lora, "rank", 99))       # (the recompute form itself reaches r <= 32 since round 6; the fp8 image stays with r <= 16)
+    return rank <= 16 and bool(_ffi.load().sam3_lora_bwd_act_recomputes_input(rank, DT_BF16, 0.0))
 
 
 def _dx(gy2: torch.Tensor, w: torch.Tensor, wt: Optional[torch.Tensor]) -> torch.Tensor:

@@ -707,9 +707,11 @@ def test_hi_lo_with_dropout_and_fused_gelu():
     assert _relmax(gA.cpu().numpy(), gA_w) < 3e-5 and _relmax(gB.cpu().numpy(), gB_w) < 3e-5
 
 
-@pytest.mark.parametrize("M,fin,fout,p", [(2000, 264, 520, 0.0), (777, 1024, 4736, 0.0), (777, 4736, 1024, 0.0), (3001, 264, 1160, 0.2),
-                                            (50, 136, 64, 0.0), (1, 64, 2056, 0.0)])
-def test_backward_versions_agree_with_each_other_and_the_oracle(monkeypatch, M, fin, fout, p):
+@pytest.mark.parametrize("M,fin,fout,p,rank", [(2000, 264, 520, 0.0, 16), (777, 1024, 4736, 0.0, 16), (777, 4736, 1024, 0.0, 16), (3001, 264, 1160, 0.2, 16),
+                                                 (50, 136, 64, 0.0, 16), (1, 64, 2056, 0.0, 16),
+                                                 (2000, 264, 520, 0.0, 32), (777, 1024, 4736, 0.1, 32), (777, 4736, 1024, 0.0, 24), (3001, 264, 1160, 0.2, 17),
+                                                 (33, 136, 2056, 0.0, 32)])
+def test_backward_versions_agree_with_each_other_and_the_oracle(monkeypatch, M, fin, fout, p, rank):
     """The bf16 backward of one rank group of <= 16 has two builds: version 1 (k_t3e + k_gt_reduce + k_t3 + k_t2:
     SAM3_LORA_BWD_V2=0) and version 2 (k_t3w -- eight waves split 1024 columns, gt summed across them in LDS: 1, 2 or 5 partials here,
     written as the bf16 images directly when out_features <= 1024 -- the default).  Same products, other fp32 summation orders: gx
@@ -717,7 +719,7 @@ def test_backward_versions_agree_with_each_other_and_the_oracle(monkeypatch, M, 
     (Round 5's other variants -- the fused x / gx pass k_xgx, k_t3 riding inside k_t2's launch, the one-register-set k_t3, the
     two-stream fork -- measured slower and were removed in round 6: profiles/r05c, r05t, r05ad.)"""
     rng = np.random.default_rng(M + fout)
-    rank, s, seed = 16, 2.0, 77
+    s, seed = 2.0, 77         # rank 17..32: version 2 is k_t3w<RH = 2> (round 6), "v1" the two passes over gy (k_t1<RT = 4> + k_t3<RT = 4>)
     x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
     gy = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
     gxb = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
@@ -800,21 +802,26 @@ def test_xcd_aware_tile_order_changes_placement_not_results(monkeypatch):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("M,fin,fout,rank", [(3000, 264, 520, 16), (1000, 2304, 136, 8), (50, 136, 64, 3)])
-def test_bwd_act_recomputes_its_input_from_the_pre_activation(M, fin, fout, rank):
+@pytest.mark.parametrize("M,fin,fout,rank,p", [(3000, 264, 520, 16, 0.0), (1000, 2304, 136, 8, 0.0), (50, 136, 64, 3, 0.0),
+                                              (3000, 264, 520, 32, 0.0), (1000, 1160, 136, 24, 0.0), (3000, 264, 520, 16, 0.1),
+                                              (3000, 520, 264, 32, 0.1), (777, 4736, 1024, 32, 0.1)])
+def test_bwd_act_recomputes_its_input_from_the_pre_activation(M, fin, fout, rank, p):
     """sam3_lora_bwd_act with x == NULL ("the input is GELU(pre_act)"): the GELU' pass recomputes GELU(h) tile by tile and
     contracts it with gt for gA, instead of a second read of the stored activation.  Against the x-given form on
     x = GELU(h) exactly as sam3_lora_fwd_act writes it: gx and gB bit-identical (the same kernels' arithmetic), gA equal up
     to fp32 summation order (the partials are cut by different row blocks) and to the fp64 oracle; overwrite and accumulate
-    mode; ragged rows and a ragged last column chunk.  Refused where the kernels cannot: rank > 16, dropout, fp32."""
-    assert Fn.bwd_act_recomputes_input(rank, torch.bfloat16, 0.0)
-    assert not Fn.bwd_act_recomputes_input(24, torch.bfloat16, 0.0) and not Fn.bwd_act_recomputes_input(rank, torch.bfloat16, 0.1)
-    assert not Fn.bwd_act_recomputes_input(rank, torch.float32, 0.0)
+    mode; ragged rows and a ragged last column chunk.  Round 6: every rank group of <= 32 (two rank tiles: the reference's default
+    rank) and WITH the dropout mask (the recomputed tile is masked with the keep bits the same pass already draws for gx) -- the
+    reference's default configuration (r = 32, dropout 0.1) no longer keeps fc2's input.  Refused: rank > 32, fp32."""
+    assert Fn.bwd_act_recomputes_input(rank, torch.bfloat16, p)
+    assert Fn.bwd_act_recomputes_input(24, torch.bfloat16, 0.0) and Fn.bwd_act_recomputes_input(32, torch.bfloat16, 0.1)
+    assert not Fn.bwd_act_recomputes_input(40, torch.bfloat16, 0.0) and not Fn.bwd_act_recomputes_input(rank, torch.float32, 0.0)
+    seed = 1234 + M
     g = torch.Generator(device=DEV).manual_seed(M + rank)
     h = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
     # a = GELU(h) by the library's own forward pass (zero adapter: the update leaves h as it is)
     a, hh = torch.empty_like(h), h.clone()
-    Fn.lora_fwd_(torch.zeros(M, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(64, rank, device=DEV), torch.zeros(rank, fin, device=DEV),
+    Fn.lora_fwd_(torch.zeros(M, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(64, 8, device=DEV), torch.zeros(8, fin, device=DEV),
                  hh, 2.0, cases.LAYOUT_ROOT, gelu_out=a)
     assert torch.equal(hh, h)
     gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
@@ -822,7 +829,7 @@ def test_bwd_act_recomputes_its_input_from_the_pre_activation(M, fin, fout, rank
     A = torch.randn(fin, rank, device=DEV, generator=g) / fin ** 0.5
     B = torch.randn(rank, fout, device=DEV, generator=g) / rank ** 0.5
     y = torch.zeros(M, fout, device=DEV, dtype=torch.bfloat16)
-    tT = Fn.lora_fwd_(a, A, B, y, 2.0, cases.LAYOUT_ROOT, save_t=True)
+    tT = Fn.lora_fwd_(a, A, B, y, 2.0, cases.LAYOUT_ROOT, save_t=True, drop_p=p, seed=seed)
     res = {}
     for mode in ("given", "recomputed"):
         out = []
@@ -830,23 +837,21 @@ def test_bwd_act_recomputes_its_input_from_the_pre_activation(M, fin, fout, rank
             gx = gbase.clone()
             gA, gB = torch.full_like(A, 0.5), torch.full_like(B, 0.25)
             Fn.lora_bwd_(gy, a if mode == "given" else None, tT, A, B, gx, gA, gB, 2.0, cases.LAYOUT_ROOT, accumulate=accumulate,
-                         gelu_pre=h)
+                         drop_p=p, seed=seed, gelu_pre=h)
             out += [gx, gA, gB]
         res[mode] = out
     for i in (0, 2, 3, 5):          # gx, gB
         assert torch.equal(res["given"][i], res["recomputed"][i])
     for i in (1, 4):                # gA
         assert _relmax(res["recomputed"][i].cpu().numpy(), res["given"][i].cpu().numpy()) < 2e-6
+    mask = O.dropout_scale_mask(M, fin, p, seed) if p else None
     _, gA_r, _ = O.adapter_backward(gy.float().cpu().numpy(), a.float().cpu().numpy(), A.cpu().numpy(), B.cpu().numpy(), 2.0,
-                                    cases.LAYOUT_ROOT, acc_dtype=np.float64)
+                                    cases.LAYOUT_ROOT, drop_scale_mask=mask, acc_dtype=np.float64)
     assert _relmax(res["recomputed"][1].cpu().numpy(), gA_r) < 3e-5
-    # refusals
-    A24, B24 = torch.randn(fin, 24, device=DEV) / 16, torch.randn(24, fout, device=DEV) / 4
-    t24 = Fn.lora_fwd_(a, A24, B24, torch.zeros_like(y), 2.0, cases.LAYOUT_ROOT, save_t=True)
+    # refusals: more than one rank group; no pre-activation to recompute from
+    A40, B40 = torch.randn(fin, 40, device=DEV) / 16, torch.randn(40, fout, device=DEV) / 4
+    t40 = Fn.lora_fwd_(a, A40, B40, torch.zeros_like(y), 2.0, cases.LAYOUT_ROOT, save_t=True)
     with pytest.raises(Fn.LoRAKernelError):
-        Fn.lora_bwd_(gy, None, t24, A24, B24, gbase.clone(), torch.zeros_like(A24), torch.zeros_like(B24), 2.0, cases.LAYOUT_ROOT, gelu_pre=h)
-    with pytest.raises(Fn.LoRAKernelError):
-        Fn.lora_bwd_(gy, None, tT, A, B, gbase.clone(), torch.zeros_like(A), torch.zeros_like(B), 2.0, cases.LAYOUT_ROOT, drop_p=0.1,
-                     seed=3, gelu_pre=h)
+        Fn.lora_bwd_(gy, None, t40, A40, B40, gbase.clone(), torch.zeros_like(A40), torch.zeros_like(B40), 2.0, cases.LAYOUT_ROOT, gelu_pre=h)
     with pytest.raises(Fn.LoRAKernelError):
         Fn.lora_bwd_(gy, None, tT, A, B, gbase.clone(), torch.zeros_like(A), torch.zeros_like(B), 2.0, cases.LAYOUT_ROOT)

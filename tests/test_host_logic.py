@@ -252,8 +252,9 @@ def test_cabi_library_builds_loads_and_exports_header_symbols():
     assert lib2.sam3_lora_abi_version() == _ffi.ABI_VERSION == 6
     # which backward calls may leave x out (the GELU' pass recomputes it): a host-side rule, no device needed
     assert lib2.sam3_lora_bwd_act_recomputes_input(16, _ffi.DT_BF16, 0.0) == 1 and lib2.sam3_lora_bwd_act_recomputes_input(3, _ffi.DT_BF16, 0.0) == 1
-    assert lib2.sam3_lora_bwd_act_recomputes_input(17, _ffi.DT_BF16, 0.0) == 0 and lib2.sam3_lora_bwd_act_recomputes_input(16, _ffi.DT_F32, 0.0) == 0
-    assert lib2.sam3_lora_bwd_act_recomputes_input(16, _ffi.DT_BF16, 0.1) == 0
+    assert lib2.sam3_lora_bwd_act_recomputes_input(17, _ffi.DT_BF16, 0.0) == 1 and lib2.sam3_lora_bwd_act_recomputes_input(32, _ffi.DT_BF16, 0.1) == 1
+    assert lib2.sam3_lora_bwd_act_recomputes_input(33, _ffi.DT_BF16, 0.0) == 0 and lib2.sam3_lora_bwd_act_recomputes_input(16, _ffi.DT_F32, 0.0) == 0
+    assert lib2.sam3_lora_bwd_act_recomputes_input(16, _ffi.DT_BF16, 0.1) == 1      # (round 6: one rank group of <= 32, with or without the mask)
     # pure host-side argument validation works without a device
     assert lib2.sam3_lora_fwd_workspace_bytes(41472, 1024, 4736, 16, 0) > 0
     assert lib2.sam3_lora_fwd_workspace_bytes(41472, 1023, 4736, 16, 0) == 0
