@@ -35,7 +35,8 @@ import torch.distributed as dist
 class LoRAGradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
                  bucket_bytes: int = 16 << 20, average: bool = True, overlap: bool = True,
-                 broadcast_parameters: bool = True, run_collectives_alone: bool = False):
+                 broadcast_parameters: bool = True, run_collectives_alone: bool = False,
+                 comms_dtype: Optional[torch.dtype] = None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("LoRAGradReducer: no trainable parameters")
@@ -49,6 +50,12 @@ class LoRAGradReducer:
         # world size 1 normally skips the exchange; `run_collectives_alone` issues it anyway (a 1-rank RCCL all-reduce is
         # the identity) so that the whole side-stream path can be exercised on a single GPU
         self.run_alone = bool(run_collectives_alone) and dist.is_initialized()
+        # the reference's optional gradient compression (native_trainer.py:329-340: torch's bf16 / fp16 compress hooks): a bucket travels
+        # as `(bucket / world).to(comms_dtype)` and the summed result is written back into the fp32 buffer -- the division happens BEFORE
+        # the exchange, in fp32, and finish() then does not scale again.  Halves 23.6 MB that already hide behind backward: off by default.
+        if comms_dtype not in (None, torch.bfloat16, torch.float16):
+            raise ValueError("LoRAGradReducer: comms_dtype must be None, torch.bfloat16 or torch.float16")
+        self.comms_dtype = comms_dtype
         self.overlap = overlap and dev.type == "cuda"
         # flat buffer: [one "used this step" flag per parameter | 64-element aligned gradient slots in registration order].
         # The flags are summed by the same exchange: torch DDP leaves the gradient of a GLOBALLY unused parameter None, so
@@ -207,20 +214,30 @@ class LoRAGradReducer:
             self._flags_back.copy_(self.flat[:len(self.params)], non_blocking=True)
             self._flags_back_event = torch.cuda.Event()
             self._flags_back_event.record(torch.cuda.current_stream(self.device))
+
+        def exchange():
+            if self.comms_dtype is None:
+                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                return
+            comp = (chunk / float(self.world_size) if self.average else chunk).to(self.comms_dtype)
+            work = dist.all_reduce(comp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.wait()                                     # stream-level on a GPU (the issuing stream waits); blocking with gloo
+            chunk.copy_(comp)
+            self._works.append(work)
         if self.overlap:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
                 if self.trace:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self._side)
-                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                exchange()
                 if self.trace:
                     e1.record(self._side)
                     self.launch_events.append((b, e0, e1, origin))
                 if want_flags:
                     flags_back(self._works[-1])
         else:
-            self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            exchange()
             if want_flags:
                 flags_back(self._works[-1])
 
@@ -236,7 +253,7 @@ class LoRAGradReducer:
             w.wait()
         if self.overlap:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
-        if self.average and self.world_size > 1:
+        if self.average and self.world_size > 1 and self.comms_dtype is None:        # (compressed buckets were divided before they travelled)
             self.flat.mul_(1.0 / self.world_size)
         if locally_unused:
             # a parameter unused on EVERY rank keeps .grad = None (the optimizer then skips it, as after the reference's

@@ -254,7 +254,10 @@ class SAM3TrainerNative:
         self.optimizer = make_adamw(trainable, lr=float(self.config["training"]["learning_rate"]),
                                     weight_decay=self.config["training"]["weight_decay"])
         self.trainable = trainable
-        self.reducer = LoRAGradReducer(trainable) if self.world_size > 1 else None
+        # engine.comms_dtype: "bf16" / "fp16" = the reference's optional gradient compression (native_trainer.py:329-340); default fp32
+        comms = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16}.get(
+            str(engine.get("comms_dtype") or "").lower())
+        self.reducer = LoRAGradReducer(trainable, comms_dtype=comms) if self.world_size > 1 else None
         # the adapters' backward adds straight into param.grad (the reducer's flat buffer under data parallelism)
         # instead of handing fresh gradient tensors to autograd: engine.direct_grad (default on).  The switch is scoped to
         # this trainer's own loss.backward() calls (functional.direct_grad_accumulation) -- nothing else in the process

@@ -240,3 +240,56 @@ def test_reducer_world4_and_world8_gloo(world):
     """The world-2 protocol test (buckets, no-sync micro-batches, broadcast, used flags, notify) at 4 and 8 ranks, so that the
     first real 8-GPU run is not also the first 8-rank run."""
     _run_world(_worker, world)
+
+
+def _compress_worker(rank, world, port, q, dtype_name):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sam3_lora_amd.ddp import LoRAGradReducer
+        dt = getattr(torch, dtype_name)
+        torch.manual_seed(7)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in [(64, 4), (4, 96), (96, 4), (4, 64)]]
+        unused = torch.nn.Parameter(torch.randn(5, 5))
+        red = LoRAGradReducer(params + [unused], bucket_bytes=2048, comms_dtype=dt)
+        red.zero_grad()
+        x = torch.full((8, 64), float(rank + 1))
+        (x @ params[0] @ params[1] @ params[2] @ params[3]).sum().backward()
+        local = [p.grad.clone() for p in params]          # hooks have launched (gloo: blocking), so take the expected value from a recompute
+        red.finish()
+        got = torch.cat([p.grad.flatten() for p in params])
+        # expected (torch's bf16 / fp16 compress hooks): sum over ranks of round(local / world), accumulated in the compressed type
+        plain = LoRAGradReducer([torch.nn.Parameter(p.detach().clone()) for p in params], bucket_bytes=2048, broadcast_parameters=False)
+        plain.zero_grad()
+        (x @ plain.params[0] @ plain.params[1] @ plain.params[2] @ plain.params[3]).sum().backward()
+        plain.finish()
+        want = torch.cat([p.grad.flatten() for p in plain.params])
+        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        ok = bool((got - want).abs().max() <= 2.5 * eps * want.abs().max())        # one rounding per rank's share + the sum's
+        ok = ok and not torch.equal(got, want)                                    # it really travelled compressed
+        ok = ok and unused.grad is None                                           # the used-flags survive the compression (0 stays 0)
+        g_all = [torch.zeros_like(got) for _ in range(world)]
+        dist.all_gather(g_all, got)
+        ok = ok and all(torch.equal(g_all[0], g) for g in g_all)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+def test_compressed_exchange_world2_gloo(dtype_name):
+    """``comms_dtype`` = the reference's optional gradient compression (native_trainer.py:329-340, torch's bf16 / fp16 compress hooks):
+    buckets travel as (bucket / world) in the compressed type and are written back into the fp32 buffer; the mean agrees with the
+    fp32 exchange to the compressed type's rounding, ranks end identical, globally unused parameters keep ``.grad = None``."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compress_worker, args=(r, 2, port, q, dtype_name)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(res) == [(0, True), (1, True)], res
