@@ -1122,9 +1122,9 @@ def main():
                     "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "vs_bf16_line": round(world * args.batch * n32 / dt32 / out["value"], 4),
                     "what": "the same whole training step in the exact-fp32 layout (the reference CLI's precision: fp32 frozen tensors and "
                             "activations on the fp32 MFMA / hipBLASLt fp32 GEMMs, exact-fp32 adapter kernels): the layout whose logits meet "
-                            "north_star's 1e-3 against the reference at full size (measured 1.3e-5, profiles/r04f_parity_full_fp32.json); the bf16 "
-                            "line above sits at the reference's own autocast(bf16) deviation (3.4e-2 of max at full size, "
-                            "profiles/r05*_parity_full_bf16.json)"}
+                            "north_star's 1e-3 against the reference at full size (measured 1.8e-5 over three AdamW steps, profiles/r06d_parity_full_fp32.json); "
+                            "the bf16 line above sits at the reference's own autocast(bf16) deviation (2.7-3.4e-2 of max at full size, "
+                            "profiles/r06d_parity_full_bf16.json)"}
                 del f32
             except Exception as e:
                 out["parity_layout_fp32"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}

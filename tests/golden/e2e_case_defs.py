@@ -39,7 +39,7 @@ def samples_for(which):
     e2e_boxes.json.  The model's forward does not depend on them."""
     import json
     import os
-    base = FULL_SAMPLES if which == "full" else SAMPLES
+    base = FULL_SAMPLES if which.startswith("full") else SAMPLES
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "e2e_boxes.json")
     chosen = json.load(open(path)).get(which) if os.path.exists(path) else None
     if not chosen:
@@ -138,6 +138,12 @@ LR_FULL = 5e-5          # the reference's own setting (configs/full_lora_config.
 CONFIGS = {"tiny": (TINY, RES, LORA, LR), "wide": (WIDE, WIDE_RES, LORA_WIDE, LR_WIDE), "full": (FULL, FULL_RES, LORA_FULL, LR_FULL)}
 for _name, _yaml in YAML_CASES.items():
     CONFIGS[_name] = (WIDE, WIDE_RES, lora_section_of(_yaml), LR_WIDE)
+# BASELINE configs[3] at the REAL model size (round 6): configs/large_r32_config.yaml's adapters -- r = 32, alpha = 64 on the trunk's fc1 / fc2
+# (64), the 24-layer text tower's c_fc / c_proj (48) and the DETR layers' linear1 / linear2 (24): 136 modules -- on e2e_case_defs.FULL, one
+# image, STEPS_FULL AdamW steps.
+FULL_YAML_CASES = {"full_large_r32": "large_r32_config.yaml"}
+for _name, _yaml in FULL_YAML_CASES.items():
+    CONFIGS[_name] = (FULL, FULL_RES, lora_section_of(_yaml), LR_FULL)
 
 
 def seeded_parameter(name: str, shape) -> torch.Tensor:

@@ -328,7 +328,7 @@ def main():
     res["sd_keys"] = np.array(list(model.state_dict().keys()))
     res["param_names"] = np.array(sorted(param_names))
 
-    full = which == "full"
+    full = which.startswith("full")
     search = "--search-boxes" in sys.argv
     yardstick_only = "--yardstick" in sys.argv
     samples = D.samples_for(which)

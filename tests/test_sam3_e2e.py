@@ -373,7 +373,7 @@ BF16_CURVE_BAR = 1e-2           # the full-size fixture (four MI355X runs: first
 BF16_CURVE_BAR_SMALL = 1.5e-2   # the 256-wide / tiny fixtures: their loss is ~90 % mask focal term x 200 on a bf16 mask head, and seven
                                 # MI355X runs of the two most sensitive ones (wide, wide_minimal_r4) read 4.9 / 5.0 / 6.3 / 6.5 / 6.8 / 7.1 / 8.0 /
                                 # 9.0e-3 on the worst step of the curve -- a 1e-2 bar would fail one run in ten for no defect
-BF16_GRAD_MEASURED = {"tiny": 0.145, "wide": 0.116, "wide_large_r32": 0.087, "wide_minimal_r4": 0.106, "full": 0.069}      # worst over the round-6 runs (profiles/r06*_parity_*)
+BF16_GRAD_MEASURED = {"tiny": 0.145, "wide": 0.116, "wide_large_r32": 0.087, "wide_minimal_r4": 0.106, "full": 0.069, "full_large_r32": 0.10}      # worst over the round-6 runs (profiles/r06*_parity_*)
 
 
 def _assert_bf16_layout_step(m, yard, case, floor=None):
@@ -573,7 +573,7 @@ def test_yaml_configurations_inject_the_references_modules(case):
 GOLD_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_full.npz")
 
 
-def _full_size_step(layout, islands=None, holes=None, post_layout=None, steps=None):
+def _full_size_step(layout, islands=None, holes=None, post_layout=None, steps=None, case="full"):
     """One training step at the REAL model size through this library on the GPU, `layout` = "fp32" (exact-fp32 adapters) or "bf16"
     (vit.to_training_layout: exactly what bench.py runs -- bf16 frozen tensors and activations, fp32 A/B, the default fp32
     islands, fused fc1, hi + lo operands); returns the error record against e2e_full.npz.  The REAL model size (e2e_case_defs.FULL = sam3/model_builder.py:69-187,486-495: 1008^2 input, 72 x 72 tokens, depth-32
@@ -584,7 +584,7 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None, steps=No
     north_star's 1e-3 on every output's logits / boxes / masks, every loss term, matcher indices of the final and the five
     auxiliary outputs bit-exact, the A/B gradients of all 64 adapters (four stored in full, the others as strided samples)."""
     from sam3_lora_amd.trainer import match_all_steps, move_to_device
-    gold = np.load(GOLD_FULL)
+    gold = np.load(GOLD_FULL if case == "full" else os.path.join(os.path.dirname(GOLD), f"e2e_{case}.npz"))
     dev = torch.device("cuda")
     model = build_sam3_image_model(device="cpu", eval_mode=False, config=D.FULL, tokenizer=D.toy_tokenizer_32,
                                    act_checkpoint=False, match_in_forward=False)
@@ -594,8 +594,8 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None, steps=No
     sd.update(state_dict_of(gold))
     model.load_state_dict(sd, strict=True)
     del sd
-    layers = _inject(model, gold, D.LORA_FULL)
-    assert len(layers) == 64
+    layers = _inject(model, gold, D.CONFIGS[case][2])           # asserts the reference's module manifest
+    assert len(layers) == {"full": 64, "full_large_r32": 136}[case]
     model.to(dev).train()
     if layout == "bf16":
         from sam3_lora_amd.vit import DEFAULT_FP32_ISLANDS, to_training_layout
@@ -608,7 +608,7 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None, steps=No
             post_layout(model)
     # the batch: the first sample at 1008^2 (the generator's first draw), 2 boxes + rectangular masks
     res = D.FULL_RES
-    (text, boxes), img = D.samples_for("full")[0], D.make_images_res(res)[0]
+    (text, boxes), img = D.samples_for(case)[0], D.make_images_res(res)[0]
     objs = [Object(bbox=torch.tensor(b, dtype=torch.float32), area=b[2] * b[3], object_id=j, segment=D.box_mask_res(b, res))
             for j, b in enumerate(boxes)]
     q = FindQueryLoaded(query_text=text, image_id=0, object_ids_output=list(range(len(objs))), is_exhaustive=True,
@@ -626,7 +626,7 @@ def _full_size_step(layout, islands=None, holes=None, post_layout=None, steps=No
     model.set_prefetch_matcher(wrapper)
     # the loop of train_sam3_lora_native.py:887-943: D.STEPS_FULL AdamW steps (the fixture's loss curve); everything else is judged on
     # the first step
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.CONFIGS["full"][3], weight_decay=D.WD)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=D.CONFIGS[case][3], weight_decay=D.WD)
     rec = {"outputs": {}, "loss_terms": {}, "grads_full": {}, "grads_sampled_worst": 0.0, "losses": []}
 
     def err(a, ref):
@@ -696,7 +696,7 @@ def test_full_size_training_step_fp32_matches_reference():
     assert len(rec["losses"]) == D.STEPS_FULL and max(rec["loss_curve_rel"]) <= 1e-3, (rec["losses"], rec["loss_curve_rel"])
 
 
-def _full_bf16_verdict(rec, yard):
+def _full_bf16_verdict(rec, yard, case="full"):
     """The bars of the benchmarked layout at the benchmarked size (shared with bench.py's parity gate): every one of the 12 decisions
     as the reference's fp32 run takes it; first-step total and every step of the loss curve within BF16_CURVE_BAR; worst A/B gradient
     (4 adapters in full, 60 sampled) within twice this build's measured figure; logits / boxes / presence within the reference's own
@@ -712,7 +712,7 @@ def _full_bf16_verdict(rec, yard):
               "pred_logits": sm["pred_logits"] <= yard["pred_logits"], "pred_boxes": sm["pred_boxes"] <= yard["pred_boxes"],
               "presence_logit_dec": sm["presence_logit_dec"] <= yard["presence_logit_dec"], "pred_masks": sm["pred_masks"] <= 2.0 * yard["pred_masks"],
               "core_loss": sm["core_loss"] <= BF16_CURVE_BAR, "loss_curve": max(sm["loss_curve_rel"]) <= BF16_CURVE_BAR,
-              "AB_grad": sm["worst_AB_grad"] <= 2.0 * BF16_GRAD_MEASURED["full"]}
+              "AB_grad": sm["worst_AB_grad"] <= 2.0 * BF16_GRAD_MEASURED[case]}
     return sm, checks
 
 
@@ -730,6 +730,33 @@ def test_full_size_training_step_bf16_layout_against_reference():
     rec["reference_autocast_bf16_vs_its_fp32"] = yard
     rec["summary"], checks = _full_bf16_verdict(rec, yard)
     _record("full_bf16", rec)
+    assert all(checks.values()), (checks, rec["summary"], yard)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("layout", ["fp32", "bf16"])
+def test_full_size_configs3_training_steps_match_reference(layout):
+    """BASELINE configs[3] at the REAL model size (round 6): configs/large_r32_config.yaml's adapters -- r = 32, alpha = 64 on the trunk's
+    fc1 / fc2, the 24-layer text tower's c_fc / c_proj and the DETR layers' linear1 / linear2: 136 modules through the root injector --
+    on the depth-32 / 1008^2 model, one image, three AdamW steps of the reference on the CPU in fp32 (e2e_full_large_r32.npz,
+    make_e2e_golden.py full_large_r32; boxes chosen for decision margins: Hungarian gap 0.77, one-to-many 0.128).  fp32 layout: outputs,
+    loss terms, curve 1e-3, gradients 5e-3, all 12 decisions bit-exact; bf16 layout: the strict bars of _full_bf16_verdict against this
+    configuration's own autocast yardstick."""
+    case = "full_large_r32"
+    rec = _full_size_step(layout, case=case)
+    if layout == "fp32":
+        _record(f"{case}_fp32", rec)
+        assert rec["indices_equal"], rec["decisions_differing"]
+        assert max(rec["outputs"].values()) <= 1e-3, rec["outputs"]
+        assert max(rec["loss_terms"].values()) <= 1e-3, rec["loss_terms"]
+        assert max(rec["grads_full"].values()) <= 5e-3 and rec["grads_sampled_worst"] <= 5e-3, (rec["grads_full"], rec["grads_sampled_worst"])
+        assert len(rec["losses"]) == D.STEPS_FULL and max(rec["loss_curve_rel"]) <= 1e-3, (rec["losses"], rec["loss_curve_rel"])
+        return
+    yard = _yardstick(case)
+    rec["reference_autocast_bf16_vs_its_fp32"] = yard
+    rec["summary"], checks = _full_bf16_verdict(rec, yard, case)
+    _record(f"{case}_bf16", rec)
     assert all(checks.values()), (checks, rec["summary"], yard)
 
 
@@ -904,7 +931,7 @@ def test_training_layout_islands_and_holes_on_cpu(gold):
     assert model._sam3_layout_hooks == [] and all(p.dtype == torch.bfloat16 for p in model.parameters() if not p.requires_grad)
 
 
-@pytest.mark.parametrize("case", ["tiny", "wide", "wide_large_r32", "wide_minimal_r4", "full"])
+@pytest.mark.parametrize("case", ["tiny", "wide", "wide_large_r32", "wide_minimal_r4", "full", "full_large_r32"])
 def test_fixture_decisions_have_margins(case):
     """No GPU: every committed whole-step fixture takes each of its discrete decisions with a margin, re-derived here from the
     reference's STORED fp32 outputs with this library's cost expressions (matcher.cost_matrix; the one-to-many score
