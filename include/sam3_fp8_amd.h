@@ -24,7 +24,8 @@ extern "C" {
 /* amax state of one tensor role: SAM3_FP8_AMAX_SLOTS slots, slot s at float index s * SAM3_FP8_AMAX_STRIDE (one 128-byte line
  * per slot: atomics on the same line serialise like atomics on the same address) -- an array of SAM3_FP8_AMAX_FLOATS floats.
  * A writer raises ONE slot (at most one atomic per workgroup / wave, spread over the slots), a reader takes the maximum of
- * all of them; the floats between the slots are never read or written by the kernels. */
+ * all of them.  Float 1 of the array (inside slot 0's line) carries the EFFECTIVE amax the call scaled with -- the protocol's short
+ * memory, below; the other floats between the slots are never read or written by the kernels. */
 #define SAM3_FP8_AMAX_SLOTS 64
 #define SAM3_FP8_AMAX_STRIDE 32
 #define SAM3_FP8_AMAX_FLOATS (SAM3_FP8_AMAX_SLOTS * SAM3_FP8_AMAX_STRIDE)
@@ -32,7 +33,11 @@ extern "C" {
 const char* sam3_fp8_last_error(void);
 
 /*
- *   scale      = max(max_s amax_in[s], 2^-24) / fmt_max              (written to *scale_out: the dequantisation factor)
+ *   observed   = max_s amax_in[s]                                    (what the PREVIOUS call on this role gathered)
+ *   eff        = observed > 0 ? max(observed, 0.5 * amax_in[1]) : amax_in[1]     (amax_in[1]: the previous call's eff; the range shrinks at
+ *                                          most 2x per call and grows at once; an empty observation carries the range over)
+ *   scale      = max(eff, 2^-24) / fmt_max                           (written to *scale_out: the dequantisation factor; eff to amax_out[1]).
+ *                eff == 0 (nothing observed yet at all): *scale_out is left as the caller initialised it (1) and used
  *   out[i]     = fp8( x[i] / scale )       round-to-nearest-even; a finite value beyond the format's range saturates to
  *                                          +-fmt_max; NaN stays NaN; +-Inf leaves as the format's non-finite encoding
  *                                          (e5m2: Inf; e4m3fn has none: NaN)

@@ -783,7 +783,40 @@ __global__ __launch_bounds__(256, GA ? 2 : (HL && RT == 4) ? (ACT == 1 ? 2 : 3) 
     const bool colfull = c0 + CW <= N;
     const long long t_fast_end = colfull ? min(t_end, nfull) : t_begin;   // tiles with no tail at all
     long long t = t_begin;
-    if (t < t_fast_end) {
+    if (HL && !GA && tiles_per_wg <= 12 && t < t_fast_end) {
+        // At most three tiles per wave (launch_t2's geometry at every size it was swept on): their T fragments are fetched UP FRONT, with
+        // the W fragments, and the loop below is unrolled over them.  Inside the loop a T load sits in the middle of the queue of the tile
+        // loads and the s_waitcnt that hands it to the next iteration also waits for the three tile loads issued before it; hoisted
+        // (measured with the loads dropped altogether: 132.8 -> 126.5 us at N = 4736, 37.1 -> 36.0 at N = 1024).  The unrolled form also
+        // stops re-reading the wave's own last tile as its "next" one.
+        uint4 tp[3], tp2[RT == 4 ? 3 : 1];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const long long ti = t + 4 * i < t_end ? t + 4 * i : t;
+            tp[i] = *reinterpret_cast<const uint4*>(T + (ti * 16 + n) * RP + g * 8);
+            if (RT == 4) tp2[i] = *reinterpret_cast<const uint4*>(T + (ti * 16 + n) * RP + 32 + g * 8);
+        }
+        YTile<YT> cur, nxt, hcur, hnxt;
+        nxt.template load<true>(Y, ldy, t * 16, col, lane, M, N);
+        if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, t * 16, col, lane, M, N);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (t < t_fast_end) {       // wave-uniform
+                cur = nxt;
+                if (ACT == 2) hcur = hnxt;
+                if (i < 2 && t + 4 < t_fast_end) {
+                    nxt.template load<true>(Y, ldy, (t + 4) * 16, col, lane, M, N);
+                    if (ACT == 2) hnxt.template load<true, true>(AUX, ldaux, (t + 4) * 16, col, lane, M, N);
+                }
+                if (RT == 4) tq2 = tp2[i];
+                delta_to_slab(make_uint2(tp[i].x, tp[i].y), make_uint2(tp[i].z, tp[i].w));
+                wave_sync();
+                cur.template add_store<true, DROP, ACT, Q8, QF, GA>(Y, ldy, t * 16, col, lane, M, N, slab, LDW, scale, dk, AUX, ldaux, hcur, &q8, &qs, &seen, atile);
+                wave_sync();
+                t += 4;
+            }
+        }
+    } else if (t < t_fast_end) {
         // branch-free stream: tile t+4 (and its t fragment, issued first) is in flight while tile t is updated.  (TWO tiles
         // ahead -- 124 VGPRs, the same 4 waves per SIMD, twice the bytes in flight -- measured SLOWER on MI355X: 159 vs 132 us
         // at N = 4736, profiles/r03j_adapter_sweep.json: this stream is not short of outstanding loads.)

@@ -6,7 +6,9 @@ CDNA4 fp8 MFMA on base GEMMs").  A build-side extension -- 
                input-gradient GEMM;
   activations  bf16 -> e4m3 (forward) / e5m2 (incoming gradients) by the HIP quantiser (C-ABI ``sam3_fp8_quantize``,
                include/sam3_fp8_amd.h) with delayed scaling: a call scales with the amax its predecessor on the same
-               tensor role observed, and gathers the amax for its successor in the same pass;
+               tensor role observed -- but never with less than half the range the predecessor itself scaled with (the
+               protocol's short memory: the range shrinks at most one octave per call, grows at once) -- and gathers the
+               amax for its successor in the same pass;
   GEMMs        hipBLASLt fp8 MFMA kernels through ``torch._scaled_mm`` (measured on MI355X at M = 41,472: fc1 429 -> 268 us,
                fc2 317 -> 146 us, qkv 218 -> 126 us, proj 75 -> 48 us), bf16 out;
   LoRA branch  unchanged: bf16 activations through the adapter kernels, fp32 A / B.

@@ -35,6 +35,24 @@ def test_quantiser_matches_torch_cast_bitwise_and_tracks_amax(fmt, src):
     assert torch.isfinite(out4.float()).all() and out4.float().abs().max().item() == fmax
 
 
+def test_the_scale_shrinks_at_most_one_octave_per_call_and_grows_at_once():
+    """Round 6, the protocol's short memory: a call scales with max(observed by its predecessor, half of what the predecessor scaled
+    with).  A role whose magnitude drops 8x and comes back saturates by one octave at most instead of by the whole drop."""
+    from sam3_lora_amd import _ffi
+    from sam3_lora_amd.fp8 import Fp8Quantizer
+    q = Fp8Quantizer(_ffi.FP8_E4M3)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(64, 256, device=DEV, generator=g).bfloat16()
+    A = float(x.abs().max())
+    scales = []
+    for t in (x, x, x * 0.125, x * 0.125, x * 0.125, x * 0.125, x, x):
+        scales.append(float(q(t)[1]) * 448.0 / A)
+    # calibrate, observed A, observed A, then the drop: the predecessor saw A/8 but scaled with A -> A/2, A/4, A/8; the return: the
+    # predecessor saw A/8 (one call late, as always) -> A/8, then A at once
+    want = [1.0, 1.0, 1.0, 0.5, 0.25, 0.125, 0.125, 1.0]
+    assert all(abs(a - b) <= 1e-6 * max(b, 1e-3) for a, b in zip(scales, want)), (scales, want)
+
+
 def test_an_empty_observation_keeps_the_previous_scale():
     """Delayed scaling after a call that observed NOTHING (an all-zero tensor: a gradient that vanished for a step, a fully masked
     batch): the amax it gathered is 0.  The next call must not scale with it -- "amax = tiny" multiplies a real tensor by 7.5e9 and
@@ -140,7 +158,7 @@ def test_producers_write_the_image_the_separate_quantiser_would(fmt):
     y_plain = V._FrozenLayerNorm.apply(x, w, b, 1e-5)
     assert torch.equal(y, y_plain)
     assert torch.equal(img.view(torch.uint8), expect(y, 3.0)) and torch.allclose(scale, torch.tensor([3.0 / fmax], device=DEV))
-    assert float(amax[1].max()) == float(y.float().abs().max())
+    assert float(amax[1][::_ffi.FP8_AMAX_STRIDE].max()) == float(y.float().abs().max())
     # adapter forward with GELU: the image is GELU(y)'s
     M, fin, fout, r = 777, 264, 520, 16
     xa = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
@@ -153,7 +171,7 @@ def test_producers_write_the_image_the_separate_quantiser_would(fmt):
     y0, act0 = base.clone(), torch.empty_like(base)
     Fn.lora_fwd_(xa, A, B, y0, 2.0, 0, gelu_out=act0)
     assert torch.equal(yq, y0) and torch.equal(act, act0)
-    assert torch.equal(img.view(torch.uint8), expect(act, 2.0)) and float(amax[1].max()) == float(act.float().abs().max())
+    assert torch.equal(img.view(torch.uint8), expect(act, 2.0)) and float(amax[1][::_ffi.FP8_AMAX_STRIDE].max()) == float(act.float().abs().max())
     # adapter backward with GELU': the image is the pre-activation gradient's
     gy = torch.randn(M, fout, device=DEV, generator=g).bfloat16()
     h = torch.randn(M, fin, device=DEV, generator=g).bfloat16()
@@ -167,7 +185,7 @@ def test_producers_write_the_image_the_separate_quantiser_would(fmt):
         Fn.lora_bwd_(gy, xa, None, A, B, gx, gA, gB, 2.0, 0, gelu_pre=h, q8=(img, code, amax[0], amax[1], scale) if q8 else None)
         res.append((gx, gA, gB))
     assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
-    assert torch.equal(img.view(torch.uint8), expect(res[1][0], 5.0)) and float(amax[1].max()) == float(res[1][0].float().abs().max())
+    assert torch.equal(img.view(torch.uint8), expect(res[1][0], 5.0)) and float(amax[1][::_ffi.FP8_AMAX_STRIDE].max()) == float(res[1][0].float().abs().max())
     # refused where the image cannot ride: rank > 16, dropout on the input gradient
     A32, B32 = torch.randn(fin, 32, device=DEV) / 16, torch.randn(32, fout, device=DEV) / 4
     with pytest.raises(Fn.LoRAKernelError):
@@ -265,7 +283,7 @@ def test_fp8_image_and_recomputed_input_ride_on_the_same_pass():
         amax, scale = _slot_state(4.0)
         img = torch.empty(M, fin, dtype=torch.float8_e5m2, device=DEV)
         Fn.lora_bwd_(gy, x, tT, A, B, gx, gA, gB, 2.0, 0, gelu_pre=h, q8=(img, _ffi.FP8_E5M2, amax[0], amax[1], scale))
-        res.append((gx, gB, img.view(torch.uint8), amax[1].max().clone(), gA))
+        res.append((gx, gB, img.view(torch.uint8), amax[1][::_ffi.FP8_AMAX_STRIDE].max().clone(), gA))
     for u, v in zip(res[0][:4], res[1][:4]):
         assert torch.equal(u, v)
     assert ((res[0][4] - res[1][4]).abs().max() / res[0][4].abs().max()).item() < 2e-6
