@@ -284,6 +284,29 @@ __device__ __forceinline__ void store_t4_hl(bf16_t* __restrict__ T, bf16_t* __re
     }
 }
 
+// store_t4_hl for a whole 256-thread workgroup that owns 64 CONSECUTIVE rows starting at a multiple of 64 (r <= 16: one rank tile): the row-major
+// image goes out as before (16 bytes per lane); the fragment-major image -- eight 2-byte stores per lane, 16 bytes apart, in store_t4_hl --
+// is assembled in 4 KB of LDS and leaves as ONE 16-byte store per thread (the 64 rows' image is 4 KB contiguous: two 32-row steps x
+// [hi | lo] x 4 x 16 x 8).  Every thread of the workgroup must call it (one barrier inside); `stage` = 4 KB of LDS nobody else is using.
+__device__ __forceinline__ void store_t4_hl_wg64(bf16_t* __restrict__ T, bf16_t* __restrict__ TTf, long long m0, int row, int r0, f32x4 v,
+                                                 bf16_t* stage) {
+    const unsigned h0 = pack2(v[0], v[1]), h1 = pack2(v[2], v[3]);
+    const unsigned l0 = pack2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), l1 = pack2(v[2] - bf_lo(h1), v[3] - bf_hi(h1));
+    *reinterpret_cast<uint4*>(T + (m0 + row) * 32 + 2 * r0) = make_uint4(h0, h1, l0, l1);
+    const int blk = row >> 5, gq = (row & 31) >> 3, jq = row & 7;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const unsigned p0 = hh ? l0 : h0, p1 = hh ? l1 : h1;
+        bf16_t* tb = stage + (((blk * 2 + hh) * 4 + gq) * 16 + r0) * 8 + jq;
+        tb[0] = (bf16_t)(p0 & 0xffffu);
+        tb[8] = (bf16_t)(p0 >> 16);
+        tb[16] = (bf16_t)(p1 & 0xffffu);
+        tb[24] = (bf16_t)(p1 >> 16);
+    }
+    __syncthreads();
+    reinterpret_cast<uint4*>(TTf + (m0 >> 5) * 1024)[threadIdx.x] = reinterpret_cast<const uint4*>(stage)[threadIdx.x];
+}
+
 // PART (small M, r <= 16): blockIdx.y selects a range of K chunks and the workgroup writes its fp32 partial to
 // P[split][row][16]; k_gt_reduce then adds the splits in fixed order and emits T / TTf.  With M/64 workgroups alone a
 // small batch leaves most CUs idle (M = 5184: 81 workgroups on 256 CUs).
@@ -313,15 +336,18 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
     uint4 xr[XP], wr[WP];
     auto gload = [&](int kc) {
         const int k = kc * BK + lc * 8;
-#pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const long long m = m0 + lrow + RPP * i;
-            xr[i] = (m < M && k < K) ? load8(X + m * ldx + k) : zero4();
-        }
+        // the W1 chunk first: it comes from the L2 and has landed when the x chunk (HBM) arrives; behind the x loads it was the last
+        // thing the chunk's s_waitcnt saw (20.6 -> 19.3 us at K = 1024, equal at 4736)
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
             const int r = lrow + RPP * j;
             wr[j] = (k < K) ? *reinterpret_cast<const uint4*>(W1 + (long long)r * K + k) : zero4();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const long long m = m0 + lrow + RPP * i;
+            xr[i] = (m < M && k < K) ? load8(X + m * ldx + k) : zero4();
         }
     };
     // dropout is applied here, when the chunk moves to LDS -- not at load time, which would expose the
@@ -380,6 +406,10 @@ __global__ __launch_bounds__(256) void k_t1(const XT* __restrict__ X, long long 
         return;
     }
     if (HL) {
+        if (RH == 1) {      // (the chunk loop ended on a barrier: xs is free)
+            store_t4_hl_wg64(T, TTf, m0, wave * 16 + n, g * 4, acc[0], reinterpret_cast<bf16_t*>(&xs[0][0]));
+            return;
+        }
 #pragma unroll
         for (int tt = 0; tt < RH; ++tt) store_t4_hl<RH>(T, TTf, m, tt, g * 4, acc[tt]);
         return;
@@ -1213,14 +1243,28 @@ template <bool HL, int RH = 1>
 __global__ __launch_bounds__(256) void k_gt_reduce(const float* __restrict__ GTP, int nchunks, bf16_t* __restrict__ T,
                                                    bf16_t* __restrict__ TTf, long long Mp) {
     static_assert(RH == 1 || HL, "two rank tiles: the hi + lo images of r <= 32 (k_t3w<RH = 2>)");
+    __shared__ __attribute__((aligned(16))) bf16_t stage[(HL && RH == 1) ? 2048 : 8];
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 4 consecutive rank entries
-    if (idx >= Mp * 4 * RH) return;
+    if (idx >= Mp * 4 * RH) return;     // (Mp is a multiple of 64: at RH == 1 a workgroup is 64 whole rows, never cut)
     const long long m = idx / (4 * RH);
     const int r0 = (int)(idx % (4 * RH)) * 4;
+    // the partials of a row in groups of eight, every load of a group issued before the first is consumed (the chunk count is a run-time
+    // value: the plain loop waited for each load in turn -- five dependent round trips to the L2 / Infinity Cache at N = 4736); the sum
+    // keeps its fixed order 0, 1, 2, ...
     f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nchunks; ++c)
-        s4 += __builtin_bit_cast(f32x4, ldg16(GTP + ((long long)c * Mp + m) * (16 * RH) + r0));
-    if (HL) store_t4_hl<RH>(T, TTf, m, r0 >> 4, r0 & 15, s4);
+    for (int cb = 0; cb < nchunks; cb += 8) {
+        f32x4 part[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int cc = cb + c < nchunks ? cb + c : nchunks - 1;
+            part[c] = __builtin_bit_cast(f32x4, ldg16(GTP + ((long long)cc * Mp + m) * (16 * RH) + r0));
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (cb + c < nchunks) s4 += part[c];
+    }
+    if (HL && RH == 1) store_t4_hl_wg64(T, TTf, (long long)blockIdx.x * 64, (int)(threadIdx.x >> 2), r0, s4, stage);
+    else if (HL) store_t4_hl<RH>(T, TTf, m, r0 >> 4, r0 & 15, s4);
     else store_t4<1>(T, TTf, m, 0, r0, pack2(s4[0], s4[1]), pack2(s4[2], s4[3]));
 }
 

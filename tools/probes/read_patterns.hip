@@ -103,13 +103,12 @@ int main() {
     };
     for (int g : {2048, 4096, 16384}) { char nm[64]; snprintf(nm, 64, "linear nt grid=%d", g);
         run(nm, [&] { hipLaunchKernelGGL(k_linear, dim3(g), dim3(256), 0, 0, (const u32x4*)a, bytes / 16, o); }); }
-#define PIECE(CB, D, NR) { char nm[64]; snprintf(nm, 64, "piece %4d B x depth %d, NR=%3d (%d wgs)", CB, D, NR, ((rowbytes + 4 * CB - 1) / (4 * CB)) * NR); \
-        const int nx = (rowbytes + 4 * CB - 1) / (4 * CB), rpw = (rows + NR - 1) / NR; \
+#define PIECE(CB, D, NR) { const int nx = (rowbytes + 4 * CB - 1) / (4 * CB), rpw = (rows + NR - 1) / NR, act = ((rowbytes + CB - 1) / CB) * NR; \
+        char nm[64]; snprintf(nm, 64, "piece %4d B x depth %d, %5d waves (%4d wgs)", CB, D, act, nx * NR); \
         run(nm, [&] { hipLaunchKernelGGL((k_piece<CB, D>), dim3(nx, NR), dim3(256), 0, 0, a, rows, rowbytes, rpw, o); }); }
-    PIECE(256, 1, 13) PIECE(256, 1, 27) PIECE(256, 1, 54) PIECE(256, 2, 13) PIECE(256, 2, 27)
-    PIECE(512, 1, 26) PIECE(512, 1, 54) PIECE(512, 1, 108) PIECE(512, 2, 26) PIECE(512, 2, 54)
-    PIECE(1024, 1, 51) PIECE(1024, 1, 102) PIECE(1024, 1, 204) PIECE(1024, 2, 51) PIECE(1024, 2, 102)
-    PIECE(2048, 1, 128) PIECE(2048, 1, 256) PIECE(2048, 1, 512) PIECE(2048, 2, 256)
+#define SWEEP(CB) { const int per = (rowbytes + CB - 1) / CB; for (int w : {1024, 2048, 4096, 8192}) { const int NR = (w + per - 1) / per; PIECE(CB, 1, NR) } \
+                    { const int NR = (2048 + per - 1) / per; PIECE(CB, 2, NR) } }
+    SWEEP(256) SWEEP(512) SWEEP(1024) SWEEP(2048) SWEEP(4096)
     { run("wg tile 64 rows x 256 B, barrier per chunk (648 wgs)", [&] { hipLaunchKernelGGL((k_wgtile<256>), dim3((rows + 63) / 64), dim3(256), 0, 0, a, rows, rowbytes, o); });
       run("wg tile 64 rows x 512 B, barrier per chunk (648 wgs)", [&] { hipLaunchKernelGGL((k_wgtile<512>), dim3((rows + 63) / 64), dim3(256), 0, 0, a, rows, rowbytes, o); }); }
     return 0;
