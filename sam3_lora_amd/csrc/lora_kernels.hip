@@ -1081,6 +1081,118 @@ __global__ __launch_bounds__(256, (HL && RT == 4 && !DROP) ? 2 : 1) void k_t3(co
 }
 
 // ------------------------------------------------------------------------------------------
+// T3C (round 6; bf16, hi + lo, r <= 16): k_t3's contraction with the tile handed over the way k_t1 hands its chunks over -- all 256 threads
+// load ONE [64 rows x 128 columns] tile (4 x 16 bytes per thread), write it to the LDS, barrier; one tile is in flight while the previous
+// one is contracted.  Same ownership as k_t3 (workgroup = column chunk x row group), same partial layout, but the four waves walk the SAME
+// rows in lockstep instead of four quarters of the group on their own.  Why: the bare access patterns, measured
+// (tools/probes/read_patterns.hip, profiles/r06u_read_patterns.txt, 393 MB, 481 workgroups): wave-private 32 x 256-byte pieces 5.2 TB/s
+// (k_t3 itself: 5.4-5.5); the cooperative 64-row tile walking down the rows 6.7 TB/s -- as fast as a linear read.  The HBM system rewards
+// a workgroup whose loads of one instant cover neighbouring rows, with FEWER bytes under way (16 KB per workgroup against 32).
+// Wave w owns column tiles 2w, 2w + 1 of the chunk over ALL rows of the group: 8 accumulator registers instead of 32, no cross-wave sum at
+// the end; the t^T fragments of the 64 rows (4 KB, contiguous in the fragment-major image) are fetched ONCE per workgroup (one 16-byte load
+// per thread) and shared through the LDS instead of once per wave.
+// ------------------------------------------------------------------------------------------
+// CT: 16-column tiles per wave -- 2: a 128-column chunk, [64 rows x 256 B] tiles (what is launched); 4: a 256-column chunk, [32 rows x 512 B]
+// tiles: the same 16 KB per tile and the same bare pattern speed (profiles/r06w_read_patterns.txt) with HALF the t^T bytes per activation
+// byte -- measured EQUAL at N = 4736 and at 1024 (71-74 against 69-71 us, 21.9 against 21.7: profiles/r06y_sweep_t3c_cw.json), so the
+// fragment traffic is not what is left here; kept as a template parameter, not dispatched.
+template <bool DROP, int CT>
+__global__ __launch_bounds__(256) void k_t3c(const bf16_t* __restrict__ X, long long ldx, const bf16_t* __restrict__ TTf,
+                                             float* __restrict__ Gpart, long long M, long long Mp, int N, int rows_per_wg, DropKey dk,
+                                             int xcd_order) {
+    static_assert(CT == 2 || CT == 4, "column tiles per wave");
+    constexpr int CW = CT * 64, SUB = CW / 128, TR = 128 / CT;         // tile = TR rows x CW columns = 16 KB
+    constexpr int LPR = CW / 8, RPP = 256 / LPR, NH = TR / 32;        // lanes per tile row, rows per pass, 32-row halves per tile
+    __shared__ uint4 xs[2][NH * SUB][32 * 16];  // [buffer][32-row half x 128-column sub-chunk][row][16-byte chunk]: k_t3's slab layout each
+    __shared__ uint4 ts[2][NH * 128];           // [buffer][(half * 2 + hi / lo) * 64 + lane]
+    unsigned ptile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (xcd_order) ptile = xcd_tile_index(ptile, gridDim.x * gridDim.y);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int c0 = (int)(ptile % gridDim.x) * CW;
+    const int rg = (int)(ptile / gridDim.x);
+    const long long w_begin = (long long)rg * rows_per_wg;      // rows_per_wg % 128 == 0, Mp % 64 == 0: whole tiles
+    long long w_end = w_begin + rows_per_wg;
+    if (w_end > Mp) w_end = Mp;
+    const int nst = w_end > w_begin ? (int)((w_end - w_begin) / TR) : 0;
+    const int lr = tid / LPR, lc = tid % LPR;
+    const int col = c0 + lc * 8;
+    const unsigned cmask = col < N ? 0xffffffffu : 0u;
+    const unsigned m_last = (unsigned)(M - 1), ldx32 = (unsigned)ldx, wb32 = (unsigned)w_begin;
+    const bf16_t* const Xc = X + (col < N ? col : N - 8);
+    uint4 xr[4], tr_;
+    auto gload = [&](int s0) {
+        const unsigned mb = wb32 + (unsigned)s0 * TR;
+        // the tile's t^T fragments: [hi | lo] x 64 lanes x 8 per 32-row step, contiguous in the fragment-major image
+        // (CT == 4: 2 KB per tile -- the upper half of the workgroup fetches and stores duplicates: a load under `tid < 128` is a divergent
+        // branch, and hipcc then drains the whole load queue behind it before the tile loads are issued: 90 us instead of 70)
+        tr_ = *reinterpret_cast<const uint4*>(TTf + (unsigned long long)(mb >> 5) * 1024u + (unsigned)(tid & (NH * 128 - 1)) * 8u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[i] = ldg16(Xc + (unsigned long long)min(mb + (unsigned)(lr + RPP * i), m_last) * ldx32);
+    };
+    auto sstore = [&](int buf, int s0) {
+        const long long mb = w_begin + (long long)s0 * TR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lr + RPP * i, r32 = row & 31;
+            const long long m = mb + row;
+            uint4 v = and4(xr[i], m < M ? cmask : 0u);
+            if (DROP) v = drop8(v, (unsigned long long)m * dk.width + col, dk);
+            xs[buf][(row >> 5) * SUB + (lc >> 4)][r32 * 16 + ((lc & 15) ^ (t3_h(r32) << 1))] = v;
+        }
+        ts[buf][tid & (NH * 128 - 1)] = tr_;
+    };
+    f32x4 acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (nst > 0) {
+        gload(0);
+        sstore(0, 0);
+        __syncthreads();
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nst) gload(s + 1);
+            __builtin_amdgcn_sched_barrier(0);      // the next tile's loads go out before this one is contracted
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const bf16x8 thi = __builtin_bit_cast(bf16x8, ts[buf][(h * 2 + 0) * 64 + lane]);
+                const bf16x8 tlo = __builtin_bit_cast(bf16x8, ts[buf][(h * 2 + 1) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    // as k_t3: 16-lane group g reads the [4 rows x 16 cols] blocks at rows g*8 + {0..3} and g*8 + {4..7} of the half
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                    const int ctw = wave * CT + j, ct = ctw & 7;
+                    const int rowA = g * 8 + (n >> 2), rowB = rowA + 4;
+                    const int c = ct * 2 + ((n & 3) >> 1), half = n & 1;
+                    const char* base = reinterpret_cast<const char*>(&xs[buf][h * SUB + (ctw >> 3)][0]);
+                    const char* pa = base + ((rowA * 16 + (c ^ (t3_h(rowA) << 1))) * 16 + half * 8);
+                    const char* pb = base + ((rowB * 16 + (c ^ (t3_h(rowB) << 1))) * 16 + half * 8);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, both);
+                    // D[i = rank idx][n = column] += sum_m (t_hi + t_lo)[m][i] * X[m][col]
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(thi, xf, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tlo, xf, acc[j], 0, 0, 0);
+                }
+            }
+            if (s + 1 < nst) sstore(buf ^ 1, s + 1);
+            __syncthreads();
+        }
+    }
+    float* out = Gpart + (long long)rg * 16 * N;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int ocol = c0 + (wave * CT + j) * 16 + n;
+        if (ocol < N) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) out[(long long)(g * 4 + jj) * N + ocol] = acc[j][jj];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // T3E (r <= 16, backward over gy): ONE pass over gy produces both the column reduction gB = t^T . gy (as k_t3) and
 // the row reduction gt = gy . B_c^T that k_t1 would otherwise re-read gy for.  A workgroup owns TWO 128-column chunks
 // of a row group; each wave streams its rows as sub-steps (rows of step s, chunk 0), (rows of step s, chunk 1) through
@@ -1552,6 +1664,8 @@ inline Geo geo_of(int rank, int dtype) {
     return g;
 }
 
+// k_t3c (cooperative tiles) serves the bf16 hi + lo kernels at r <= 16 unless the validation gather path or the wave-private form is asked for
+bool t3_coop_enabled() { return env_int("SAM3_LORA_T3_COOP", 1) != 0 && !env_flag("SAM3_LORA_T3_GATHER"); }
 T3Plan plan_t3(long long Mp, int N, int RT) {
     // workgroup = 128 columns x a row group (4 waves x a quarter each, 32-row steps).  ~190 VGPRs allow
     // 2 workgroups per CU: keep all of them co-resident (<= 512) so there is no tail round, and keep the
@@ -1668,7 +1782,7 @@ Knob g_knobs[] = {{"SAM3_LORA_T3_WGS", false, 0},       {"SAM3_LORA_T3E_WGS", fa
                   {"SAM3_LORA_XCD_ORDER", false, 0},       {"SAM3_LORA_GA_IN_T2", false, 0},  {"SAM3_LORA_FUSED_WGS", false, 0},
                   {"SAM3_LORA_FUSED_HALF", false, 0},  {"SAM3_LORA_FUSED_PROBE", false, 0},
                   {"SAM3_LORA_HL_MAX_RANK", false, 0},
-                  {"SAM3_LORA_T1_BK", false, 0},
+                  {"SAM3_LORA_T1_BK", false, 0},       {"SAM3_LORA_T3_COOP", false, 0},
                   {"SAM3_LORA_BWD_V2", false, 0},       {"SAM3_LORA_T3W_WGS", false, 0}};
 std::atomic<bool> g_knobs_loaded{false};
 void load_knobs() {
@@ -1957,7 +2071,11 @@ void launch_t3(const void* X, long long ldx, const bf16_t* TT, float* part, long
     } else if (hl && RT == 4) {
         if (gather) T3_LAUNCH(4, true, true); else T3_LAUNCH(4, false, true);
     } else if (hl) {
-        if (gather) T3_LAUNCH(2, true, true); else T3_LAUNCH(2, false, true);
+        if (gather) T3_LAUNCH(2, true, true);
+        else if (sizeof(XT) == 2 && t3_coop_enabled()) {    // the cooperative-tile form (k_t3c)
+            if (dk.thr) hipLaunchKernelGGL((k_t3c<true, 2>), grid, dim3(256), 0, st, (const bf16_t*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk, xcd);
+            else hipLaunchKernelGGL((k_t3c<false, 2>), grid, dim3(256), 0, st, (const bf16_t*)X, ldx, TT, part, M, Mp, N, p.rows_per_wg, dk, xcd);
+        } else T3_LAUNCH(2, false, true);
     } else {
         if (gather) T3_LAUNCH(2, true, false); else T3_LAUNCH(2, false, false);
     }

@@ -58,7 +58,8 @@ def _knobs_back_to_environment():
     yield
     if torch.cuda.is_available():
         import os
-        for k in ("SAM3_LORA_T3_GATHER", "SAM3_LORA_TWO_PASS_GY", "SAM3_LORA_T1_NO_SPLIT", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE"):
+        for k in ("SAM3_LORA_T3_GATHER", "SAM3_LORA_TWO_PASS_GY", "SAM3_LORA_T1_NO_SPLIT", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE",
+                  "SAM3_LORA_T3_COOP"):
             os.environ.pop(k, None)
         _reload_knobs()
 
@@ -160,7 +161,8 @@ def test_module_forward_backward_vs_reference_golden(golden_dir, name, dtype):
 
 @pytest.mark.parametrize("gather", ["0", "1"])
 def test_t3_transpose_read_equals_gather(gather, monkeypatch):
-    """ds_read_b64_tr_b16 operand fetch == explicit 2-byte gathers (bitwise)."""
+    """ds_read_b64_tr_b16 operand fetch == explicit 2-byte gathers (bitwise; the wave-private k_t3 carries the validation path)."""
+    monkeypatch.setenv("SAM3_LORA_T3_COOP", "0")
     c = cases.make_case("root_ffn_r8")
     x, gy, A, B = _t(c["x"], torch.bfloat16), _t(c["gy"], torch.bfloat16), _t(c["A"]), _t(c["B"])
     outs = []
@@ -171,6 +173,32 @@ def test_t3_transpose_read_equals_gather(gather, monkeypatch):
         Fn.lora_bwd_(gy, x, None, A, B, None, gA, gB, c["scaling"], c["layout"])
         outs.append((gA.clone(), gB.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("M,fin,fout,r,drop", [(1000, 256, 384, 16, 0.0), (4111, 1024, 520, 8, 0.0), (777, 264, 136, 16, 0.1), (20000, 4736, 1024, 16, 0.0),
+                                               (3001, 2176, 256, 16, 0.0), (2050, 2056, 128, 5, 0.1)])
+def test_cooperative_tile_t3_equals_the_wave_private_one(M, fin, fout, r, drop, monkeypatch):
+    """Round 6: gA = gt^T x by k_t3c (the workgroup's 64-row tile handed over through the LDS, waves own column tiles) against k_t3
+    (wave-private row quarters, cross-wave sum): the same products in a different fp32 summation order -- and both against fp64."""
+    rng = np.random.default_rng(M + fin)
+    x = O.bf16_round(rng.standard_normal((M, fin)).astype(np.float32))
+    gy = O.bf16_round(rng.standard_normal((M, fout)).astype(np.float32))
+    A = rng.uniform(-.25, .25, (fin, r)).astype(np.float32)
+    B = (rng.standard_normal((r, fout)) * .05).astype(np.float32)
+    res = []
+    for coop in ("1", "0"):
+        monkeypatch.setenv("SAM3_LORA_T3_COOP", coop)
+        _reload_knobs()
+        gA, gB = torch.zeros_like(_t(A)), torch.zeros_like(_t(B))
+        gx = torch.zeros(M, fin, device=DEV, dtype=torch.bfloat16)
+        Fn.lora_bwd_(_t(gy, torch.bfloat16), _t(x, torch.bfloat16), None, _t(A), _t(B), gx, gA, gB, 2.0, 0, drop_p=drop, seed=11)
+        res.append((gA.clone(), gB.clone(), gx.clone()))
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])          # gB, gx: not k_t3's
+    assert ((res[0][0] - res[1][0]).abs().max() / res[1][0].abs().max()).item() < 2e-6      # gA: summation order only
+    assert not torch.equal(res[0][0], torch.zeros_like(res[0][0]))
+    if drop == 0.0:
+        _, gA_r, _ = O.adapter_backward(gy, x, A, B, 2.0, 0, acc_dtype=np.float64)
+        assert _relmax(res[0][0].cpu().numpy(), gA_r) < 1e-4
 
 
 @pytest.mark.parametrize("M", [1, 15, 16, 17, 63, 64, 65, 127, 1000])

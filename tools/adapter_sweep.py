@@ -22,7 +22,7 @@ VARIANTS = {
     "no_ride": {"SAM3_LORA_NO_RIDE": "1"},
     "round-2 equivalent (single_round + no_ride)": {"SAM3_LORA_SINGLE_ROUND": "1", "SAM3_LORA_NO_RIDE": "1"},
 }
-KNOBS = ("SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE", "SAM3_LORA_T3E_WGS", "SAM3_LORA_T3_WGS", "SAM3_LORA_T2_TPW", "SAM3_LORA_XCD_ORDER",
+KNOBS = ("SAM3_LORA_T3_COOP", "SAM3_LORA_SINGLE_ROUND", "SAM3_LORA_NO_RIDE", "SAM3_LORA_T3E_WGS", "SAM3_LORA_T3_WGS", "SAM3_LORA_T2_TPW", "SAM3_LORA_XCD_ORDER",
          "SAM3_LORA_BWD_V2", "SAM3_LORA_T3W_WGS", "SAM3_LORA_TWO_PASS_GY")
 
 

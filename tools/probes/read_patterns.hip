@@ -84,6 +84,35 @@ __global__ __launch_bounds__(256) void k_wgtile(const char* p, int rows, int row
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
+// k_t3's ownership (a workgroup owns a 256-byte column chunk and walks DOWN a row group) with k_t1's hand-over: all 256 threads load
+// a [TR rows x 256 B] tile, write it to the LDS, barrier -- one tile in flight while the previous one is consumed.
+template <int TR, int CB = 256>
+__global__ __launch_bounds__(256) void k_wgtile_down(const char* p, int rows, int rowbytes, int rows_per_wg, unsigned* out) {
+    constexpr int LPR = CB / 16, RPP = 256 / LPR, XP = TR / RPP;
+    __shared__ u32x4 xs[2][TR * LPR];
+    const int cb = blockIdx.x * CB, r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    const int nst = (r1 - r0 + TR - 1) / TR, lr = threadIdx.x / LPR, lc = threadIdx.x % LPR;
+    u32x4 xr[XP];
+    unsigned acc = 0;
+    auto ld = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < XP; ++i) xr[i] = ldnt(p + (size_t)min(r0 + st * TR + lr + RPP * i, rows - 1) * rowbytes + min(cb + lc * 16, rowbytes - 16));
+    };
+    auto st_ = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XP; ++i) xs[buf][(lr + RPP * i) * LPR + lc] = xr[i];
+    };
+    ld(0); st_(0);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) ld(s + 1);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) acc ^= fold(xs[s & 1][((threadIdx.x + i * 37) % TR) * LPR + lc]);
+        if (s + 1 < nst) st_((s + 1) & 1);
+        __syncthreads();
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
 int main() {
     const int rows = 41472, rowbytes = 9472;
     const size_t bytes = (size_t)rows * rowbytes;
@@ -108,7 +137,12 @@ int main() {
         run(nm, [&] { hipLaunchKernelGGL((k_piece<CB, D>), dim3(nx, NR), dim3(256), 0, 0, a, rows, rowbytes, rpw, o); }); }
 #define SWEEP(CB) { const int per = (rowbytes + CB - 1) / CB; for (int w : {1024, 2048, 4096, 8192}) { const int NR = (w + per - 1) / per; PIECE(CB, 1, NR) } \
                     { const int NR = (2048 + per - 1) / per; PIECE(CB, 2, NR) } }
-    SWEEP(256) SWEEP(512) SWEEP(1024) SWEEP(2048) SWEEP(4096)
+    SWEEP(256)
+#define DOWN(TR, CB, NR) { const int nx = (rowbytes + CB - 1) / CB; char nm[64]; snprintf(nm, 64, "wg tile DOWN %3d rows x %4d B, %4d wgs", TR, CB, nx * NR); const int rpw = (((rows + NR - 1) / NR) + TR - 1) / TR * TR; \
+        run(nm, [&] { hipLaunchKernelGGL((k_wgtile_down<TR, CB>), dim3(nx, NR), dim3(256), 0, 0, a, rows, rowbytes, rpw, o); }); }
+    DOWN(64, 256, 13) DOWN(64, 256, 20) DOWN(32, 256, 27)
+    DOWN(32, 512, 13) DOWN(32, 512, 26) DOWN(32, 512, 40) DOWN(32, 512, 52) DOWN(64, 512, 13) DOWN(64, 512, 26) DOWN(64, 512, 40)
+    DOWN(16, 1024, 26) DOWN(16, 1024, 52) DOWN(16, 1024, 78) DOWN(32, 1024, 26) DOWN(32, 1024, 52)
     { run("wg tile 64 rows x 256 B, barrier per chunk (648 wgs)", [&] { hipLaunchKernelGGL((k_wgtile<256>), dim3((rows + 63) / 64), dim3(256), 0, 0, a, rows, rowbytes, o); });
       run("wg tile 64 rows x 512 B, barrier per chunk (648 wgs)", [&] { hipLaunchKernelGGL((k_wgtile<512>), dim3((rows + 63) / 64), dim3(256), 0, 0, a, rows, rowbytes, o); }); }
     return 0;
