@@ -1199,6 +1199,17 @@ def main():
                                    "achieved": round(step_bytes / (msa * 1e-3) / 1e9, 1), "unit": "GB/s",
                                    "frac": round(step_bytes / (msa * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                    "what": "all 256 C-ABI calls of the adapter path (fwd + recompute + bwd of 64 Linears)"}
+        nr_ms = out["adapter_path"]["no_recompute"]["ms_per_step"]
+        seq_bytes = (per_block - fwd_b(D_MODEL, D_HID) - fwd_b(D_HID, D_MODEL)) * args.blocks
+        out["roofline"]["in_sequence"] = {"algorithmic_bytes": seq_bytes, "ms": nr_ms, "us_per_block": round(nr_ms * 1e3 / args.blocks, 2),
+                                          "achieved": round(seq_bytes / (nr_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                          "frac": round(seq_bytes / (nr_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                          "what": "the same four calls per block in the ORDER a training step issues them (forward of all %d "
+                                                  "blocks, then backward, each block on its own activations; operand packing and the "
+                                                  "gradient exchange of the step included): the no-recompute adapter step over %d x the "
+                                                  "block's algorithmic bytes.  `frac` above times each call repeated on its own, where every "
+                                                  "in-place pass starts on the write-back of its predecessor (k_t2 at N = 4736: 144 us there, "
+                                                  "124 us here; profiles/r06ad_op_kernel_split.json)" % (args.blocks, args.blocks)}
         try:
             tu = torch_unfused_block(w)
             ours = ops[-1]["avg_us"]

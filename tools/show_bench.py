@@ -7,6 +7,8 @@ if "roofline" in d:
     print("roofline", {k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_us", "traffic")})
 if "step" in d.get("roofline", {}):
     print("whole step vs roofline", d["roofline"]["step"])
+    if "in_sequence" in d["roofline"]:
+        print("block in sequence", d["roofline"]["in_sequence"])
 for k in d.get("kernels", []):
     print(f"  {k['kernel']:9s} dim={k['dim']:5d} n={k['launches']:4d} avg={k['avg_us']:8.2f} med={k['median_us']:8.2f} min={k['min_us']:8.2f} tot={k['total_us']:9.1f} {(k['GBps'] or 0):7.1f} GB/s")
 for k in d.get("ops", []):
