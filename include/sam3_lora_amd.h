@@ -276,7 +276,7 @@ int sam3_lora_merge(const float* W, const float* A, const float* B, float* Wm,
 #define SAM3_LORA_STAGE_T1 2u       /* k_t1     : t = x.A_c (fwd) / gt = gy.B_c^T (bwd)         */
 #define SAM3_LORA_STAGE_T2 4u       /* k_t2     : y += s.t.B_c (fwd) / gx += s.gt.A_c^T (bwd)   */
 #define SAM3_LORA_STAGE_T3_GB 8u    /* k_t3     : gB partials = t^T.gy (+ gt partials, r <= 16) */
-#define SAM3_LORA_STAGE_T3_GA 16u   /* k_t3     : gA partials = gt^T.x                          */
+#define SAM3_LORA_STAGE_T3_GA 16u   /* k_t3c / k_t3 : gA partials = gt^T.x                      */
 #define SAM3_LORA_STAGE_REDUCE 32u  /* fixed-order sum of the partials into gA/gB: rides on the backward's k_t2 launch (bf16, gx wanted), k_reduce otherwise */
 #define SAM3_LORA_STAGE_GT_REDUCE 64u /* k_gt_reduce : chunk sum of the gt partials k_t3 emitted (r <= 16)  */
 #define SAM3_LORA_STAGE_FUSED 128u  /* k_fused_linear : frozen GEMM + rank-r K step + bias + activation (sam3_lora_linear_fwd) */
@@ -288,7 +288,7 @@ unsigned sam3_lora_debug_set_stages(unsigned mask);
 /* Tuning / validation knobs (SAM3_LORA_T3_GATHER, SAM3_LORA_TWO_PASS_GY, SAM3_LORA_T1_NO_SPLIT, SAM3_LORA_T1_LDS_PAD,
  * SAM3_LORA_T2_TPW, SAM3_LORA_T3_WGS, SAM3_LORA_T3E_WGS, SAM3_LORA_SINGLE_ROUND, SAM3_LORA_NO_RIDE, SAM3_LORA_FUSED_WGS,
  * SAM3_LORA_FUSED_HALF, SAM3_LORA_FUSED_PROBE, SAM3_LORA_HL_MAX_RANK, SAM3_LORA_BWD_V2,
- * SAM3_LORA_T3W_WGS, SAM3_LORA_XCD_ORDER, SAM3_LORA_GA_IN_T2, SAM3_LORA_T1_BK; INTEGRATION.md section D says what each selects) are read from the
+ * SAM3_LORA_T3W_WGS, SAM3_LORA_XCD_ORDER, SAM3_LORA_GA_IN_T2, SAM3_LORA_T1_BK, SAM3_LORA_T3_COOP; INTEGRATION.md section D says what each selects) are read from the
  * environment once, at the first launch; this re-reads them (tests that flip a knob between calls).  SAM3_LORA_SINGLE_ROUND
  * changes the layout of packed blobs and saved t: blobs made before a flip must be re-packed. */
 void sam3_lora_debug_reload_knobs(void);
