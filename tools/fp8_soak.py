@@ -72,11 +72,14 @@ def main():
                     hooks.append(m.register_forward_hook(lambda mod, inp, out, n=n: note(n, out)))
             try:
                 loss = full.step()
-            except Exception as e:
-                if not args.debug:
-                    raise
+            except Exception as e:      # (a non-finite matching cost raises inside scipy's assignment solver)
                 print(f"run {run} fp8 step {step}: {type(e).__name__}: {str(e)[:100]}", flush=True)
                 loss = torch.full((), float("nan"), device=dev)
+                if not args.debug:
+                    torch.cuda.synchronize()
+                    full.opt.zero_grad(set_to_none=True) if hasattr(full, "opt") else None
+                    flags.append(torch.ones((), dtype=torch.bool, device=dev))
+                    break
             for h in hooks:
                 h.remove()
             if args.debug:
