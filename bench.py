@@ -827,7 +827,14 @@ class FullStep:
             self.backward_end_event.record(torch.cuda.current_stream(self.dev))
         mark("backward")
         self.reducer.finish()
-        self.opt.step()
+        from sam3_lora_amd import fp8 as _fp8
+        if _fp8.fp8_enabled():              # the fp8 mode's trainer skips a step with non-finite gradients (trainer.NonFiniteStepGuard)
+            from sam3_lora_amd.trainer import NonFiniteStepGuard
+            if getattr(self, "_guard", None) is None or self._guard.optimizer is not self.opt:
+                self._guard = NonFiniteStepGuard(self.opt, self.dev)
+            self._guard.step()
+        else:
+            self.opt.step()
         self._repack(self.model)            # operand images of all adapters, batched (sam3_lora_pack_many)
         mark("exchange + AdamW")
         self.last_loss = loss

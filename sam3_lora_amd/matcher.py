@@ -55,6 +55,14 @@ def _solve(cost: np.ndarray, repeats: int, want_tgt: bool, filter_invalid: bool)
     """One image: rows = queries, cols = its targets (tiled ``repeats`` times for one-to-many)."""
     if repeats > 1:
         cost = np.tile(cost, (1, repeats))
+    if not np.isfinite(cost).all():
+        # the reference lets scipy raise here (a diverged run ends); in the fp8 frozen-W mode a non-finite forward is an event the
+        # trainer survives -- the loss and every gradient of the step are non-finite too and the optimizer step is skipped
+        # (trainer.NonFiniteStepGuard) -- so the assignment only has to exist
+        from . import fp8
+        if not fp8.fp8_enabled():
+            raise ValueError("matrix contains invalid numeric entries")
+        cost = np.nan_to_num(cost, nan=1e9, posinf=1e9, neginf=-1e9)
     rows, cols = linear_sum_assignment(cost)
     if filter_invalid:
         keep = cost[rows, cols] < VALID_THRESH

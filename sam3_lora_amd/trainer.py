@@ -206,6 +206,37 @@ def make_adamw(params, lr: float, weight_decay: float) -> AdamW:
     return AdamW(params, lr=lr, weight_decay=weight_decay)
 
 
+class NonFiniteStepGuard:
+    """fp8 frozen-W mode: an optimizer step whose A / B gradients are not all finite is SKIPPED -- what the reference's fp16 path gets from
+    ``GradScaler`` (native_trainer.py:902-903, 1014, 1155: ``scaler.step`` skips a step with non-finite gradients).  Delayed scaling quantises a tensor with the range of its predecessor; about one training
+    sequence in 400 of the soak (tools/fp8_soak.py, profiles/r06a*_fp8_soak_*) produced a backward pass with astronomically large or
+    non-finite gradients, never in the bf16 mode.  One fused check kernel over the gradients
+    (``torch._amp_foreach_non_finite_check_and_unscale_`` with scale 1) raises a device flag that torch's fused AdamW takes as ``found_inf``:
+    the update, the moments and the step counts stay untouched -- no host synchronisation.  ``skipped`` counts on the device."""
+
+    def __init__(self, optimizer, device):
+        self.optimizer = optimizer
+        self.found = torch.zeros((), device=device)
+        self.one = torch.ones((), device=device)
+        self.skipped = torch.zeros((), device=device)
+        self.fused = any(g.get("fused") for g in optimizer.param_groups)
+
+    def step(self) -> None:
+        grads = [p.grad for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+        self.found.zero_()
+        if grads:
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, self.found, self.one)
+        self.skipped += self.found
+        if self.fused:
+            self.optimizer.grad_scale, self.optimizer.found_inf = None, self.found
+            try:
+                self.optimizer.step()
+            finally:
+                self.optimizer.found_inf = None
+        elif not bool(self.found.item()):       # the unfused optimizers have no such input: one host round trip
+            self.optimizer.step()
+
+
 class SAM3TrainerNative:
     def __init__(self, config_path: str, model_builder: Optional[Callable] = None,
                  data_builder: Optional[Callable] = None, bf16_frozen: Optional[bool] = None,
@@ -342,7 +373,13 @@ class SAM3TrainerNative:
             self.reducer.finish()                   # leaves .grad = None on globally unused parameters
         else:
             self._drop_unused_grads()
-        self.optimizer.step()
+        from . import fp8
+        if fp8.fp8_enabled() and self.device.type == "cuda":
+            if getattr(self, "_nonfinite_guard", None) is None or self._nonfinite_guard.optimizer is not self.optimizer:
+                self._nonfinite_guard = NonFiniteStepGuard(self.optimizer, self.device)
+            self._nonfinite_guard.step()            # a step with non-finite gradients is skipped (counted in .skipped)
+        else:
+            self.optimizer.step()
         if self.device.type == "cuda":      # A / B just changed: refresh every adapter's operand images in one batch
             from .functional import repack_adapters
             repack_adapters(self.model)

@@ -342,3 +342,48 @@ def test_fused_fp8_linear_is_one_rounding_from_the_dequantised_oracle(M, fin, fo
     assert float(slots[1].max()) == float(a.abs().max().float())       # gathered for the next call
     monkeypatch.delenv("SAM3_LORA_SINGLE_ROUND", raising=False)
     _ffi.load().sam3_lora_debug_reload_knobs()
+
+
+def test_a_step_with_non_finite_gradients_is_skipped_on_the_device():
+    """trainer.NonFiniteStepGuard on the GPU with torch's fused AdamW (round 6): a trunk block in the fp8 frozen-W mode is stepped five
+    times; in the third step one incoming gradient element is made Inf.  That step must leave A / B, the moments and the step counts
+    untouched and be counted; the steps before and after it are ordinary updates."""
+    import lora_layers as L
+    from sam3_lora_amd import fp8
+    from sam3_lora_amd import vit as V
+    from sam3_lora_amd.trainer import NonFiniteStepGuard, make_adamw
+    torch.manual_seed(0)
+    blk = V.Block(256, 4, 4.0, True, 0.0, window_size=0, input_size=(8, 8), rope_pt_size=(8, 8), rope_interp=False)
+    blk.mlp.fc1, blk.mlp.fc2 = L.LoRALinear(blk.mlp.fc1, rank=8, alpha=16), L.LoRALinear(blk.mlp.fc2, rank=8, alpha=16)
+    with torch.no_grad():
+        blk.mlp.fc1.lora.lora_B.normal_(0, 0.02), blk.mlp.fc2.lora.lora_B.normal_(0, 0.02)
+    blk.to(DEV)
+    params = []
+    for n, p in blk.named_parameters():
+        if "lora_" in n:
+            params.append(p)
+        else:
+            p.requires_grad_(False)
+            p.data = p.data.to(torch.bfloat16)
+    opt = make_adamw(params, lr=1e-2, weight_decay=0.01)
+    guard = NonFiniteStepGuard(opt, torch.device(DEV))
+    assert guard.fused
+    fp8.enable_fp8_frozen(True)
+    try:
+        x = torch.randn(4, 8, 8, 256, device=DEV).bfloat16()
+        moved = []
+        for step in range(5):
+            opt.zero_grad(set_to_none=True)
+            y = blk(x)
+            w = torch.ones_like(y, dtype=torch.float32)
+            if step == 2:
+                w[0, 0, 0, 0] = float("inf")
+            (y.float() * w).mean().backward()
+            before = [p.detach().clone() for p in params]
+            guard.step()
+            moved.append(any(not torch.equal(a, b) for a, b in zip(before, params)))
+            assert all(bool(torch.isfinite(p).all()) for p in params)
+    finally:
+        fp8.enable_fp8_frozen(False)
+    assert moved == [True, True, False, True, True] and float(guard.skipped) == 1.0
+    assert all(float(st["step"]) == 4.0 for st in opt.state.values())

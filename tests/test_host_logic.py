@@ -274,3 +274,44 @@ def test_forward_refuses_cpu_tensors():
         root_api.LoRALinear(nn.Linear(16, 16))(torch.zeros(2, 16))
     with pytest.raises(LoRAKernelError, match="no CPU fallback"):
         pkg_api.LinearWithLoRA(nn.Linear(16, 16))(torch.zeros(2, 16))
+
+
+def test_nonfinite_step_guard_skips_the_update_and_counts_it():
+    """fp8 frozen-W mode (trainer.NonFiniteStepGuard): a step whose gradients are not all finite leaves the parameters, the moments and
+    the step counts untouched -- the reference's GradScaler behaviour (native_trainer.py:902-903) -- and the next finite step is an
+    ordinary AdamW step; with the unfused optimizer the same through one host test."""
+    import torch
+    from sam3_lora_amd.trainer import NonFiniteStepGuard
+    for fused in (True, False):
+        p = [torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(3))]
+        try:
+            opt = torch.optim.AdamW(p, lr=0.1, weight_decay=0.0, fused=fused)
+        except (RuntimeError, TypeError):
+            continue
+        guard = NonFiniteStepGuard(opt, torch.device("cpu"))
+        p[0].grad, p[1].grad = torch.tensor([1.0, float("inf"), 0.0, 0.0]), torch.ones(3)
+        guard.step()
+        assert torch.equal(p[0].data, torch.ones(4)) and torch.equal(p[1].data, torch.ones(3)) and float(guard.skipped) == 1.0
+        assert not opt.state or all(float(st["step"]) == 0.0 for st in opt.state.values())
+        p[0].grad = torch.tensor([float("nan"), 0.0, 0.0, 0.0])
+        guard.step()
+        assert torch.equal(p[0].data, torch.ones(4)) and float(guard.skipped) == 2.0
+        p[0].grad = torch.ones(4)
+        guard.step()
+        assert float(guard.skipped) == 2.0 and torch.allclose(p[0].data, torch.full((4,), 0.9), atol=1e-3)
+        assert all(float(st["step"]) == 1.0 for st in opt.state.values())
+
+
+def test_matcher_raises_on_a_nonfinite_cost_like_the_reference_unless_the_fp8_mode_is_on():
+    import numpy as np
+    import pytest as _pytest
+    from sam3_lora_amd import fp8, matcher
+    cost = np.array([[0.1, np.nan], [0.3, 0.2]])
+    with _pytest.raises(ValueError):
+        matcher._solve(cost, 1, True, False)
+    fp8.enable_fp8_frozen(True)
+    try:
+        rows, cols = matcher._solve(cost, 1, True, False)
+        assert sorted(rows.tolist()) == [0, 1] and sorted(cols.tolist()) == [0, 1]
+    finally:
+        fp8.enable_fp8_frozen(False)
